@@ -1,0 +1,281 @@
+"""akaze_hip -- Python host mirror of the CUDA-AKAZE interface over libhipakaze's C ABI.
+
+This is harness code (tests, bench): the product is the C-ABI shared library
+``cuda-akaze_amd/libhipakaze.so`` and the C++ header ``include/akaze.h``.  The
+names below follow the reference's API (akaze.h:10-30, akaze_structures.h:19-59)
+so the parity tests read like the reference's demo (main.cpp:128-233):
+
+    initAkazeData / freeAkazeData / cuMatch / Akazer.init / Akazer.detectAndCompute
+
+There is NO CPU fallback: importing works anywhere (the library loads without a
+GPU so symbol tests can run), but every compute call raises ``HakError`` when no
+HIP device is usable, and a missing ``libhipakaze.so`` raises at import.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhipakaze.so")
+
+FLEN = 61            # akaze_structures.h:29
+MAX_DIST = 96        # akazed.cu:11
+PM_G1, PM_G2, WEICKERT, CHARBONNIER = 0, 1, 2, 3   # akaze_structures.h:53-59
+
+# akaze_structures.h:19-40 (104 bytes; numpy adds the 3 padding bytes explicitly)
+POINT_DTYPE = np.dtype([
+    ("x", "<f4"), ("y", "<f4"), ("octave", "<i4"), ("response", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+    ("features", "u1", (FLEN,)), ("_pad", "u1", (3,)),
+    ("match", "<i4"), ("distance", "<i4"), ("match_x", "<f4"), ("match_y", "<f4"),
+])
+assert POINT_DTYPE.itemsize == 104
+
+
+class HakError(RuntimeError):
+    pass
+
+
+class hak_config(C.Structure):
+    _fields_ = [
+        ("noctaves", C.c_int), ("max_scale", C.c_int), ("per", C.c_float), ("kcontrast", C.c_float),
+        ("soffset", C.c_float), ("reordering", C.c_int), ("derivative_factor", C.c_float),
+        ("dthreshold", C.c_float), ("diffusivity", C.c_int), ("descriptor_pattern_size", C.c_int),
+        ("max_pts", C.c_int), ("upright", C.c_int), ("batch", C.c_int),
+    ]
+
+
+class hak_traffic(C.Structure):
+    _fields_ = [("fed_px_steps", C.c_double), ("fed_bytes", C.c_double), ("all_stage_bytes", C.c_double),
+                ("fed_launches", C.c_int)]
+
+
+PROF = dict(fed=0, lowpass=1, flow=2, hessian=3, contrast=4, down=5, extrema=6, nms=7, describe=8, match=9)
+
+# every symbol include/hipakaze.h declares: name -> (restype, argtypes)
+_vp, _fp, _ip = C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int)
+SYMBOLS = {
+    "hak_device_count": (C.c_int, []),
+    "hak_set_device": (C.c_int, [C.c_int]),
+    "hak_last_error": (C.c_char_p, []),
+    "hak_default_config": (None, [C.POINTER(hak_config)]),
+    "hak_create": (C.c_int, [C.POINTER(hak_config), C.c_int, C.c_int, C.POINTER(_vp)]),
+    "hak_destroy": (None, [_vp]),
+    "hak_set_stream": (C.c_int, [_vp, _vp]),
+    "hak_sync": (C.c_int, [_vp]),
+    "hak_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
+    "hak_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "hak_match": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
+    "hak_match_batch": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "hak_points_alloc": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "hak_points_free": (C.c_int, [_vp]),
+    "hak_image_alloc": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _ip]),
+    "hak_image_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
+    "hak_image_free": (C.c_int, [_vp]),
+    "hak_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_long]),
+    "hak_host_free": (C.c_int, [_vp]),
+    "hak_download_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),
+    "hak_memcpy_d2h": (C.c_int, [_vp, _vp, C.c_long]),
+    "hak_memcpy_h2d": (C.c_int, [_vp, _vp, C.c_long]),
+    "hak_fed_tau": (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_int, _fp, C.c_int]),
+    "hak_gauss_taps": (None, [C.c_float, C.c_int, _fp]),
+    "hak_compare_indices": (None, [_ip, _ip]),
+    "hak_query_schedule": (C.c_int, [_vp, _ip, _ip, _fp, _fp]),
+    "hak_query_geometry": (C.c_int, [_vp, _ip]),
+    "hak_debug_plane": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "hak_debug_kcontrast": (C.c_int, [_vp, C.c_int, _fp]),
+    "hak_query_traffic": (C.c_int, [_vp, C.c_int, C.POINTER(hak_traffic)]),
+    "hak_prof_enable": (C.c_int, [_vp, C.c_int]),
+    "hak_prof_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _ip]),
+    "hak_prof_reset": (C.c_int, [_vp]),
+    "hak_op_lowpass": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
+    "hak_op_down_smooth": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hak_op_kcontrast": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _ip]),
+    "hak_op_flow": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
+    "hak_op_nld_steps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, C.c_int]),
+    "hak_op_hessian": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+}
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(there is no CPU fallback for the HIP path)")
+lib = C.CDLL(LIB_PATH)
+for _name, (_res, _args) in SYMBOLS.items():
+    _f = getattr(lib, _name)          # AttributeError here = ABI drift between header and library
+    _f.restype = _res
+    _f.argtypes = _args
+
+
+def check(status):
+    if status != 0:
+        raise HakError(lib.hak_last_error().decode() or f"libhipakaze status {status}")
+
+
+def iAlignUp(a, b):
+    """cuda_utils.h:160"""
+    return a - a % b + b if a % b else a
+
+
+def device_count():
+    return lib.hak_device_count()
+
+
+def default_config(**kw):
+    cfg = hak_config()
+    lib.hak_default_config(C.byref(cfg))
+    for k, v in kw.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+# ----------------------------------------------------------------- host helpers
+def fed_tau(T, M=1, tau_max=0.25, reordering=True):
+    buf = np.zeros(4096, np.float32)
+    n = lib.hak_fed_tau(T, M, tau_max, int(reordering), buf.ctypes.data_as(_fp), 4096)
+    if n < 0:
+        raise HakError("FED cycle too long")
+    return buf[:n].copy()
+
+
+def gauss_taps(var, radius):
+    buf = np.zeros(8, np.float32)
+    lib.hak_gauss_taps(var, radius, buf.ctypes.data_as(_fp))
+    return buf[:radius + 1].copy()
+
+
+def compare_indices():
+    a = np.zeros(488, np.int32)
+    b = np.zeros(488, np.int32)
+    lib.hak_compare_indices(a.ctypes.data_as(_ip), b.ctypes.data_as(_ip))
+    return a, b
+
+
+# ------------------------------------------------------ reference-shaped API
+class AkazeData:
+    """akaze_structures.h:44-50 {num_pts, max_pts, h_data, d_data}"""
+
+    def __init__(self):
+        self.num_pts = 0
+        self.max_pts = 0
+        self.h_data = None      # numpy structured array (POINT_DTYPE) or None
+        self.d_data = None      # device pointer (int) or None
+
+
+def initAkazeData(data, max_pts, host, dev):
+    """akaze.cpp:26-40"""
+    data.num_pts = 0
+    data.max_pts = max_pts
+    data.h_data = np.zeros(max_pts, POINT_DTYPE) if host else None
+    data.d_data = None
+    if dev:
+        p = _vp()
+        check(lib.hak_points_alloc(C.byref(p), max_pts))
+        data.d_data = p.value
+
+
+def freeAkazeData(data):
+    """akaze.cpp:43-52"""
+    if data.d_data is not None:
+        check(lib.hak_points_free(data.d_data))
+    data.d_data = None
+    data.h_data = None
+    data.num_pts = 0
+    data.max_pts = 0
+
+
+class Akazer:
+    """akaze.h:18-67.  ``whp0`` is (width, height, pitch) like the reference's int3."""
+
+    def __init__(self):
+        self._ctx = None
+        self._cfg = default_config()
+        self.whp = (0, 0, 0)
+
+    def init(self, whp0, noctaves=4, max_scale=4, per=0.7, kcontrast=0.03, soffset=1.6, reordering=True,
+             derivative_factor=1.5, dthreshold=0.001, diffusivity=PM_G2, descriptor_pattern_size=10,
+             max_pts=10000, upright=False, batch=1):
+        self.whp = tuple(whp0)
+        self._cfg = default_config(
+            noctaves=noctaves, max_scale=max_scale, per=per, kcontrast=kcontrast, soffset=soffset,
+            reordering=int(reordering), derivative_factor=derivative_factor, dthreshold=dthreshold,
+            diffusivity=int(diffusivity), descriptor_pattern_size=descriptor_pattern_size,
+            max_pts=max_pts, upright=int(upright), batch=batch)
+        self._make_ctx(self.whp[0], self.whp[1])
+
+    def _make_ctx(self, w, h):
+        self.close()
+        ctx = _vp()
+        check(lib.hak_create(C.byref(self._cfg), w, h, C.byref(ctx)))
+        self._ctx = ctx
+        self._ctx_wh = (w, h)
+
+    @property
+    def ctx(self):
+        if self._ctx is None:
+            raise HakError("Akazer.init() has not been called")
+        return self._ctx
+
+    def detectAndCompute(self, image, result, whp0, desc=True):
+        """akaze.cpp:101-150.  ``image`` = device pointer (int) to float32 [0,1], pitch whp0[2]."""
+        w, h, p = whp0
+        if self._ctx is None or self._ctx_wh != (w, h):       # akaze.cpp:109: size differs from init -> new arena
+            self._make_ctx(w, h)
+        if result.max_pts < self._cfg.max_pts:
+            raise HakError("AkazeData smaller than the detector's max_pts")
+        n = C.c_int(0)
+        hptr = result.h_data.ctypes.data if result.h_data is not None else None
+        check(lib.hak_detect_and_compute(self.ctx, image, p, result.d_data, result.max_pts, C.byref(n), hptr, int(desc)))
+        result.num_pts = n.value
+
+    def fastDetectAndCompute(self, image, result, whp0, desc=True):
+        """akaze.h:30 -- integer FAST path: out of scope this round."""
+        raise HakError("fastDetectAndCompute (16.16 fixed-point path) is not implemented")
+
+    # -- introspection used by tests
+    def plane(self, kind, octave, sublevel, img=0):
+        whp = self.geometry()[octave]
+        out = np.zeros((whp[1], whp[0]), np.float32)
+        check(lib.hak_debug_plane(self.ctx, img, kind, octave, sublevel, out.ctypes.data))
+        return out
+
+    def kcontrast(self, img=0):
+        v = C.c_float()
+        check(lib.hak_debug_kcontrast(self.ctx, img, C.byref(v)))
+        return v.value
+
+    def geometry(self):
+        buf = np.zeros(3 * 8, np.int32)
+        n = lib.hak_query_geometry(self.ctx, buf.ctypes.data_as(_ip))
+        return [tuple(int(v) for v in buf[3 * o:3 * o + 3]) for o in range(n)]
+
+    def schedule(self):
+        ns = np.zeros(40, np.int32); ss = np.zeros(40, np.int32)
+        sz = np.zeros(40, np.float32); bd = np.zeros(40, np.float32)
+        n = lib.hak_query_schedule(self.ctx, ns.ctypes.data_as(_ip), ss.ctypes.data_as(_ip),
+                                   sz.ctypes.data_as(_fp), bd.ctypes.data_as(_fp))
+        m = n * self._cfg.max_scale
+        return dict(noct=n, nsteps=ns[:m].copy(), sigma_size=ss[:m].copy(), sizes=sz[:m].copy(), borders=bd[:m].copy())
+
+    def traffic(self, npts_hint=0):
+        t = hak_traffic()
+        check(lib.hak_query_traffic(self.ctx, npts_hint, C.byref(t)))
+        return t
+
+    def close(self):
+        if self._ctx is not None:
+            lib.hak_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def cuMatch(result1, result2, akazer=None):
+    """akaze.h:14, akaze.cpp:55-64: fills match/distance/match_x/match_y of result1."""
+    ctx = akazer.ctx if akazer is not None else None
+    hptr = result1.h_data.ctypes.data if result1.h_data is not None else None
+    check(lib.hak_match(ctx, result1.d_data, result1.num_pts, result2.d_data, result2.num_pts, hptr))

@@ -1,0 +1,662 @@
+// hak_api.hip -- C ABI of libhipakaze: context, FED schedule, launch sequence.
+//
+// Host orchestration restates Akazer::detectAndCompute / detect
+// (akaze.cpp:101-150, 240-503) with every per-image scalar kept on the device
+// (kcontrast, point counts), one launch sequence per BATCH of images
+// (blockIdx.z = image) and no host synchronisation inside the sequence.
+#include "hak_internal.h"
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+static int fail(const std::string& m) { g_err = m; return 1; }
+#define HIP_TRY(call)                                                                           \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(std::string(#call) + ": " + hipGetErrorString(e__));                    \
+    } while (0)
+
+extern "C" const char* hak_last_error(void) { return g_err.c_str(); }
+
+extern "C" int hak_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int hak_set_device(int dev)
+{
+    int n = hak_device_count();
+    if (n == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    dev = dev < 0 ? 0 : (dev >= n ? n - 1 : dev);                   // cuda_utils.h:50
+    HIP_TRY(hipSetDevice(dev));
+    return 0;
+}
+
+extern "C" void hak_default_config(hak_config* c)
+{
+    c->noctaves = 4; c->max_scale = 4; c->per = 0.7f; c->kcontrast = 0.03f; c->soffset = 1.6f;
+    c->reordering = 1; c->derivative_factor = 1.5f; c->dthreshold = 0.001f; c->diffusivity = HAK_PM_G2;
+    c->descriptor_pattern_size = 10; c->max_pts = 10000; c->upright = 0; c->batch = 1;
+}
+
+// --------------------------------------------------- host-side schedule math
+static bool fed_is_prime(int number)                                // fed.cpp:128-148
+{
+    if (number <= 1) return false;
+    if (number == 2 || number == 3 || number == 5 || number == 7) return true;
+    if (number % 2 == 0 || number % 3 == 0 || number % 5 == 0 || number % 7 == 0) return false;
+    int upper = (int)std::sqrt(number + 1.0);
+    for (int d = 11; d <= upper; d += 2)
+        if (number % d == 0) return false;
+    return true;
+}
+
+extern "C" int hak_fed_tau(float T, int M, float tau_max, int reordering, float* tau, int cap)
+{
+    // fed.cpp:41-119; mixed float/double arithmetic as in the source
+    const float t = T / (float)M;
+    const int n = (int)(std::ceil(std::sqrt(3.0 * t / tau_max + 0.25f) - 0.5f - 1.0e-8f) + 0.5f);
+    if (n <= 0) return 0;
+    if (n > cap) return -n;
+    const float scale = (float)(3.0 * t / (tau_max * (float)(n * (n + 1))));
+    const float c = 1.0f / (4.0f * (float)n + 2.0f);
+    const float d = scale * tau_max / 2.0f;
+    std::vector<float> tauh(n);
+    for (int k = 0; k < n; ++k) {
+        float hh = (float)std::cos(HAK_PI_D * (2.0f * (float)k + 1.0f) * c);
+        tauh[k] = d / (hh * hh);
+    }
+    if (!reordering) {
+        for (int k = 0; k < n; k++) tau[k] = tauh[k];
+        return n;
+    }
+    const int kappa = n / 2;
+    int prime = n + 1;
+    while (!fed_is_prime(prime)) prime++;
+    for (int k = 0, l = 0; l < n; ++k, ++l) {
+        int index;
+        while ((index = ((k + 1) * kappa) % prime - 1) >= n) k++;
+        tau[l] = tauh[index];
+    }
+    return n;
+}
+
+extern "C" void hak_gauss_taps(float var, int radius, float* taps)
+{
+    // akazed.cu:2298-2333
+    const float denom = 1.f / (2.f * var);
+    float ksum = 0;
+    for (int i = 0; i <= radius; i++) {
+        taps[i] = expf(-i * i * denom);
+        ksum += (i == 0) ? taps[i] : taps[i] + taps[i];
+    }
+    ksum = 1 / ksum;
+    for (int i = 0; i <= radius; i++) taps[i] *= ksum;
+}
+
+extern "C" void hak_compare_indices(int* idx1, int* idx2)
+{
+    // akazed.cu:65-159: per grid (2x2 cells 0-3, 3x3 cells 4-12, 4x4 cells 13-28), channel-major, pairs j<i
+    static const int lo[3] = {0, 4, 13}, hi[3] = {4, 13, 29};
+    int n = 0;
+    for (int g = 0; g < 3; g++)
+        for (int ch = 0; ch < 3; ch++)
+            for (int j = lo[g]; j < hi[g] - 1; ++j)
+                for (int i = j + 1; i < hi[g]; ++i) {
+                    idx1[n] = 3 * j + ch;
+                    idx2[n] = 3 * i + ch;
+                    n++;
+                }
+    for (; n < 488; n++) idx1[n] = idx2[n] = 0;
+}
+
+// ----------------------------------------------------------------- context
+struct LevelPlan {
+    int nsteps = 0;
+    std::vector<float> tau;
+    int sigma_size = 0;
+    float size = 0, border = 0;
+};
+
+struct ProfClass {
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    double acc_ms = 0;
+    int launches = 0;
+};
+
+struct hak_ctx {
+    hak_config cfg;
+    HakLayout L;
+    HakTables htab;
+    HakTables* dtab = nullptr;
+    std::vector<LevelPlan> plan;    // [noct*ms]
+    float taps1[8], taps_base[8];
+    int base_R = 4;
+    int psz = 28;
+    float* arena = nullptr;
+    unsigned long long* maps = nullptr;
+    unsigned long long* bitmap = nullptr;
+    int* rowcount = nullptr;
+    HakImgState* state = nullptr;
+    int* d_num = nullptr;           // [batch] counts for the synchronous entry points
+    int* h_num = nullptr;           // pinned
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    bool prof_on = false;
+    ProfClass prof[HAK_PROF_COUNT];
+    int fed_launches = 0;
+};
+
+static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
+
+struct ProfScope {
+    hak_ctx* c; int k; hipEvent_t stop = nullptr;
+    ProfScope(hak_ctx* ctx, int klass) : c(ctx), k(klass)
+    {
+        if (!c->prof_on) return;
+        ProfClass& p = c->prof[k];
+        if (p.used + 2 > p.ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            p.ev.push_back(a); p.ev.push_back(b);
+        }
+        (void)hipEventRecord(p.ev[p.used], c->stream);
+        stop = p.ev[p.used + 1];
+        p.used += 2;
+        p.launches++;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, c->stream); }
+};
+
+static int build_plan(hak_ctx* c, int w, int h)
+{
+    const hak_config& cfg = c->cfg;
+    if (cfg.noctaves < 1 || cfg.noctaves > HAK_MAX_OCTAVES) return fail("noctaves out of range");
+    if (cfg.max_scale < 1 || cfg.max_scale > HAK_MAX_SCALES) return fail("max_scale out of range");
+    if (w < 80 || h < 80) return fail("image smaller than 80 px");
+    HakLayout& L = c->L;
+    memset(&L, 0, sizeof(L));
+    L.ms = cfg.max_scale;
+    // akaze.cpp:204-237 allocMemory; octave count fixed up front
+    int noct = 1;
+    L.oct[0] = {w, h, align_up(w, 64), 0};
+    for (int j = 1; j < cfg.noctaves; j++) {
+        int ww = L.oct[j - 1].w >> 1, hh = L.oct[j - 1].h >> 1;
+        if (ww < 80 || hh < 80) break;
+        L.oct[j] = {ww, hh, align_up(ww, 64), 0};
+        noct = j + 1;
+    }
+    L.noct = noct;
+    long off = 0;
+    for (int o = 0; o < noct; o++) {
+        L.oct[o].plane = (long)L.oct[o].h * L.oct[o].p;
+        L.lvl_off[o] = off;       off += 4L * L.ms * L.oct[o].plane;
+        L.smooth_off[o] = off;    off += L.oct[o].plane;
+        L.flow_off[o] = off;      off += L.oct[o].plane;
+        L.tmp_off[o] = off;       off += L.oct[o].plane;
+    }
+    L.arena = off;
+
+    // akaze.cpp:268-439 schedule
+    c->plan.assign((size_t)noct * L.ms, LevelPlan());
+    const float tmax = 0.25f;
+    float esigma = cfg.soffset;
+    float last_etime = (float)(0.5 * cfg.soffset * cfg.soffset);                 // akaze.cpp:270
+    const float smax = (float)(10.0 * sqrtf(2.0f));                               // akaze.cpp:279 (MLDB)
+    int oratio = 1;
+    float psz = 10000;
+    float tau[4096];
+    for (int i = 0; i < noct; i++) {
+        for (int j = 0; j < L.ms; j++) {
+            LevelPlan& lp = c->plan[(size_t)i * L.ms + j];
+            if (i == 0 && j == 0) {
+                lp.size = esigma * cfg.derivative_factor;                         // akaze.cpp:336-338
+                lp.sigma_size = (int)(esigma * cfg.derivative_factor + 0.5f);
+                lp.border = smax * lp.sigma_size;
+                continue;
+            }
+            esigma = cfg.soffset * powf(2, (float)j / L.ms + i);                  // akaze.cpp:357
+            float curr_etime = 0.5f * esigma * esigma;
+            float ttime = curr_etime - last_etime;
+            int n = hak_fed_tau(ttime, 1, tmax, cfg.reordering, tau, 4096);
+            if (n < 0) return fail("FED cycle longer than 4096 steps");
+            if (n == 0) return fail("FED cycle with zero steps (non-increasing scale schedule)");
+            lp.nsteps = n;
+            lp.tau.assign(tau, tau + n);
+            lp.size = esigma * cfg.derivative_factor / oratio;
+            lp.sigma_size = (int)(lp.size + 0.5f);
+            lp.border = smax * lp.sigma_size;
+            last_etime = curr_etime;
+        }
+        float b0 = c->plan[(size_t)i * L.ms].border * oratio;
+        psz = psz < b0 ? psz : b0;                                                // akaze.cpp:434
+        oratio *= 2;
+    }
+    c->psz = (int)psz;
+    memset(&c->htab, 0, sizeof(c->htab));
+    for (int l = 0; l < noct * L.ms; l++) {
+        c->htab.sizes[l] = c->plan[l].size;
+        c->htab.borders[l] = c->plan[l].border;
+        c->htab.sigma_size[l] = c->plan[l].sigma_size;
+    }
+    for (int r2 = 0; r2 < 36; r2++) c->htab.orient_w[r2] = hak_expf(-r2 * 0.08f);  // akazed.cu:1697
+    hak_compare_indices(c->htab.comp1, c->htab.comp2);
+    hak_gauss_taps(1.f, 2, c->taps1);
+    int ksz = (int)(2 * ceilf((cfg.soffset - 0.8f) / 0.3f) + 3);                 // akaze.cpp:328
+    c->base_R = ksz <= 5 ? 2 : ksz <= 7 ? 3 : ksz <= 9 ? 4 : 5;                   // akazed.cu:2345-2377
+    if (ksz > 11) return fail("Kernels larger than 11 not implemented");
+    hak_gauss_taps(cfg.soffset * cfg.soffset, c->base_R, c->taps_base);
+    return 0;
+}
+
+extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
+{
+    if (!cfg || !out) return fail("null argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    hak_ctx* c = new hak_ctx();
+    c->cfg = *cfg;
+    if (c->cfg.batch < 1) c->cfg.batch = 1;
+    if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
+    if (build_plan(c, w, h)) { delete c; return 1; }
+    const int B = c->cfg.batch;
+    const HakLayout& L = c->L;
+    const int words = (L.oct[0].w + 63) / 64;
+    hipError_t e = hipSuccess;
+    auto A = [&](void** p, size_t bytes) { if (e == hipSuccess) e = hipMalloc(p, bytes); };
+    A((void**)&c->arena, sizeof(float) * (size_t)L.arena * B);
+    A((void**)&c->maps, sizeof(unsigned long long) * (size_t)L.oct[0].plane * B);
+    A((void**)&c->bitmap, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
+    A((void**)&c->rowcount, sizeof(int) * (size_t)L.oct[0].h * B);
+    A((void**)&c->state, sizeof(HakImgState) * (size_t)B);
+    A((void**)&c->d_num, sizeof(int) * (size_t)B);
+    A((void**)&c->dtab, sizeof(HakTables));
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_num, sizeof(int) * (size_t)B);
+    if (e == hipSuccess) e = hipMemcpy(c->dtab, &c->htab, sizeof(HakTables), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+        fail(std::string("hak_create: ") + hipGetErrorString(e));
+        hak_destroy(c);
+        return 1;
+    }
+    c->stream = c->own_stream;
+    *out = c;
+    return 0;
+}
+
+extern "C" void hak_destroy(hak_ctx* c)
+{
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& p : c->prof)
+        for (auto ev : p.ev) (void)hipEventDestroy(ev);
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->state, c->d_num, c->dtab};
+    for (void* b : bufs) (void)hipFree(b);
+    if (c->h_num) (void)hipHostFree(c->h_num);
+    if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+extern "C" int hak_set_stream(hak_ctx* c, void* s)
+{
+    if (!c) return fail("null context");
+    c->stream = s ? (hipStream_t)s : c->own_stream;
+    return 0;
+}
+
+extern "C" int hak_sync(hak_ctx* c)
+{
+    if (!c) return fail("null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+// ------------------------------------------------------- the launch sequence
+static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
+                          hak_point* d_points, int* d_num_pts, int desc)
+{
+    const hak_config& cfg = c->cfg;
+    const HakLayout& L = c->L;
+    hipStream_t st = c->stream;
+    float* A = c->arena;
+    const long S = L.arena;
+    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount};
+    c->fed_launches = 0;
+
+    hak_launch_reset_state(st, c->state, nimg);
+    if (hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * nimg, st) != hipSuccess)
+        return fail("memset maps");
+
+    for (int o = 0; o < L.noct; o++) {
+        const HakOct oc = L.oct[o];
+        float* smooth = A + L.smooth_off[o];
+        float* flow = A + L.flow_off[o];
+        float* tmp = A + L.tmp_off[o];
+        for (int s = 0; s < L.ms; s++) {
+            const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
+            float* Lt = A + L.lt(o, s);
+            if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
+                { ProfScope ps(c, HAK_PROF_LOWPASS);
+                  hak_launch_lowpass(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->taps1, 2); }
+                { ProfScope ps(c, HAK_PROF_CONTRAST);
+                  hak_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct); }
+                { ProfScope ps(c, HAK_PROF_LOWPASS);
+                  hak_launch_lowpass(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps_base, c->base_R); }
+                { ProfScope ps(c, HAK_PROF_HESSIAN);
+                  hak_launch_derivate(st, Lt, A + L.lx(o, s), A + L.ly(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                  hak_launch_hessian(st, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+                continue;
+            }
+            const int n = lp.nsteps;
+            const float* fsrc;          // input of the first FED step
+            if (s == 0) {                                                         // akaze.cpp:369-392
+                // decimate Lt(o-1,0) so that the last of n ping-pong steps lands in Lt(o,0)
+                float* first = (n % 2 == 0) ? Lt : tmp;
+                { ProfScope ps(c, HAK_PROF_DOWN);
+                  hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1); }
+                fsrc = first;
+            } else {                                                              // akaze.cpp:393-421
+                { ProfScope ps(c, HAK_PROF_LOWPASS);
+                  hak_launch_lowpass(st, A + L.lt(o, s - 1), S, oc.p, smooth, S, oc.w, oc.h, oc.p, nimg, c->taps1, 2); }
+                fsrc = A + L.lt(o, s - 1);
+            }
+            { ProfScope ps(c, HAK_PROF_FLOW);
+              hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f); }
+            {
+                // n explicit steps, ping-pong between Lt and tmp, ending in Lt
+                const float* src = fsrc;
+                for (int k = 0; k < n; k++) {
+                    float* dst;
+                    if (s == 0) dst = (src == Lt) ? tmp : Lt;
+                    else dst = ((n - k) % 2 == 1) ? Lt : tmp;
+                    ProfScope ps(c, HAK_PROF_FED);
+                    hak_launch_fed_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, 0.5f * lp.tau[k]);   // akazed.cu:2515
+                    c->fed_launches++;
+                    src = dst;
+                }
+            }
+            { ProfScope ps(c, HAK_PROF_HESSIAN);                                  // akaze.cpp:423
+              hak_launch_derivate(st, smooth, A + L.lx(o, s), A + L.ly(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+              hak_launch_hessian(st, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+        }
+        { ProfScope ps(c, HAK_PROF_EXTREMA);                                      // akaze.cpp:431-433
+          hak_launch_extrema(st, b, L, c->dtab, o, cfg.dthreshold); }
+    }
+    { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
+      hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts); }
+    { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
+      hak_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
+    if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    return 0;
+}
+
+extern "C" int hak_detect_and_compute_batch(hak_ctx* c, const float* d_images, long image_stride, int pitch,
+                                            int nimg, hak_point* d_points, int* d_num_pts, int desc)
+{
+    if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
+    if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
+    if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+}
+
+extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitch, hak_point* d_points, int max_pts,
+                                      int* num_pts, hak_point* h_points, int desc)
+{
+    if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
+    if (max_pts < c->cfg.max_pts) return fail("point array smaller than cfg.max_pts");
+    if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    if (enqueue_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
+    HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *num_pts = c->h_num[0];
+    if (h_points && *num_pts > 0)                                                 // akaze.cpp:134-139
+        HIP_TRY(hipMemcpy(h_points, d_points, sizeof(hak_point) * (size_t)*num_pts, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point* d_pts2, int n2, hak_point* h_pts1)
+{
+    // ctx may be NULL (cuMatch is a free function in the reference): default stream, no profiling
+    if (!d_pts1 || (!d_pts2 && n2 > 0)) return fail("null argument");
+    if (n1 <= 0) return 0;
+    hipStream_t st = c ? c->stream : nullptr;
+    if (c) {
+        ProfScope ps(c, HAK_PROF_MATCH);
+        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1);
+    } else {
+        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1);
+    }
+    if (hipGetLastError() != hipSuccess) return fail("match launch failed");
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h_pts1)                                                                   // akaze.cpp:58-63
+        HIP_TRY(hipMemcpy2D(&h_pts1[0].match, sizeof(hak_point), &d_pts1[0].match, sizeof(hak_point), 16, n1,
+                            hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num_pts, int npairs)
+{
+    if (!c || !d_points || !d_num_pts || npairs < 1) return fail("bad argument");
+    const long mp = c->cfg.max_pts;
+    { ProfScope ps(c, HAK_PROF_MATCH);
+      hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs); }
+    if (hipGetLastError() != hipSuccess) return fail("match launch failed");
+    return 0;
+}
+
+// ----------------------------------------------------------- memory helpers
+extern "C" int hak_points_alloc(hak_point** d, int count)
+{
+    HIP_TRY(hipMalloc((void**)d, sizeof(hak_point) * (size_t)count));
+    HIP_TRY(hipMemset(*d, 0, sizeof(hak_point) * (size_t)count));
+    return 0;
+}
+extern "C" int hak_points_free(hak_point* d) { HIP_TRY(hipFree(d)); return 0; }
+
+extern "C" int hak_image_alloc(float** d, int w, int h, int* pitch)
+{
+    int p = (w % 128 != 0) ? (w - w % 128 + 128) : w;                             // cuda_utils.h:160, main.cpp:174
+    HIP_TRY(hipMalloc((void**)d, sizeof(float) * (size_t)p * h));
+    if (pitch) *pitch = p;
+    return 0;
+}
+extern "C" int hak_image_upload(float* d, int pitch, const float* hsrc, int w, int h)
+{
+    HIP_TRY(hipMemcpy2D(d, sizeof(float) * pitch, hsrc, sizeof(float) * w, sizeof(float) * w, h, hipMemcpyHostToDevice));
+    return 0;
+}
+extern "C" int hak_image_free(float* d) { HIP_TRY(hipFree(d)); return 0; }
+extern "C" int hak_host_alloc(void** p, long bytes) { HIP_TRY(hipHostMalloc(p, (size_t)bytes)); return 0; }
+extern "C" int hak_host_free(void* p) { HIP_TRY(hipHostFree(p)); return 0; }
+
+extern "C" int hak_download_batch(hak_ctx* c, const hak_point* d_points, const int* d_num_pts, int nimg,
+                                  hak_point* h_points, int* h_num_pts)
+{
+    if (!c || !d_points || !d_num_pts || !h_points || !h_num_pts) return fail("null argument");
+    HIP_TRY(hipMemcpyAsync(h_num_pts, d_num_pts, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const long mp = c->cfg.max_pts;
+    for (int i = 0; i < nimg; i++)
+        if (h_num_pts[i] > 0)
+            HIP_TRY(hipMemcpyAsync(h_points + i * mp, d_points + i * mp, sizeof(hak_point) * (size_t)h_num_pts[i],
+                                   hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int hak_memcpy_d2h(void* dst, const void* src, long bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+    return 0;
+}
+extern "C" int hak_memcpy_h2d(void* dst, const void* src, long bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+    return 0;
+}
+
+// ------------------------------------------------------------ introspection
+extern "C" int hak_query_schedule(const hak_ctx* c, int* nsteps, int* sigma_size, float* sizes, float* borders)
+{
+    if (!c) return -1;
+    for (size_t l = 0; l < c->plan.size(); l++) {
+        if (nsteps) nsteps[l] = c->plan[l].nsteps;
+        if (sigma_size) sigma_size[l] = c->plan[l].sigma_size;
+        if (sizes) sizes[l] = c->plan[l].size;
+        if (borders) borders[l] = c->plan[l].border;
+    }
+    return c->L.noct;
+}
+
+extern "C" int hak_query_geometry(const hak_ctx* c, int* whp)
+{
+    if (!c) return -1;
+    for (int o = 0; o < c->L.noct; o++) {
+        whp[3 * o] = c->L.oct[o].w; whp[3 * o + 1] = c->L.oct[o].h; whp[3 * o + 2] = c->L.oct[o].p;
+    }
+    return c->L.noct;
+}
+
+extern "C" int hak_debug_plane(hak_ctx* c, int img, int kind, int o, int s, float* h_dst)
+{
+    if (!c || img < 0 || img >= c->cfg.batch || o < 0 || o >= c->L.noct || s < 0 || s >= c->L.ms) return fail("bad plane");
+    const HakLayout& L = c->L;
+    long off = kind == HAK_PLANE_LT ? L.lt(o, s) : kind == HAK_PLANE_DET ? L.det(o, s) : kind == HAK_PLANE_LX ? L.lx(o, s) : L.ly(o, s);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy2D(h_dst, sizeof(float) * L.oct[o].w, c->arena + (long)img * L.arena + off, sizeof(float) * L.oct[o].p,
+                        sizeof(float) * L.oct[o].w, L.oct[o].h, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int hak_debug_kcontrast(hak_ctx* c, int img, float* kc)
+{
+    if (!c || img < 0 || img >= c->cfg.batch) return fail("bad image index");
+    HakImgState s;
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    HIP_TRY(hipMemcpy(&s, c->state + img, sizeof(s), hipMemcpyDeviceToHost));
+    *kc = s.kcontrast[0];
+    return 0;
+}
+
+extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* out)
+{
+    if (!c || !out) return fail("null argument");
+    const HakLayout& L = c->L;
+    double pxsteps = 0, all = 0;
+    int launches = 0;
+    for (int o = 0; o < L.noct; o++) {
+        const double N = (double)L.oct[o].w * L.oct[o].h;
+        for (int s = 0; s < L.ms; s++) {
+            const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
+            pxsteps += N * lp.nsteps;
+            launches += lp.nsteps;
+            if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue
+            else if (s == 0) all += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 8.0 * N + 8.0 * N + 24.0 * N + 4.0 * N;
+            else all += 44.0 * N;
+        }
+    }
+    all += 16.0 * L.oct[0].w * L.oct[0].h;                                        // maps init + NMS scan
+    all += 12.0 * pxsteps;
+    all += (872.0 + 5292.0 + 104.0) * npts_hint;
+    out->fed_px_steps = pxsteps;
+    out->fed_bytes = 12.0 * pxsteps;
+    out->all_stage_bytes = all;
+    out->fed_launches = launches;
+    return 0;
+}
+
+extern "C" int hak_prof_enable(hak_ctx* c, int on) { if (!c) return 1; c->prof_on = on != 0; return 0; }
+extern "C" int hak_prof_reset(hak_ctx* c)
+{
+    if (!c) return 1;
+    for (auto& p : c->prof) { p.used = 0; p.acc_ms = 0; p.launches = 0; }
+    return 0;
+}
+extern "C" int hak_prof_read(hak_ctx* c, int k, double* total_ms, int* launches)
+{
+    if (!c || k < 0 || k >= HAK_PROF_COUNT) return fail("bad profile class");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    ProfClass& p = c->prof[k];
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, p.ev[i], p.ev[i + 1]));
+        p.acc_ms += ms;
+    }
+    p.used = 0;
+    if (total_ms) *total_ms = p.acc_ms;
+    if (launches) *launches = p.launches;
+    return 0;
+}
+
+// ------------------------------------------------ single-stage test operators
+extern "C" int hak_op_lowpass(const float* s, float* d, int w, int h, int p, float var, int radius)
+{
+    if (radius < 1 || radius > 5) return fail("radius must be 1..5");
+    float taps[8];
+    hak_gauss_taps(var, radius, taps);
+    hak_launch_lowpass(nullptr, s, 0, p, d, 0, w, h, p, 1, taps, radius);
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int hak_op_down_smooth(const float* s, float* d, float* sm, int sw, int sh, int sp, int dw, int dh, int dp)
+{
+    float taps[8];
+    hak_gauss_taps(1.f, 2, taps);
+    HakOct so{sw, sh, sp, (long)sh * sp}, dd{dw, dh, dp, (long)dh * dp};
+    hak_launch_down_smooth(nullptr, s, d, sm, 0, so, dd, 1, taps);
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int hak_op_kcontrast(const float* smooth, int w, int h, int p, float per, float* kc, float* hmax, int* hist)
+{
+    HakImgState* st = nullptr;
+    HIP_TRY(hipMalloc((void**)&st, sizeof(HakImgState)));
+    hak_launch_reset_state(nullptr, st, 1);
+    hak_launch_contrast(nullptr, smooth, 0, w, h, p, 1, st, per, 1);
+    HakImgState hs;
+    HIP_TRY(hipMemcpy(&hs, st, sizeof(hs), hipMemcpyDeviceToHost));
+    HIP_TRY(hipFree(st));
+    if (kc) *kc = hs.kcontrast[0];
+    if (hmax) memcpy(hmax, &hs.hmax_bits, 4);
+    if (hist) memcpy(hist, hs.hist, sizeof(hs.hist));
+    return 0;
+}
+
+extern "C" int hak_op_flow(const float* s, float* d, int w, int h, int p, int diffusivity, float kcontrast)
+{
+    float ikc = 1.f / (kcontrast * kcontrast);                                    // akazed.cu:2493
+    hak_launch_flow(nullptr, s, d, 0, w, h, p, 1, diffusivity, nullptr, 0, ikc);
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst, float* tmp, int w, int h, int p,
+                                const float* tau, int nsteps)
+{
+    if (nsteps < 1) return fail("nsteps < 1");
+    if (p % 4) return fail("pitch must be a multiple of 4");
+    const float* s = src;
+    for (int k = 0; k < nsteps; k++) {
+        float* d = ((nsteps - k) % 2 == 1) ? dst : tmp;
+        hak_launch_fed_step(nullptr, s, flow, d, 0, w, h, p, 1, 0.5f * tau[k]);
+        s = d;
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, int w, int h, int p, int step)
+{
+    hak_launch_derivate(nullptr, s, lx, ly, 0, w, h, p, 1, step);
+    hak_launch_hessian(nullptr, lx, ly, det, 0, w, h, p, 1, step);
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}

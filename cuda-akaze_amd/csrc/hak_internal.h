@@ -1,0 +1,177 @@
+// hak_internal.h -- shared declarations of libhipakaze (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hipakaze.h"
+
+#define HAK_NBINS 300        // akazed.cu:8
+#define HAK_WAVE 64
+
+// ---------------------------------------------------------------- geometry
+struct HakOct {
+    int w, h, p;             // width, height, pitch (elements) of one octave plane
+    long plane;              // h * p
+};
+
+// Per-image arena (floats). Planes persist until the descriptors are done.
+//   per (octave o, sublevel s): Lt, det, Lx, Ly                 persistent
+//   per octave: smooth, flow, tmp                                scratch
+struct HakLayout {
+    int noct, ms;
+    HakOct oct[HAK_MAX_OCTAVES];
+    long lvl_off[HAK_MAX_OCTAVES];              // start of the 4*ms persistent planes of octave o
+    long smooth_off[HAK_MAX_OCTAVES], flow_off[HAK_MAX_OCTAVES], tmp_off[HAK_MAX_OCTAVES];
+    long arena;                                 // floats per image
+
+    __host__ __device__ long lt(int o, int s) const { return lvl_off[o] + (long)(0 * ms + s) * oct[o].plane; }
+    __host__ __device__ long det(int o, int s) const { return lvl_off[o] + (long)(1 * ms + s) * oct[o].plane; }
+    __host__ __device__ long lx(int o, int s) const { return lvl_off[o] + (long)(2 * ms + s) * oct[o].plane; }
+    __host__ __device__ long ly(int o, int s) const { return lvl_off[o] + (long)(3 * ms + s) * oct[o].plane; }
+};
+
+// Per-image device scalars.
+struct HakImgState {
+    unsigned int hmax_bits;                     // max Scharr gradient magnitude (float bits), floored at 0.03f
+    int hist[HAK_NBINS];
+    float kcontrast[HAK_MAX_OCTAVES];           // per octave: k0, k0*0.75, ...
+    float ikc[HAK_MAX_OCTAVES];                 // 1/(k*k)
+    int total_pts;                              // NMS survivors before clamping to max_pts
+    int num_pts;                                // min(total, max_pts)
+};
+
+// Read-only tables shared by all images of a context.
+struct HakTables {
+    float sizes[HAK_MAX_OCTAVES * HAK_MAX_SCALES];     // d_extrema_param sizes, per layer
+    float borders[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
+    int sigma_size[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
+    float orient_w[36];                                // exp(-r2*0.08f)
+    int comp1[488], comp2[488];                        // MLDB pair table (akazed.cu:65-159)
+};
+
+// ---------------------------------------------------------------- device helpers
+// reflect-101 as the reference: left/top abs(i), right/bottom borderAdd (akazed.cu:162-170)
+__device__ __forceinline__ int hak_refl(int i, int m)
+{
+    i = i < 0 ? -i : i;
+    i = i < m ? i : m + m - 2 - i;
+    // tiles hanging over the image can index past one reflection; those values are never used
+    i = i < 0 ? 0 : i;
+    return i < m ? i : m - 1;
+}
+
+// ------------------------------------------------- deterministic float32 math
+// Same operation sequence as the parity oracle's (oracle/okz_math.h): one IEEE
+// binary32 op per step, explicit fmaf only.  The reference's libdevice /
+// fast-math calls (akazed.cu:1697,1701,1887-1888) are not reproducible.
+#define HAK_PI_F  3.14159274101257324f
+#define HAK_HPI_F 1.57079637050628662f
+#define HAK_PI_D  3.14159265358979323846
+
+__host__ __device__ __forceinline__ void hak_sincosf(float a, float* s_out, float* c_out)
+{
+    float q = floorf(a * 0.636619747f + 0.5f);
+    float r = fmaf(q, -1.57079601287841796875f, a);
+    r = fmaf(q, -3.139164786504813217e-7f, r);
+    r = fmaf(q, -5.390302529957764765e-15f, r);
+    int n = ((int)q) & 3;
+    float r2 = r * r;
+    float sp = fmaf(r2, -1.9515295891e-4f, 8.3321608736e-3f);
+    sp = fmaf(sp, r2, -1.6666654611e-1f);
+    float sr = fmaf(r * r2, sp, r);
+    float cp = fmaf(r2, 2.443315711809948e-5f, -1.388731625493765e-3f);
+    cp = fmaf(cp, r2, 4.166664568298827e-2f);
+    float cr = fmaf(r2 * r2, cp, fmaf(r2, -0.5f, 1.0f));
+    float s, c;
+    if (n == 0)      { s = sr;  c = cr;  }
+    else if (n == 1) { s = cr;  c = -sr; }
+    else if (n == 2) { s = -sr; c = -cr; }
+    else             { s = -cr; c = sr;  }
+    *s_out = s;
+    *c_out = c;
+}
+
+__host__ __device__ __forceinline__ float hak_atan2f(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = ax > ay ? ax : ay;
+    float mn = ax > ay ? ay : ax;
+    if (mx == 0.0f) return 0.0f;
+    float a = mn / mx;
+    float t, base;
+    if (a > 0.4142135679721832275f) {
+        t = (a - 1.0f) / (a + 1.0f);
+        base = 0.785398185253143310546875f;
+    } else {
+        t = a;
+        base = 0.0f;
+    }
+    float z = t * t;
+    float p = fmaf(8.05374449538e-2f, z, -1.38776856032e-1f);
+    p = fmaf(p, z, 1.99777106478e-1f);
+    p = fmaf(p, z, -3.33329491539e-1f);
+    float r = base + fmaf(p * z, t, t);
+    if (ay > ax) r = HAK_HPI_F - r;
+    if (x < 0.0f) r = HAK_PI_F - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+
+__host__ __device__ __forceinline__ float hak_expf(float x)
+{
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float k = floorf(x * 1.44269502162933349609375f + 0.5f);
+    float r = fmaf(k, -0.693359375f, x);
+    r = fmaf(k, 2.12194440e-4f, r);
+    float p = fmaf(1.9875691500e-4f, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float e = fmaf(p, r * r, r) + 1.0f;
+    return ldexpf(e, (int)k);
+}
+
+// ---------------------------------------------------------------- launchers
+// (defined in the kernel files; all asynchronous on `st`; nimg = batch images,
+//  base = arena of image 0, stride = floats between image arenas)
+struct HakBatch {
+    float* base;                  // arena of image 0
+    long stride;                  // floats between consecutive image arenas
+    int nimg;
+    HakImgState* state;           // [nimg]
+    unsigned long long* maps;     // [nimg][map_stride] packed response/layer keys, full resolution
+    long map_stride;              // h0 * p0
+    unsigned long long* bitmap;   // [nimg][h0][ceil(w0/64)] NMS survivor bits
+    int* rowcount;                // [nimg][h0]
+};
+
+// scale space (kernels_scalespace.hip)
+void hak_launch_lowpass(hipStream_t st, const float* src, long src_stride, int src_pitch, float* dst, long dst_stride,
+                        int w, int h, int p, int nimg, const float* taps, int R);
+void hak_launch_down_smooth(hipStream_t st, const float* src, float* dst, float* smooth, long stride,
+                            HakOct so, HakOct dd, int nimg, const float* taps);
+void hak_launch_contrast(hipStream_t st, const float* smooth, long stride, int w, int h, int p, int nimg,
+                         HakImgState* state, float per, int noct);
+void hak_launch_reset_state(hipStream_t st, HakImgState* state, int nimg);
+void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, int w, int h, int p, int nimg,
+                     int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
+void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+                         int w, int h, int p, int nimg, float stepfac);
+void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly, long stride,
+                         int w, int h, int p, int nimg, int step);
+void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
+                        int w, int h, int p, int nimg, int step);
+
+// detector tail (kernels_detect.hip)
+void hak_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, float dthreshold);
+void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
+                         hak_point* points, int max_pts, int* num_out);
+
+// descriptors (kernels_describe.hip)
+void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
+                         hak_point* points, int max_pts, int patsize, int upright, int desc);
+
+// matcher (kernels_match.hip)
+void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
+                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs);

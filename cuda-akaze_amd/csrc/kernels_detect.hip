@@ -1,0 +1,209 @@
+// kernels_detect.hip -- Hessian-determinant extrema, cross-scale map, disc NMS,
+// deterministic compaction and sub-pixel refinement (gfx950, wave64).
+//
+//   hCalcExtremaMap/gCalcExtremaMap  akazed.cu:2563, 1334 -> k_extrema
+//   hNmsR/gNmsRNaive                 akazed.cu:2611, 1554 -> k_nms_mark, k_row_scan, k_emit
+//   hRefine/gRefine                  akazed.cu:2635, 1615 -> fused into k_emit
+//
+// The reference keeps three full-resolution maps (response, size, layer)
+// updated by a racy compare-then-write and appends survivors in
+// atomic arrival order (D6).  Here one u64 per pixel holds
+//   key = response_bits << 32 | (0xFFFFFFFF - layer)
+// updated with a single atomicMax: the larger response wins and, on a tie, the
+// lower layer (= the reference's sequential "strict <" order).  Survivors are
+// compacted in raster order: ballot -> bitmap + per-row counts -> scan -> emit.
+#include "hak_internal.h"
+
+__device__ __forceinline__ float key_resp(unsigned long long k) { return __uint_as_float((unsigned)(k >> 32)); }
+__device__ __forceinline__ int key_layer(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)k); }
+
+// ------------------------------------------------------------------ extrema
+// grid: (x tiles, y tiles, ms * nimg)
+__global__ __launch_bounds__(256) void k_extrema(const float* __restrict__ base, long stride, unsigned long long* maps,
+                                                 long map_stride, HakLayout L, const HakTables* __restrict__ tab,
+                                                 int octave, float threshold)
+{
+    const int s = blockIdx.z % L.ms, img = blockIdx.z / L.ms;
+    const HakOct oc = L.oct[octave];
+    const float* det = base + (long)img * stride + L.det(octave, s);
+    unsigned long long* map = maps + (long)img * map_stride;
+    const int layer = octave * L.ms + s;
+    const float border = tab->borders[layer];
+    const int psz = (int)tab->borders[octave * L.ms];               // akazed.cu:2572
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
+    if (x < psz || x >= oc.w) return;
+    // akazed.cu:1346-1353
+    if ((int)(x - border + 0.5f) - 1 < 0 || (int)(x + border + 0.5f) + 1 >= oc.w) return;
+    for (int y = y0; y < blockIdx.y * 16 + 16 && y < oc.h; y += 4) {
+        if (y < psz) continue;
+        if ((int)(y - border + 0.5f) - 1 < 0 || (int)(y + border + 0.5f) + 1 >= oc.h) continue;
+        const float* vp = det + (long)y * oc.p + x;
+        const float* vp0 = vp - oc.p;
+        const float* vp2 = vp + oc.p;
+        float v = *vp;
+        if (v > threshold && v > *vp0 && v > *vp2 && v > vp[-1] && v > vp[1] &&
+            v > vp0[-1] && v > vp0[1] && v > vp2[-1] && v > vp2[1]) {
+            long oidx = (long)(y << octave) * L.oct[0].p + (x << octave);
+            unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)layer);
+            atomicMax(&map[oidx], key);
+        }
+    }
+}
+
+// ---------------------------------------------------------------- NMS: mark
+// One lane per full-res pixel; a wave covers 64 consecutive pixels of a row so
+// the survivor mask of the wave is one u64 bitmap word.  (akazed.cu:1554-1613)
+__global__ __launch_bounds__(256) void k_nms_mark(const unsigned long long* __restrict__ maps, long map_stride,
+                                                  const HakTables* __restrict__ tab, int psz, int w, int h, int p,
+                                                  unsigned long long* bitmap, int words_per_row, int* rowcount)
+{
+    const int img = blockIdx.z;
+    const unsigned long long* map = maps + (long)img * map_stride;
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (y >= h) return;                                             // wave-uniform
+    bool keep = false;
+    if (x >= psz && x + psz < w && y >= psz && y + psz < h) {
+        unsigned long long kc = map[(long)y * p + x];
+        if (kc != 0ull) {
+            const float rc = key_resp(kc);
+            const float fsz = tab->sizes[key_layer(kc)];
+            const int isz = (int)(fsz + 0.5f);
+            const int sqsz = (int)(fsz * fsz);
+            bool to_nms = false;
+            for (int i = -isz; i <= isz && !to_nms; i++)
+                for (int j = -isz; j <= isz; j++) {
+                    if ((i == 0 && j == 0) || i * i + j * j >= sqsz) continue;
+                    float rn = key_resp(map[(long)(y + i) * p + (x + j)]);
+                    if (rn > rc || (rn == rc && i <= 0 && j <= 0)) to_nms = true;
+                }
+            keep = !to_nms;
+        }
+    }
+    unsigned long long mask = __ballot(keep);
+    if ((threadIdx.x & 63) == 0) {
+        bitmap[((long)img * h + y) * words_per_row + blockIdx.x] = mask;
+        if (mask) atomicAdd(&rowcount[(long)img * h + y], __popcll(mask));
+    }
+}
+
+// exclusive scan of the per-row survivor counts (one block per image)
+__global__ __launch_bounds__(256) void k_row_scan(int* rowcount, int h, HakImgState* state, int max_pts, int* num_out)
+{
+    __shared__ int part[256];
+    int* rc = rowcount + (long)blockIdx.x * h;
+    const int per = (h + 255) / 256;
+    const int beg = threadIdx.x * per, end = min(beg + per, h);
+    int sum = 0;
+    for (int i = beg; i < end; i++) sum += rc[i];
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int i = 0; i < 256; i++) { int t = part[i]; part[i] = run; run += t; }
+        state[blockIdx.x].total_pts = run;
+        int n = run < max_pts ? run : max_pts;
+        state[blockIdx.x].num_pts = n;
+        if (num_out) num_out[blockIdx.x] = n;
+    }
+    __syncthreads();
+    int run = part[threadIdx.x];
+    for (int i = beg; i < end; i++) { int t = rc[i]; rc[i] = run; run += t; }
+}
+
+// emit survivors in raster order + gRefine (akazed.cu:1615-1662); one wave per row
+__global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, long stride,
+                                              const unsigned long long* __restrict__ maps, long map_stride,
+                                              HakLayout L, const HakTables* __restrict__ tab,
+                                              const unsigned long long* __restrict__ bitmap, int words_per_row,
+                                              const int* __restrict__ rowstart, hak_point* points, int max_pts)
+{
+    const int img = blockIdx.z;
+    const int h = L.oct[0].h, p0 = L.oct[0].p;
+    const int y = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (y >= h) return;
+    const unsigned long long* map = maps + (long)img * map_stride;
+    const float* arena = base + (long)img * stride;
+    hak_point* pts = points + (long)img * max_pts;
+    int row_base = rowstart[(long)img * h + y];
+    for (int w0 = 0; w0 < words_per_row; w0 += 64) {
+        unsigned long long word = (w0 + lane < words_per_row) ? bitmap[((long)img * h + y) * words_per_row + w0 + lane] : 0ull;
+        int cnt = __popcll(word);
+        // inclusive wave prefix sum of cnt
+        int incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) {
+            int t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        int idx = row_base + incl - cnt;
+        while (word) {
+            int bit = __ffsll((long long)word) - 1;
+            word &= word - 1;
+            if (idx < max_pts) {
+                int x = (w0 + lane) * 64 + bit;
+                unsigned long long k = map[(long)y * p0 + x];
+                int layer = key_layer(k);
+                int o = layer / L.ms, s = layer - o * L.ms;
+                float px = (float)x, py = (float)y;
+                // refine on the det plane of the winning level
+                const float* det = arena + L.det(o, s);
+                int pp = L.oct[o].p;
+                int yy = y >> o, xx = x >> o;
+                long id = (long)yy * pp + xx;
+                float c = det[id];
+                float v2 = c + c;
+                float dx = 0.5f * (det[id + 1] - det[id - 1]);
+                float dy = 0.5f * (det[id + pp] - det[id - pp]);
+                float dxx = det[id + 1] + det[id - 1] - v2;
+                float dyy = det[id + pp] + det[id - pp] - v2;
+                float dxy = 0.25f * (det[id + pp + 1] + det[id - pp - 1] - det[id - pp + 1] - det[id + pp - 1]);
+                float dd = dxx * dyy - dxy * dxy;
+                float idd = dd != 0.f ? 1.f / dd : 0.f;
+                float dst0 = idd * (dxy * dy - dyy * dx);
+                float dst1 = idd * (dxy * dx - dxx * dy);
+                bool weak = dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f;
+                if (!weak) {
+                    int ratio = 1 << o;
+                    py = ratio * (yy + dst1);
+                    px = ratio * (xx + dst0);
+                }
+                hak_point* pt = pts + idx;
+                pt->x = px;
+                pt->y = py;
+                pt->octave = layer;
+                pt->response = key_resp(k);                         // D8
+                pt->size = tab->sizes[layer];
+                pt->angle = 0.f;
+                pt->match = -1;
+                pt->distance = -1;
+                pt->match_x = -1.f;
+                pt->match_y = -1.f;
+            }
+            idx++;
+        }
+        row_base += __shfl(incl, 63);
+    }
+}
+
+void hak_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
+                        float dthreshold)
+{
+    const HakOct oc = L.oct[octave];
+    dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, L.ms * b.nimg);
+    k_extrema<<<grid, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, octave, dthreshold);
+}
+
+void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
+                         hak_point* points, int max_pts, int* num_out)
+{
+    const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
+    const int words = (w + 63) / 64;
+    (void)hipMemsetAsync(b.rowcount, 0, sizeof(int) * (size_t)b.nimg * h, st);
+    dim3 g1(words, (h + 3) / 4, b.nimg);
+    k_nms_mark<<<g1, 256, 0, st>>>(b.maps, b.map_stride, tab, psz, w, h, p, b.bitmap, words, b.rowcount);
+    k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
+    dim3 g3((h + 3) / 4, 1, b.nimg);
+    k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts);
+}

@@ -1,0 +1,438 @@
+// kernels_scalespace.hip -- nonlinear scale space for gfx950 (CDNA4, wave64).
+//
+// Stages (reference wrapper -> kernel here):
+//   hLowPass/gConv2d<R>            akazed.cu:2336, 204   -> k_lowpass<R>
+//   hDownWithSmooth                akazed.cu:2389, 449   -> k_down_smooth
+//   hScharrContrast                akazed.cu:2410, 644, 827, 901 -> k_grad_max, k_grad_hist, k_kcontrast
+//   hFlow/gFlowNaive               akazed.cu:2487, 1068  -> k_flow
+//   hNldStep/gNldStepNaive         akazed.cu:2509, 1241  -> k_fed_step      (the FED hot loop)
+//   hHessianDeterminant            akazed.cu:2531, 1267, 1299 -> k_derivate, k_hessian
+//
+// All kernels take the batch image in blockIdx.z.  Float evaluation order is
+// the reference's source order (no contraction: built with -ffp-contract=off);
+// the only fused op is the explicit fmaf of the FED step (akazed.cu:1263).
+#include "hak_internal.h"
+
+#define TILE_X 64
+#define TILE_Y 16
+
+struct HakTaps { float k[8]; };
+
+// ------------------------------------------------------------------ lowpass
+// Separable Gaussian, reflect-101.  One 64x16 output tile per 256-thread
+// block: raw tile (+R halo) -> LDS, row pass -> LDS, column pass -> HBM.
+template <int R>
+__global__ __launch_bounds__(256) void k_lowpass(const float* __restrict__ src, long src_stride, int sp,
+                                                 float* __restrict__ dst, long dst_stride,
+                                                 int w, int h, int p, HakTaps taps)
+{
+    constexpr int RW = TILE_X + 2 * R, RH = TILE_Y + 2 * R;
+    __shared__ float raw[RH][RW + 1];
+    __shared__ float rowp[RH][TILE_X];
+    const float* s = src + (long)blockIdx.z * src_stride;
+    float* d = dst + (long)blockIdx.z * dst_stride;
+    const int x0 = blockIdx.x * TILE_X, y0 = blockIdx.y * TILE_Y, tid = threadIdx.x;
+
+    for (int i = tid; i < RH * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        raw[r][c] = s[(long)hak_refl(y0 - R + r, h) * sp + hak_refl(x0 - R + c, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * TILE_X; i += 256) {
+        int r = i >> 6, c = i & 63;
+        float ws = raw[r][c + R] * taps.k[0];
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws += taps.k[k] * (raw[r][c + R - k] + raw[r][c + R + k]);
+        rowp[r][c] = ws;
+    }
+    __syncthreads();
+    const int c = tid & 63, x = x0 + c;
+    if (x >= w) return;
+    for (int rr = tid >> 6; rr < TILE_Y; rr += 4) {
+        int y = y0 + rr;
+        if (y >= h) break;
+        float ws = rowp[rr + R][c] * taps.k[0];
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws += taps.k[k] * (rowp[rr + R - k][c] + rowp[rr + R + k][c]);
+        d[(long)y * p + x] = ws;
+    }
+}
+
+void hak_launch_lowpass(hipStream_t st, const float* src, long src_stride, int src_pitch, float* dst, long dst_stride,
+                        int w, int h, int p, int nimg, const float* taps, int R)
+{
+    HakTaps t;
+    for (int i = 0; i < 8; i++) t.k[i] = i <= R ? taps[i] : 0.f;
+    dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
+    switch (R) {
+    case 2: k_lowpass<2><<<grid, 256, 0, st>>>(src, src_stride, src_pitch, dst, dst_stride, w, h, p, t); break;
+    case 3: k_lowpass<3><<<grid, 256, 0, st>>>(src, src_stride, src_pitch, dst, dst_stride, w, h, p, t); break;
+    case 4: k_lowpass<4><<<grid, 256, 0, st>>>(src, src_stride, src_pitch, dst, dst_stride, w, h, p, t); break;
+    default: k_lowpass<5><<<grid, 256, 0, st>>>(src, src_stride, src_pitch, dst, dst_stride, w, h, p, t); break;
+    }
+}
+
+// ------------------------------------------------------------ down + smooth
+// dst = src[2y][2x]; smooth = G(sigma=1, R=2) on the decimated lattice with the
+// mirror taken on the SOURCE extents (akazed.cu:466, 477-494).
+__device__ __forceinline__ int refl_src(int i, int m)
+{
+    i = i < 0 ? -i : i;
+    i = i < m ? i : m + m - 2 - i;
+    i = i < 0 ? 0 : i;
+    return i < m ? i : m - 1;
+}
+
+__global__ __launch_bounds__(256) void k_down_smooth(const float* __restrict__ src, float* __restrict__ dst,
+                                                     float* __restrict__ smooth, long stride,
+                                                     HakOct so, HakOct dd, HakTaps taps)
+{
+    constexpr int RW = TILE_X + 4, RH = TILE_Y + 4;
+    __shared__ float dec[RH][RW + 1];
+    __shared__ float rowp[RH][TILE_X];
+    const float* s = src + (long)blockIdx.z * stride;
+    float* d = dst + (long)blockIdx.z * stride;
+    float* sm = smooth + (long)blockIdx.z * stride;
+    const int x0 = blockIdx.x * TILE_X, y0 = blockIdx.y * TILE_Y, tid = threadIdx.x;
+
+    for (int i = tid; i < RH * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        int sy = refl_src(2 * (y0 - 2 + r), so.h), sx = refl_src(2 * (x0 - 2 + c), so.w);
+        dec[r][c] = s[(long)sy * so.p + sx];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * TILE_X; i += 256) {
+        int r = i >> 6, c = i & 63;
+        rowp[r][c] = taps.k[0] * dec[r][c + 2] + taps.k[1] * (dec[r][c + 1] + dec[r][c + 3]) +
+                     taps.k[2] * (dec[r][c] + dec[r][c + 4]);
+    }
+    __syncthreads();
+    const int c = tid & 63, x = x0 + c;
+    if (x >= dd.w) return;
+    for (int rr = tid >> 6; rr < TILE_Y; rr += 4) {
+        int y = y0 + rr;
+        if (y >= dd.h) break;
+        long o = (long)y * dd.p + x;
+        d[o] = dec[rr + 2][c + 2];
+        sm[o] = taps.k[0] * rowp[rr + 2][c] + taps.k[1] * (rowp[rr + 1][c] + rowp[rr + 3][c]) +
+                taps.k[2] * (rowp[rr][c] + rowp[rr + 4][c]);
+    }
+}
+
+void hak_launch_down_smooth(hipStream_t st, const float* src, float* dst, float* smooth, long stride,
+                            HakOct so, HakOct dd, int nimg, const float* taps)
+{
+    HakTaps t;
+    for (int i = 0; i < 8; i++) t.k[i] = i <= 2 ? taps[i] : 0.f;
+    dim3 grid((dd.w + TILE_X - 1) / TILE_X, (dd.h + TILE_Y - 1) / TILE_Y, nimg);
+    k_down_smooth<<<grid, 256, 0, st>>>(src, dst, smooth, stride, so, dd, t);
+}
+
+// ------------------------------------------------------- Scharr + contrast
+// un-normalised Scharr pair of akazed.cu:664-665 / 1088-1089
+__device__ __forceinline__ void scharr_dxdy(const float* __restrict__ s, int x, int y, int w, int h, int p,
+                                            float& dx, float& dy)
+{
+    int x0 = x - 1 < 0 ? 1 - x : x - 1;
+    int x2 = x + 1 < w ? x + 1 : w + w - 3 - x;
+    int y0 = y - 1 < 0 ? 1 - y : y - 1;
+    int y2 = y + 1 < h ? y + 1 : h + h - 3 - y;
+    const float* r0 = s + (long)y0 * p;
+    const float* r1 = s + (long)y * p;
+    const float* r2 = s + (long)y2 * p;
+    float ul = r0[x0], uc = r0[x], ur = r0[x2];
+    float cl = r1[x0], cr = r1[x2];
+    float ll = r2[x0], lc = r2[x], lr = r2[x2];
+    dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
+    dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
+}
+
+__global__ __launch_bounds__(256) void k_reset_state(HakImgState* state)
+{
+    HakImgState* st = state + blockIdx.x;
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) st->hist[i] = 0;
+    if (threadIdx.x == 0) {
+        st->hmax_bits = __float_as_uint(0.03f);        // akazed.cu:2413
+        st->total_pts = 0;
+        st->num_pts = 0;
+    }
+}
+
+void hak_launch_reset_state(hipStream_t st, HakImgState* state, int nimg)
+{
+    k_reset_state<<<nimg, 256, 0, st>>>(state);
+}
+
+// pass 1: maximum gradient magnitude (the reference's intended reduction, D2)
+__global__ __launch_bounds__(256) void k_grad_max(const float* __restrict__ smooth, long stride, int w, int h, int p,
+                                                  HakImgState* state)
+{
+    const float* s = smooth + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
+    float m = 0.f;
+    if (x < w)
+        for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+            float dx, dy;
+            scharr_dxdy(s, x, y, w, h, p, dx, dy);
+            m = fmaxf(m, sqrtf(dx * dx + dy * dy));
+        }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(&state[blockIdx.z].hmax_bits, __float_as_uint(m));
+}
+
+// pass 2: 300-bin histogram, gradient recomputed (cheaper than storing it)
+__global__ __launch_bounds__(256) void k_grad_hist(const float* __restrict__ smooth, long stride, int w, int h, int p,
+                                                   HakImgState* state)
+{
+    __shared__ int shist[HAK_NBINS];
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) shist[i] = 0;
+    __syncthreads();
+    const float* s = smooth + (long)blockIdx.z * stride;
+    const float hmax = __uint_as_float(state[blockIdx.z].hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;                       // akazed.cu:2450
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
+    if (x < w)
+        for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+            float dx, dy;
+            scharr_dxdy(s, x, y, w, h, p, dx, dy);
+            float g = sqrtf(dx * dx + dy * dy);
+            // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
+            int hi = (int)((double)g * (double)hfactor);
+            hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
+            atomicAdd(&shist[hi], 1);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256)
+        if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
+}
+
+// host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay
+// (akaze.cpp:371) and ikc = 1/(k*k) (akazed.cu:2493), kept on the device.
+__global__ void k_kcontrast(HakImgState* state, int npix, float per, int noct)
+{
+    HakImgState* st = state + blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float hmax = __uint_as_float(st->hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;
+    int thresh = (int)((npix - st->hist[0]) * per);
+    int cumuv = 0, k = 1;
+    while (k < HAK_NBINS) {
+        if (cumuv >= thresh) break;
+        cumuv += st->hist[k];
+        k++;
+    }
+    float kc = k / hfactor;
+    for (int o = 0; o < noct; o++) {
+        if (o > 0) kc *= 0.75f;
+        st->kcontrast[o] = kc;
+        st->ikc[o] = 1.f / (kc * kc);
+    }
+}
+
+void hak_launch_contrast(hipStream_t st, const float* smooth, long stride, int w, int h, int p, int nimg,
+                         HakImgState* state, float per, int noct)
+{
+    dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
+    k_grad_max<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
+    k_grad_hist<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
+    k_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+}
+
+// --------------------------------------------------------------------- flow
+__global__ __launch_bounds__(256) void k_flow(const float* __restrict__ src, float* __restrict__ dst, long stride,
+                                              int w, int h, int p, int type, const HakImgState* state, int octave,
+                                              float fixed_ikc)
+{
+    const float* s = src + (long)blockIdx.z * stride;
+    float* d = dst + (long)blockIdx.z * stride;
+    const float ikc = state ? state[blockIdx.z].ikc[octave] : fixed_ikc;
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+        float dx, dy;
+        scharr_dxdy(s, x, y, w, h, p, dx, dy);
+        float dif2 = ikc * (dx * dx + dy * dy);
+        float g;
+        if (type == HAK_PM_G2) g = 1.f / (1.f + dif2);
+        else if (type == HAK_PM_G1) g = hak_expf(-dif2);
+        else if (type == HAK_WEICKERT) {
+            float d2 = dif2 * dif2;
+            g = 1.f - hak_expf(-3.315f / (d2 * d2));
+        } else g = 1.f / sqrtf(1.f + dif2);
+        d[(long)y * p + x] = g;
+    }
+}
+
+void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, int w, int h, int p, int nimg,
+                     int diffusivity, const HakImgState* state, int octave, float fixed_ikc)
+{
+    dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
+    k_flow<<<grid, 256, 0, st>>>(src, dst, stride, w, h, p, diffusivity, state, octave, fixed_ikc);
+}
+
+// ----------------------------------------------------------------- FED step
+// One explicit diffusion step  L' = fma(0.5*tau, sum_{E,W,S,N} (g+g_n)(L_n-L), L)
+// (akazed.cu:1259-1263).  HBM-bound: 12 B/px (read L, read g, write L').
+//
+// Mapping: a wave owns a 256-px-wide column strip (one float4 per lane =
+// 1 KiB contiguous per row) and walks RY rows with a 3-row register window,
+// so each row of L and g is loaded once per wave (+2 halo rows per strip);
+// east/west neighbours come from the adjacent lane by DPP/shuffle, and only
+// lanes 0/63 fetch their out-of-strip neighbour from memory.
+__device__ __forceinline__ float4 ld4(const float* __restrict__ base, long off)
+{
+    return *reinterpret_cast<const float4*>(base + off);
+}
+
+__device__ __forceinline__ float fed_px(float L, float g, float LE, float gE, float LW, float gW,
+                                        float LS, float gS, float LN, float gN, float stepfac)
+{
+    float step = (g + gE) * (LE - L) + (g + gW) * (LW - L) + (g + gS) * (LS - L) + (g + gN) * (LN - L);
+    return fmaf(stepfac, step, L);
+}
+
+__global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src, const float* __restrict__ flow,
+                                                  float* __restrict__ dst, long stride, int w, int h, int p,
+                                                  float stepfac, int ry)
+{
+    const float* L = src + (long)blockIdx.z * stride;
+    const float* G = flow + (long)blockIdx.z * stride;
+    float* D = dst + (long)blockIdx.z * stride;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int x0 = (blockIdx.x * 64 + lane) * 4;
+    const int ybeg = (blockIdx.y * 4 + wv) * ry;
+    if (ybeg >= h) return;                                  // wave-uniform
+    const int yend = min(ybeg + ry, h);
+    const bool act = x0 < w;
+    const int xl = act ? x0 : 0;                            // keep every lane's loads in bounds
+    const bool need_l = lane == 0 && x0 > 0;
+    const bool need_r = lane == 63 && x0 + 4 < w;
+
+    int yp = ybeg - 1 < 0 ? 1 - ybeg : ybeg - 1;            // reflect-101 (abs)
+    int yn = ybeg + 1 < h ? ybeg + 1 : h + h - 3 - ybeg;    // borderAdd(y,1,h)
+    float4 Lp = ld4(L, (long)yp * p + xl), Gp = ld4(G, (long)yp * p + xl);
+    float4 Lc = ld4(L, (long)ybeg * p + xl), Gc = ld4(G, (long)ybeg * p + xl);
+    float4 Ln = ld4(L, (long)yn * p + xl), Gn = ld4(G, (long)yn * p + xl);
+
+    for (int y = ybeg; y < yend; y++) {
+        // prefetch the row after next while this one is computed
+        int y2 = y + 2 < h ? y + 2 : h + h - 4 - y;         // borderAdd(y+1,1,h)
+        y2 = y2 < 0 ? 0 : y2;
+        float4 Lf = Ln, Gf = Gn;
+        if (y + 1 < yend) { Lf = ld4(L, (long)y2 * p + xl); Gf = ld4(G, (long)y2 * p + xl); }
+
+        float Lw = __shfl_up(Lc.w, 1), Gw = __shfl_up(Gc.w, 1);
+        float Le = __shfl_down(Lc.x, 1), Ge = __shfl_down(Gc.x, 1);
+        if (need_l) { Lw = L[(long)y * p + x0 - 1]; Gw = G[(long)y * p + x0 - 1]; }
+        if (need_r) { Le = L[(long)y * p + x0 + 4]; Ge = G[(long)y * p + x0 + 4]; }
+
+        float l[6] = {Lw, Lc.x, Lc.y, Lc.z, Lc.w, Le};
+        float g[6] = {Gw, Gc.x, Gc.y, Gc.z, Gc.w, Ge};
+        float ln[4] = {Lp.x, Lp.y, Lp.z, Lp.w}, gn[4] = {Gp.x, Gp.y, Gp.z, Gp.w};
+        float ls[4] = {Ln.x, Ln.y, Ln.z, Ln.w}, gs[4] = {Gn.x, Gn.y, Gn.z, Gn.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            int x = x0 + e;
+            float LW = l[e], GW = g[e], LE = l[e + 2], GE = g[e + 2];
+            if (x == 0) { LW = LE; GW = GE; }               // abs(x-1) = 1
+            if (x == w - 1) { LE = l[e]; GE = g[e]; }        // borderAdd(x,1,w) = w-2
+            o[e] = fed_px(l[e + 1], g[e + 1], LE, GE, LW, GW, ls[e], gs[e], ln[e], gn[e], stepfac);
+        }
+        if (act) {
+            float* drow = D + (long)y * p + x0;
+            if (x0 + 3 < w) *reinterpret_cast<float4*>(drow) = make_float4(o[0], o[1], o[2], o[3]);
+            else
+                for (int e = 0; e < 4 && x0 + e < w; e++) drow[e] = o[e];
+        }
+        Lp = Lc; Gp = Gc; Lc = Ln; Gc = Gn; Ln = Lf; Gn = Gf;
+    }
+}
+
+void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+                         int w, int h, int p, int nimg, float stepfac)
+{
+    int gx = (w + 255) / 256;
+    // rows per wave: deep strips when the batch already fills the chip, shallow otherwise
+    int ry = 8;
+    while (ry > 2 && (long)gx * ((h + 4 * ry - 1) / (4 * ry)) * nimg < 2048) ry >>= 1;
+    dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
+    k_fed_step<<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, stepfac, ry);
+}
+
+// ------------------------------------------------- derivatives + determinant
+__global__ __launch_bounds__(256) void k_derivate(const float* __restrict__ src, float* __restrict__ lx,
+                                                  float* __restrict__ ly, long stride, int w, int h, int p,
+                                                  int step, float fac1, float fac2)
+{
+    const float* s = src + (long)blockIdx.z * stride;
+    float* ox = lx + (long)blockIdx.z * stride;
+    float* oy = ly + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
+    for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+        const float* r0 = s + (long)hak_refl(y - step, h) * p;
+        const float* r1 = s + (long)y * p;
+        const float* r2 = s + (long)hak_refl(y + step, h) * p;
+        float ul = r0[x0], uc = r0[x], ur = r0[x2];
+        float cl = r1[x0], cr = r1[x2];
+        float ll = r2[x0], lc = r2[x], lr = r2[x2];
+        ox[(long)y * p + x] = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);       // akazed.cu:1294
+        oy[(long)y * p + x] = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);       // akazed.cu:1295
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ lx, const float* __restrict__ ly,
+                                                 float* __restrict__ det, long stride, int w, int h, int p,
+                                                 int step, float fac1, float fac2)
+{
+    const float* dx = lx + (long)blockIdx.z * stride;
+    const float* dy = ly + (long)blockIdx.z * stride;
+    float* o = det + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
+    const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
+    for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+        long o0 = (long)hak_refl(y - step, h) * p, o1 = (long)y * p, o2 = (long)hak_refl(y + step, h) * p;
+        float xul = dx[o0 + x0], xuc = dx[o0 + x], xur = dx[o0 + x2];
+        float xcl = dx[o1 + x0], xcr = dx[o1 + x2];
+        float xll = dx[o2 + x0], xlc = dx[o2 + x], xlr = dx[o2 + x2];
+        float yul = dy[o0 + x0], yuc = dy[o0 + x], yur = dy[o0 + x2];
+        float yll = dy[o2 + x0], ylc = dy[o2 + x], ylr = dy[o2 + x2];
+        float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
+        float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
+        float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
+        o[o1 + x] = dxx * dyy - dxy * dxy;                                         // akazed.cu:1330
+    }
+}
+
+static void deriv_factors(float& fac1, float& fac2)
+{
+    float wv = 10.f / 3.f;                                   // akazed.cu:2537-2539
+    fac1 = 1.f / (2.f * (wv + 2.f));
+    fac2 = wv * fac1;
+}
+
+void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly, long stride,
+                         int w, int h, int p, int nimg, int step)
+{
+    float f1, f2;
+    deriv_factors(f1, f2);
+    dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
+    k_derivate<<<grid, 256, 0, st>>>(src, lx, ly, stride, w, h, p, step, f1, f2);
+}
+
+void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
+                        int w, int h, int p, int nimg, int step)
+{
+    float f1, f2;
+    deriv_factors(f1, f2);
+    dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
+    k_hessian<<<grid, 256, 0, st>>>(lx, ly, det, stride, w, h, p, step, f1, f2);
+}

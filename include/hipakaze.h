@@ -1,0 +1,179 @@
+/*
+ * hipakaze.h -- C ABI of libhipakaze.so, the MI355X-native AKAZE hot path
+ * (detect + describe + match) behind the CUDA-AKAZE interface.
+ *
+ * The reference has no C layer: its boundary is the C++ class in akaze.h.  The
+ * entry points below are what a binding for that class needs; each one cites
+ * the reference interface it replaces (file:line in the reference checkout).
+ * include/akaze.h re-creates akaze::Akazer / akaze::cuMatch on top of this
+ * ABI, so main.cpp-style callers drop in.
+ *
+ * Conventions (as the reference): images are DEVICE pointers to
+ * float32 in [0,1], row pitch in elements; point arrays are caller-owned
+ * device arrays of 104-byte hak_point; every function returns 0 on success and
+ * a non-zero status otherwise, with the message in hak_last_error().  There is
+ * no CPU fallback: without a usable HIP device every compute call fails.
+ */
+#ifndef HIPAKAZE_H
+#define HIPAKAZE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HAK_FLEN 61          /* akaze_structures.h:29  (FEATURE_TYPE 5, MLDB) */
+#define HAK_MAX_OCTAVES 8    /* akazed.cu:10 MAX_OCTAVE */
+#define HAK_MAX_SCALES 5     /* akazed.cu:9  MAX_SCALE  */
+#define HAK_MAX_DIST 96      /* akazed.cu:11 MAX_DIST   */
+
+/* akaze_structures.h:19-40 AkazePoint: 104 bytes, align 4.
+ * offsets: x 0, y 4, octave 8 (= octave*max_scale + sublevel), response 12,
+ * size 16, angle 20, features 24..84, pad 85..87, match 88, distance 92,
+ * match_x 96, match_y 100. */
+typedef struct hak_point {
+    float x;
+    float y;
+    int octave;
+    float response;
+    float size;
+    float angle;
+    unsigned char features[HAK_FLEN];
+    int match;
+    int distance;
+    float match_x;
+    float match_y;
+} hak_point;
+
+/* akaze_structures.h:53-59 DiffusivityType */
+enum { HAK_PM_G1 = 0, HAK_PM_G2 = 1, HAK_WEICKERT = 2, HAK_CHARBONNIER = 3 };
+
+/* The 11 arguments of Akazer::init (akaze.h:25-26, defaults akaze.h:35-54,
+ * demo values main.cpp:156-166) plus what the reference keeps as macros or
+ * call arguments. */
+typedef struct hak_config {
+    int noctaves;                 /* 4 */
+    int max_scale;                /* 4  sublevels per octave */
+    float per;                    /* 0.7  contrast percentile */
+    float kcontrast;              /* 0.03 (overwritten per image, akazed.cu:2481) */
+    float soffset;                /* 1.6 */
+    int reordering;               /* 1 */
+    float derivative_factor;      /* 1.5 */
+    float dthreshold;             /* 0.001 */
+    int diffusivity;              /* HAK_PM_G2 */
+    int descriptor_pattern_size;  /* 10 */
+    int max_pts;                  /* capacity of every per-image point array (main.cpp:155: 10000) */
+    int upright;                  /* 0; 1 = MLDB-upright extension: angle = 0 (no reference behaviour) */
+    int batch;                    /* images one launch sequence processes (>= 1) */
+} hak_config;
+
+typedef struct hak_ctx hak_ctx;
+
+/* ---- device / errors: cuda_utils.h:41-67 initDevice, :18-37 CHECK/CheckMsg */
+int hak_device_count(void);
+int hak_set_device(int dev);
+const char* hak_last_error(void);
+void hak_default_config(hak_config* cfg);
+
+/* ---- detector object: Akazer::Akazer/init/allocMemory/~Akazer (akaze.cpp:67-98, 204-237).
+ * Geometry is fixed at creation (w x h pixels); the arena for `batch` images,
+ * the FED schedule and all tables live in the context. */
+int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out);
+void hak_destroy(hak_ctx* ctx);
+/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own */
+int hak_set_stream(hak_ctx* ctx, void* hip_stream);
+int hak_sync(hak_ctx* ctx);
+
+/* ---- Akazer::detectAndCompute (akaze.h:29, akaze.cpp:101-150), one image,
+ * synchronous.  d_image: device float32, pitch elements per row.  d_points:
+ * device array of max_pts points.  *num_pts (host) receives the count; when
+ * h_points != NULL the points are copied to it (whole 104-byte records). */
+int hak_detect_and_compute(hak_ctx* ctx, const float* d_image, int pitch,
+                           hak_point* d_points, int max_pts, int* num_pts,
+                           hak_point* h_points, int desc);
+
+/* ---- batched, asynchronous form used by the frame-sharded driver.
+ * nimg <= cfg.batch images at d_images + i*image_stride (elements); points of
+ * image i at d_points + i*max_pts; counts written to d_num_pts[i] (device).
+ * Returns after enqueueing; hak_sync() or stream sync to wait. */
+int hak_detect_and_compute_batch(hak_ctx* ctx, const float* d_images, long image_stride, int pitch,
+                                 int nimg, hak_point* d_points, int* d_num_pts, int desc);
+
+/* ---- cuMatch (akaze.h:14; ctx may be NULL = default stream, akaze.cpp:55-64, akazed.cu:2144-2241): 1-NN
+ * Hamming, accepted iff dist < 96 and the minimum is attained in exactly one
+ * of the 16 residue classes j mod 16.  Fills match/distance/match_x/match_y
+ * of d_pts1; copies those 16 bytes per point into h_pts1 when not NULL. */
+int hak_match(hak_ctx* ctx, hak_point* d_pts1, int n1, const hak_point* d_pts2, int n2,
+              hak_point* h_pts1);
+/* batched: pair k matches (d_pts + (2k)*max_pts) against (d_pts + (2k+1)*max_pts),
+ * counts read from d_num_pts[2k], d_num_pts[2k+1] on the device. Asynchronous. */
+int hak_match_batch(hak_ctx* ctx, hak_point* d_points, const int* d_num_pts, int npairs);
+
+/* ---- memory helpers: initAkazeData/freeAkazeData (akaze.cpp:26-52) and the
+ * image upload of main.cpp:172-188 */
+int hak_points_alloc(hak_point** d_points, int count);
+int hak_points_free(hak_point* d_points);
+int hak_image_alloc(float** d_image, int w, int h, int* pitch);   /* pitch = iAlignUp(w,128), cuda_utils.h:160 */
+int hak_image_upload(float* d_image, int pitch, const float* h_image, int w, int h);
+int hak_image_free(float* d_image);
+/* pinned host memory + the batched counterpart of the D2H copies at akaze.cpp:134-139 / 60-62:
+ * counts first (one sync), then the first h_num_pts[i] records of every image, asynchronously,
+ * then a final sync.  h_points is [nimg][max_pts]. */
+int hak_host_alloc(void** p, long bytes);
+int hak_host_free(void* p);
+int hak_download_batch(hak_ctx* ctx, const hak_point* d_points, const int* d_num_pts, int nimg,
+                       hak_point* h_points, int* h_num_pts);
+int hak_memcpy_d2h(void* dst, const void* src, long bytes);
+int hak_memcpy_h2d(void* dst, const void* src, long bytes);
+
+/* ---- host-side schedule (pure CPU, usable without a GPU).
+ * fed.cpp:41-119 fed_tau_by_process_time; returns n, writes tau[0..n). */
+int hak_fed_tau(float T, int M, float tau_max, int reordering, float* tau, int cap);
+/* akazed.cu:2298-2333 createGaussKernel */
+void hak_gauss_taps(float var, int radius, float* taps);
+/* akazed.cu:65-159 setCompareIndices (486 pairs, arrays of >= 488 ints) */
+void hak_compare_indices(int* idx1, int* idx2);
+/* schedule the context was built with: per (octave, sublevel) the number of FED
+ * steps, sigma_size, size, border; returns effective number of octaves. */
+int hak_query_schedule(const hak_ctx* ctx, int* nsteps, int* sigma_size, float* sizes, float* borders);
+int hak_query_geometry(const hak_ctx* ctx, int* whp /* 3 ints per octave */);
+
+/* ---- introspection used by tests and bench (not on the hot path) */
+enum { HAK_PLANE_LT = 0, HAK_PLANE_DET = 1, HAK_PLANE_LX = 2, HAK_PLANE_LY = 3 };
+/* copy plane (kind, octave, sublevel) of batch image `img`, densely packed w x h, to host */
+int hak_debug_plane(hak_ctx* ctx, int img, int kind, int octave, int sublevel, float* h_dst);
+int hak_debug_kcontrast(hak_ctx* ctx, int img, float* kcontrast);
+/* algorithmic-byte accounting of the last detect call on this context */
+typedef struct hak_traffic {
+    double fed_px_steps;     /* sum over FED steps of pixels updated, per image */
+    double fed_bytes;        /* 12 B x fed_px_steps */
+    double all_stage_bytes;  /* all-stage compulsory bytes per image, keypoint part for npts_hint points */
+    int fed_launches;        /* FED kernel launches per batch */
+} hak_traffic;
+int hak_query_traffic(const hak_ctx* ctx, int npts_hint, hak_traffic* out);
+
+/* ---- per-kernel-class timing with HIP events on the context's stream.
+ * When enabled, every launch of the class is bracketed by an event pair; read
+ * back accumulated milliseconds and launch count after hak_sync(). */
+enum { HAK_PROF_FED = 0, HAK_PROF_LOWPASS, HAK_PROF_FLOW, HAK_PROF_HESSIAN, HAK_PROF_CONTRAST,
+       HAK_PROF_DOWN, HAK_PROF_EXTREMA, HAK_PROF_NMS, HAK_PROF_DESCRIBE, HAK_PROF_MATCH, HAK_PROF_COUNT };
+int hak_prof_enable(hak_ctx* ctx, int on);
+int hak_prof_read(hak_ctx* ctx, int klass, double* total_ms, int* launches);
+int hak_prof_reset(hak_ctx* ctx);
+
+/* ---- single-stage operators on caller-provided device planes (pitch p
+ * elements, dense row-major), used by the per-kernel parity tests.  Each is
+ * the HIP counterpart of one h*() wrapper of akazed.cu. Synchronous. */
+int hak_op_lowpass(const float* d_src, float* d_dst, int w, int h, int p, float var, int radius);         /* hLowPass 2336 */
+int hak_op_down_smooth(const float* d_src, float* d_dst, float* d_smooth, int sw, int sh, int sp,
+                       int dw, int dh, int dp);                                                          /* hDownWithSmooth 2389 */
+int hak_op_kcontrast(const float* d_smooth, int w, int h, int p, float per, float* kcontrast,
+                     float* hmax, int* hist300);                                                         /* hScharrContrast 2410 */
+int hak_op_flow(const float* d_src, float* d_dst, int w, int h, int p, int diffusivity, float kcontrast); /* hFlow 2487 */
+int hak_op_nld_steps(const float* d_src, const float* d_flow, float* d_dst, float* d_tmp,
+                     int w, int h, int p, const float* tau, int nsteps);                                  /* hNldStep 2509, n steps */
+int hak_op_hessian(const float* d_src, float* d_lx, float* d_ly, float* d_det, int w, int h, int p, int step); /* hHessianDeterminant 2531 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIPAKAZE_H */

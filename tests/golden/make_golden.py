@@ -1,0 +1,88 @@
+"""Regenerates the committed fixtures under tests/golden/ (run in the authoring container only).
+
+  fed_tau.json            FED tau tables produced by the REFERENCE's own fed.cpp (oracle/_ref/libfedref.so,
+                          compiled from /root/reference/fed.cpp), as uint32 bit patterns
+  left_right_u8.npz       the reference's only bundled input images (data/left.pgm, right.pgm; 1280x960 P5)
+                          as uint8 arrays -- data, not source
+  left_right_oracle.npz   oracle result on them (demo parameters main.cpp:156-166): points + match fields
+  synth_oracle.npz        oracle results on small seeded synthetic scenes (several sizes / parameter sets)
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, os.path.join(ROOT, "cuda-akaze_amd"))
+import okz  # noqa: E402
+from akaze_hip import synth  # noqa: E402  (pure numpy module)
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def fed_golden():
+    okz.build()
+    assert okz.ref_lib() is not None, "needs /root/reference"
+    ts = [0.530193, 0.749807, 1.060387, 1.499614, 2.120772, 2.999228, 4.241547, 5.998454, 8.483089, 11.996912,
+          16.966187, 23.993816, 33.932358, 47.987648, 67.864746, 95.975266, 135.729431, 191.950592, 271.458984]
+    ts += [float(np.float32(x)) for x in np.geomspace(0.01, 400.0, 60)]
+    cases = []
+    for T in ts:
+        for reorder in (0, 1):
+            tau = okz.ref_fed_tau(T, 1, 0.25, reorder)
+            cases.append(dict(T=float(np.float32(T)), M=1, tau_max=0.25, reordering=reorder,
+                              tau_bits=[int(v) for v in tau.view(np.uint32)]))
+    json.dump(dict(source="reference fed.cpp via oracle/_ref/libfedref.so", cases=cases),
+              open(os.path.join(OUT, "fed_tau.json"), "w"))
+    print("fed_tau.json", len(cases), "cases")
+
+
+def read_pgm(path):
+    from PIL import Image
+    return np.asarray(Image.open(path)).copy()
+
+
+def run_oracle(u8, **kw):
+    h, w = u8.shape
+    p = (w + 127) // 128 * 128
+    return okz.detect_and_compute(synth.to_float(u8, p), w, okz.default_params(**kw))
+
+
+def pgm_golden():
+    left = read_pgm("/root/reference/data/left.pgm")
+    right = read_pgm("/root/reference/data/right.pgm")
+    np.savez_compressed(os.path.join(OUT, "left_right_u8.npz"), left=left, right=right)
+    r1, r2 = run_oracle(left), run_oracle(right)
+    okz.match(r1.points, r2.points)
+    np.savez_compressed(os.path.join(OUT, "left_right_oracle.npz"), pts1=r1.points, pts2=r2.points,
+                        kc=np.array([r1.kcontrast, r2.kcontrast], np.float32))
+    print("left/right", len(r1.points), len(r2.points), "accepted matches", int((r1.points["match"] >= 0).sum()))
+
+
+SYNTH_CASES = [
+    # name, w, h, seed, params
+    ("s320x240", 320, 240, 11, {}),
+    ("s211x173", 211, 173, 12, {}),                       # odd sizes, 2 octaves survive the 80 px rule
+    ("s640x360_o3", 640, 360, 13, dict(noctaves=3)),
+    ("s400x300_upright", 400, 300, 14, dict(upright=1)),
+    ("s400x300_charb", 400, 300, 14, dict(diffusivity=3)),
+]
+
+
+def synth_golden():
+    out = {}
+    for name, w, h, seed, kw in SYNTH_CASES:
+        u8 = synth.scene(w, h, seed)
+        r = run_oracle(u8, **kw)
+        out[name + "_pts"] = r.points
+        out[name + "_kc"] = np.array([r.kcontrast], np.float32)
+        print(name, len(r.points))
+    np.savez_compressed(os.path.join(OUT, "synth_oracle.npz"), **out)
+
+
+if __name__ == "__main__":
+    fed_golden()
+    pgm_golden()
+    synth_golden()

@@ -1,0 +1,214 @@
+"""GPU parity, whole path: Akazer.detectAndCompute x2 + cuMatch through the C ABI against the CPU
+oracle and the committed golden fixtures.  Bar (BASELINE.json north_star): keypoint set / count and
+MLDB descriptor bits bit-exact; Hessian responses within 1e-4 relative (we require bit-equality and
+assert the tolerance separately so a failure says which bar broke)."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_points_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from akaze_hip import synth
+    return synth
+
+
+def gpu_detect(ah, torch, synth, u8, max_pts=10000, desc=True, keep=False, **kw):
+    """the reference demo's call sequence (main.cpp:172-205) on one image"""
+    h, w = u8.shape
+    p = ah.iAlignUp(w, 128)
+    img = torch.from_numpy(synth.to_float(u8, p)).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=max_pts, **kw)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, max_pts, True, True)
+    det.detectAndCompute(img.data_ptr(), data, (w, h, p), desc)
+    pts = data.h_data[:data.num_pts].copy()
+    if keep:
+        return pts, det, data
+    ah.freeAkazeData(data)
+    det.close()
+    return pts
+
+
+def okz_params(okz, **kw):
+    m = dict(kw)
+    return okz.default_params(**m)
+
+
+def load_cases():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg.SYNTH_CASES
+
+
+@pytest.mark.parametrize("case", load_cases(), ids=lambda c: c[0])
+def test_synth_golden(ah, torch, synth, golden, case):
+    name, w, h, seed, kw = case
+    pts = gpu_detect(ah, torch, synth, synth.scene(w, h, seed), **kw)
+    g = golden.synth[name + "_pts"]
+    assert_points_equal(pts, g)
+    rel = np.abs(pts["response"] - g["response"]) / np.abs(g["response"])
+    assert rel.max() <= 1e-4
+
+
+def test_planes_small(ah, okz, torch, synth):
+    """every persistent plane of every level, bit for bit (localises a failing stage)"""
+    w, h = 320, 240
+    u8 = synth.scene(w, h, 11)
+    pts, det, data = gpu_detect(ah, torch, synth, u8, keep=True)
+    r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, keep_arena=True)
+    assert np.float32(det.kcontrast()).view(np.uint32) == r.kcontrast.view(np.uint32)
+    assert len(det.geometry()) == r.noct
+    for o in range(r.noct):
+        for s in range(4):
+            for kind, nm in ((0, "Lt"), (2, "Lx"), (3, "Ly"), (1, "det")):
+                a, b = det.plane(kind, o, s), okz.plane(r, kind, o, s)
+                bad = (a.view(np.uint32) != b.view(np.uint32)).sum()
+                assert bad == 0, f"{nm}({o},{s}): {bad} px differ, max abs {np.abs(a - b).max()}"
+    assert_points_equal(pts, r.points)
+    ah.freeAkazeData(data)
+    det.close()
+
+
+def test_reference_images_and_match(ah, torch, synth, golden):
+    """data/left.pgm vs right.pgm (the reference's bundled pair, main.cpp:141-142): detect + describe + match"""
+    res = []
+    for name in ("left", "right"):
+        pts, det, data = gpu_detect(ah, torch, synth, golden.lr_u8[name], keep=True)
+        res.append((pts, det, data))
+    assert_points_equal(res[0][0], golden.lr["pts1"])
+    assert_points_equal(res[1][0], golden.lr["pts2"])
+    ah.cuMatch(res[0][2], res[1][2])
+    m = res[0][2].h_data[:res[0][2].num_pts]
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(m[f], golden.lr["pts1"][f]), f
+    assert (m["match"] >= 0).sum() == 2400
+    for _, det, data in res:
+        ah.freeAkazeData(data)
+        det.close()
+
+
+@pytest.mark.parametrize("w,h,kw", [(1920, 1080, {}), (1280, 720, {}), (3840, 2160, dict(noctaves=5, upright=True))],
+                         ids=["1080p", "720p", "4k_5oct_upright"])
+def test_full_size_vs_oracle(ah, okz, torch, synth, w, h, kw):
+    """BASELINE.json configs 2-4 at full size, against the oracle run live on the same seeded scene"""
+    u8 = synth.scene(w, h, 1)
+    pts = gpu_detect(ah, torch, synth, u8, **kw)
+    okw = {k: int(v) for k, v in kw.items()}
+    r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
+    assert len(r.points) > 500
+    assert_points_equal(pts, r.points)
+
+
+def test_max_pts_clamp_is_raster_prefix(ah, okz, torch, synth):
+    u8 = synth.scene(640, 480, 21)
+    full = okz.detect_and_compute(synth.to_float(u8, 640), 640).points
+    assert len(full) > 60
+    pts = gpu_detect(ah, torch, synth, u8, max_pts=50)
+    assert len(pts) == 50
+    assert_points_equal(pts, full[:50])
+
+
+def test_no_descriptors(ah, okz, torch, synth):
+    u8 = synth.scene(320, 240, 11)
+    pts = gpu_detect(ah, torch, synth, u8, desc=False)
+    r = okz.detect_and_compute(synth.to_float(u8, 384), 320, desc=False)
+    assert_points_equal(pts, r.points)
+    assert (pts["features"] == 0).all() and (pts["angle"] == 0).all()
+
+
+def test_batch_equals_single(ah, torch, synth):
+    """blockIdx.z batching: B different images in one launch sequence == B single calls"""
+    w, h, B, mp = 400, 300, 5, 2000
+    p = ah.iAlignUp(w, 128)
+    imgs = [synth.scene(w, h, 100 + i) for i in range(B)]
+    singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in imgs]
+    stack = torch.from_numpy(np.stack([synth.to_float(u, p) for u in imgs])).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp, batch=B)
+    d_pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+    d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), 1))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    nums = d_num.cpu().numpy()
+    allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    for i in range(B):
+        assert nums[i] == len(singles[i]) and nums[i] > 20
+        assert_points_equal(allp[i, :nums[i]], singles[i])
+    # batched pair matching == single matching
+    ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B // 2))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    allm = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    import okz
+    for k in range(B // 2):
+        a, b = singles[2 * k].copy(), singles[2 * k + 1]
+        okz.match(a, b)
+        for f in ("match", "distance", "match_x", "match_y"):
+            assert np.array_equal(allm[2 * k, :len(a)][f], a[f]), (k, f)
+    det.close()
+
+
+def test_repeat_calls_are_deterministic(ah, torch, synth):
+    u8 = synth.scene(640, 360, 13)
+    a = gpu_detect(ah, torch, synth, u8)
+    b = gpu_detect(ah, torch, synth, u8)
+    assert a.tobytes() == b.tobytes()
+
+
+# ----------------------------------------------------------------- matcher
+def gpu_match(ah, torch, p1, p2):
+    d1 = torch.from_numpy(p1.view(np.uint8).copy()).cuda()
+    d2 = torch.from_numpy(p2.view(np.uint8).copy()).cuda() if len(p2) else torch.zeros(104, dtype=torch.uint8, device="cuda")
+    out = p1.copy()
+    ah.check(ah.lib.hak_match(None, d1.data_ptr(), len(p1), d2.data_ptr(), len(p2), out.ctypes.data))
+    return out
+
+
+@pytest.mark.parametrize("n1,n2", [(1000, 1000), (37, 5), (5, 37), (16, 16), (300, 0), (1, 1), (2205, 2382)])
+def test_match_vs_oracle(ah, okz, torch, synth, n1, n2):
+    base = synth.random_descriptors(max(n2, 1), 7, ah.POINT_DTYPE)[:n2]
+    q = synth.random_descriptors(n1, 8, ah.POINT_DTYPE, planted_from=base if n2 else None,
+                                 nplanted=min(n1, n2) // 2, maxflip=60)
+    q["_pad"] = 0xAB                                 # garbage in the struct padding must not matter (D9)
+    base["_pad"] = 0xCD
+    got = gpu_match(ah, torch, q, base)
+    want = okz.match(q.copy(), base)
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(got[f], want[f]), f
+    if n2 >= 2 and n1 >= 100:
+        assert (got["match"] >= 0).sum() > 0
+
+
+def test_match_10k_x_10k(ah, okz, torch, synth):
+    """BASELINE.json config 5, full size: oracle equality + size-independent properties"""
+    train = synth.random_descriptors(10000, 7, ah.POINT_DTYPE)
+    query = synth.random_descriptors(10000, 9, ah.POINT_DTYPE, planted_from=train, nplanted=2000, maxflip=40)
+    got = gpu_match(ah, torch, query, train)
+    want = okz.match(query.copy(), train)
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(got[f], want[f]), f
+    acc = got["match"] >= 0
+    assert acc.sum() >= 1900
+    # accepted matches: distance is the true Hamming distance to the matched train descriptor and < 96
+    d = np.unpackbits(query["features"][acc] ^ train["features"][got["match"][acc]], axis=1).sum(axis=1)
+    assert np.array_equal(d, got["distance"][acc]) and (d < 96).all()
+    assert np.array_equal(got["match_x"][acc], train["x"][got["match"][acc]])
+    # idempotence: matching again does not change anything
+    again = gpu_match(ah, torch, got, train)
+    assert again.tobytes() == got.tobytes()

@@ -1,0 +1,165 @@
+"""CPU suite, part 1: the oracle against every pinned quantity.
+
+The reference ships no tests; what can be pinned is: the FED tau tables (against the reference's
+own fed.cpp, compiled into oracle/_ref and frozen in tests/golden/fed_tau.json), the constants the
+survey derived from the reference source (hex KATs), the struct layout, and the oracle's own
+frozen outputs on the reference's bundled left.pgm/right.pgm (regression pin).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+
+def bits(x):
+    return int(np.float32(x).view(np.uint32))
+
+
+def test_fed_tau_matches_reference_golden(okz):
+    cases = json.load(open(os.path.join(GOLDEN, "fed_tau.json")))["cases"]
+    assert len(cases) >= 100
+    for c in cases:
+        tau = okz.fed_tau(c["T"], c["M"], c["tau_max"], c["reordering"])
+        assert [int(v) for v in tau.view(np.uint32)] == c["tau_bits"], c["T"]
+
+
+def test_fed_tau_matches_live_reference_build(okz):
+    if okz.ref_lib() is None:
+        pytest.skip("oracle/_ref/libfedref.so not present (reference checkout absent)")
+    rng = np.random.default_rng(5)
+    for T in rng.uniform(0.01, 300.0, 300).astype(np.float32):
+        for reorder in (0, 1):
+            a, b = okz.fed_tau(float(T), 1, 0.25, reorder), okz.ref_fed_tau(float(T), 1, 0.25, reorder)
+            assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
+def test_fed_schedule_kats(okz):
+    # steps per (octave, sublevel) and first tau vectors
+    ttimes = [0.530193, 0.749807, 1.060387, 1.499614, 2.120772, 2.999228, 4.241547, 5.998454, 8.483089,
+              11.996912, 16.966187, 23.993816, 33.932358, 47.987648, 67.864746, 95.975266, 135.729431,
+              191.950592, 271.458984]
+    lens = [len(okz.fed_tau(t)) for t in ttimes]
+    assert lens == [3, 3, 4, 4, 5, 6, 7, 8, 10, 12, 14, 17, 20, 24, 29, 34, 40, 48, 57]
+    np.testing.assert_allclose(okz.fed_tau(0.530193), [0.0697266981, 0.108422101, 0.352044374], rtol=2e-6)
+    np.testing.assert_allclose(okz.fed_tau(1.060387), [0.106038667, 0.679864287, 0.0820016563, 0.192482203], rtol=2e-6)
+    np.testing.assert_allclose(okz.fed_tau(1.499614), [0.149961352, 0.961473405, 0.115967877, 0.272210985], rtol=2e-6)
+
+
+def test_gauss_taps_kat(okz):
+    k = okz.gauss_taps(1.0, 2)
+    assert [bits(v) for v in k] == [0x3ECE2433, 0x3E7A0FEA, 0x3D5F2F86]
+    k = okz.gauss_taps(float(np.float32(1.6) * np.float32(1.6)), 4)
+    np.testing.assert_allclose(k, [0.250404447, 0.205977082, 0.114643514, 0.043175146, 0.0110020069], rtol=1e-6)
+
+
+def test_derivative_factors_kat(okz):
+    f1, f2 = okz.deriv_factors()
+    assert bits(f1) == 0x3DC00001 and bits(f2) == 0x3EA00001
+
+
+def test_point_struct_layout(okz):
+    assert okz.lib().okz_sizeof_point() == 104
+    d = okz.POINT_DTYPE
+    offs = {n: d.fields[n][1] for n in d.names}
+    assert offs == dict(x=0, y=4, octave=8, response=12, size=16, angle=20, features=24, _pad=85, match=88,
+                        distance=92, match_x=96, match_y=100)
+
+
+def test_mldb_pair_table(okz):
+    a, b = okz.compare_indices()
+    assert (a[:486] < b[:486]).all() and ((b[:486] - a[:486]) % 3 == 0).all()
+    # 18 + 108 + 360 pairs, channel-major inside each grid
+    assert a[0] == 0 and b[0] == 3 and a[6] == 1 and a[18] == 12 and b[18] == 15 and a[126] == 39
+    assert len({(int(x), int(y)) for x, y in zip(a[:486], b[:486])}) == 486
+
+
+def test_oracle_on_reference_images_is_frozen(okz, golden):
+    """regression pin on data/left.pgm, right.pgm (also the survey's independent smoke datum: 3544 / 4695)"""
+    from akaze_hip import synth
+    for name, key, n in (("left", "pts1", 3544), ("right", "pts2", 4695)):
+        u8 = golden.lr_u8[name]
+        r = okz.detect_and_compute(synth.to_float(u8, 1280), 1280)
+        g = golden.lr[key]
+        assert len(r.points) == n == len(g)
+        for f in ("x", "y", "octave", "response", "size", "angle", "features"):
+            assert np.array_equal(r.points[f], g[f]), f
+    kc = golden.lr["kc"]
+    np.testing.assert_allclose(kc, [0.65252, 0.95842], rtol=1e-4)
+
+
+def test_oracle_match_frozen_and_rules(okz, golden):
+    p1, p2 = golden.lr["pts1"].copy(), golden.lr["pts2"].copy()
+    want = p1.copy()
+    p1["match"] = 0
+    okz.match(p1, p2)
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(p1[f], want[f])
+    acc = p1["match"] >= 0
+    assert acc.sum() == 2400 and (p1["distance"][acc] < 96).all() and (p1["distance"][~acc] == -1).all()
+    # brute-force check of the accept rule on a subset with numpy
+    f1, f2 = p1["features"][:200], p2["features"]
+    d = np.unpackbits(f1[:, None, :] ^ f2[None, :, :], axis=2).sum(axis=2)
+    for q in range(200):
+        dm = d[q].min()
+        idx = np.nonzero(d[q] == dm)[0]
+        ok = dm < 96 and len(set(idx % 16)) == 1
+        assert (p1["match"][q] == (idx[0] if ok else -1)) and (p1["distance"][q] == (dm if ok else -1))
+
+
+def test_oracle_match_edge_cases(okz):
+    from akaze_hip import synth
+    a = synth.random_descriptors(40, 1, okz.POINT_DTYPE)
+    b = a[:5].copy()                                    # n2 < 16
+    okz.match(a, b)
+    assert (a["match"][:5] == np.arange(5)).all() and (a["distance"][:5] == 0).all()
+    okz.match(a, b[:0])                                 # n2 == 0
+    assert (a["match"] == -1).all()
+    # duplicate train descriptors in different residue classes -> rejected; same class -> first wins
+    b = np.concatenate([a[:1], a[:1]])                  # j = 0 and 1: classes differ
+    okz.match(a[:1], b)
+    assert a["match"][0] == -1
+    b = synth.random_descriptors(17, 2, okz.POINT_DTYPE)
+    b[0] = a[0]; b[16] = a[0]                           # j = 0 and 16: same class
+    okz.match(a[:1], b)
+    assert a["match"][0] == 0 and a["distance"][0] == 0
+
+
+def test_oracle_synth_frozen(okz, golden):
+    from akaze_hip import synth
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    for name, w, h, seed, kw in mg.SYNTH_CASES:
+        r = mg.run_oracle(synth.scene(w, h, seed), **kw)
+        g = golden.synth[name + "_pts"]
+        assert len(g) > 20 and r.points.tobytes() == g.tobytes(), name
+
+
+def test_stage_properties(okz):
+    rng = np.random.default_rng(3)
+    w, h, p = 150, 97, 192
+    img = np.zeros((h, p), np.float32)
+    img[:, :w] = rng.uniform(0, 1, (h, w)).astype(np.float32)
+    # a constant image is a fixed point of every smoothing / diffusion stage
+    c = np.zeros((h, p), np.float32); c[:, :w] = 0.25
+    lp = okz.lowpass(c, w, 1.0, 2)
+    assert np.abs(lp[:, :w] - 0.25).max() < 1e-6
+    g = okz.flow(okz.lowpass(img, w, 1.0, 2), w, 1, 0.5)
+    assert (g[:, :w] > 0).all() and (g[:, :w] <= 1).all()
+    out = okz.nld_steps(c, g, w, [0.2, 5.0, 0.7])
+    assert np.array_equal(out[:, :w], c[:, :w])
+    # tau = 0 is the identity; a stable step (tau <= 0.25, g <= 1) obeys the maximum principle
+    assert np.array_equal(okz.nld_steps(img, g, w, [0.0])[:, :w], img[:, :w])
+    out = okz.nld_steps(img, g, w, [0.2, 0.25])
+    assert out[:, :w].min() >= img[:, :w].min() - 1e-6 and out[:, :w].max() <= img[:, :w].max() + 1e-6
+    # separable Gaussian == numpy reference with reflect-101 padding (fp tolerance)
+    k = okz.gauss_taps(1.0, 2).astype(np.float64)
+    full = np.concatenate([k[:0:-1], k])
+    pad = np.pad(img[:, :w].astype(np.float64), 2, mode="reflect")
+    rows = sum(full[i] * pad[:, i:i + w] for i in range(5))
+    ref = sum(full[i] * rows[i:i + h, :] for i in range(5))
+    assert np.abs(okz.lowpass(img, w, 1.0, 2)[:, :w] - ref).max() < 1e-6
