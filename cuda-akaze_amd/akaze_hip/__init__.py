@@ -16,6 +16,15 @@ import os
 
 import numpy as np
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7, and a process that
+# loads /opt/rocm's copy first makes torch see "No HIP GPUs" (and vice versa: measured on the GPU
+# box, tools/probe_runtime.py).  Importing torch first lets libhipakaze.so bind to the runtime
+# torch already loaded (same soname); without torch the library uses /opt/rocm's.
+try:
+    import torch as _torch  # noqa: F401
+except ImportError:          # pure C-ABI use without PyTorch
+    _torch = None
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhipakaze.so")
 

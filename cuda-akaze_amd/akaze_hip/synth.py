@@ -14,7 +14,7 @@ import numpy as np
 def scene(w, h, seed, nshapes=None):
     rng = np.random.default_rng(seed)
     if nshapes is None:
-        nshapes = max(40, int(400 * (w * h) / (1920.0 * 1080.0)))
+        nshapes = max(25, int(175 * (w * h) / (1920.0 * 1080.0)))
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     img = 0.35 + 0.25 * (xx / w) + 0.15 * (yy / h)
     for _ in range(nshapes):

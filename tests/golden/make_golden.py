@@ -71,11 +71,15 @@ SYNTH_CASES = [
 ]
 
 
+def case_scene(w, h, seed):
+    """small golden scenes are drawn denser than the bench scenes so they hold enough keypoints"""
+    return synth.scene(w, h, seed, nshapes=30 + int(700 * (w * h) / (1920.0 * 1080.0)))
+
+
 def synth_golden():
     out = {}
     for name, w, h, seed, kw in SYNTH_CASES:
-        u8 = synth.scene(w, h, seed)
-        r = run_oracle(u8, **kw)
+        r = run_oracle(case_scene(w, h, seed), **kw)
         out[name + "_pts"] = r.points
         out[name + "_kc"] = np.array([r.kcontrast], np.float32)
         print(name, len(r.points))

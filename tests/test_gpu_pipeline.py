@@ -50,17 +50,21 @@ def okz_params(okz, **kw):
     return okz.default_params(**m)
 
 
-def load_cases():
+def _mg():
     spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
-    return mg.SYNTH_CASES
+    return mg
+
+
+def load_cases():
+    return _mg().SYNTH_CASES
 
 
 @pytest.mark.parametrize("case", load_cases(), ids=lambda c: c[0])
 def test_synth_golden(ah, torch, synth, golden, case):
     name, w, h, seed, kw = case
-    pts = gpu_detect(ah, torch, synth, synth.scene(w, h, seed), **kw)
+    pts = gpu_detect(ah, torch, synth, _mg().case_scene(w, h, seed), **kw)
     g = golden.synth[name + "_pts"]
     assert_points_equal(pts, g)
     rel = np.abs(pts["response"] - g["response"]) / np.abs(g["response"])
@@ -70,7 +74,7 @@ def test_synth_golden(ah, torch, synth, golden, case):
 def test_planes_small(ah, okz, torch, synth):
     """every persistent plane of every level, bit for bit (localises a failing stage)"""
     w, h = 320, 240
-    u8 = synth.scene(w, h, 11)
+    u8 = _mg().case_scene(w, h, 11)
     pts, det, data = gpu_detect(ah, torch, synth, u8, keep=True)
     r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, keep_arena=True)
     assert np.float32(det.kcontrast()).view(np.uint32) == r.kcontrast.view(np.uint32)
@@ -117,7 +121,7 @@ def test_full_size_vs_oracle(ah, okz, torch, synth, w, h, kw):
 
 
 def test_max_pts_clamp_is_raster_prefix(ah, okz, torch, synth):
-    u8 = synth.scene(640, 480, 21)
+    u8 = _mg().case_scene(640, 480, 21)
     full = okz.detect_and_compute(synth.to_float(u8, 640), 640).points
     assert len(full) > 60
     pts = gpu_detect(ah, torch, synth, u8, max_pts=50)
@@ -126,7 +130,7 @@ def test_max_pts_clamp_is_raster_prefix(ah, okz, torch, synth):
 
 
 def test_no_descriptors(ah, okz, torch, synth):
-    u8 = synth.scene(320, 240, 11)
+    u8 = _mg().case_scene(320, 240, 11)
     pts = gpu_detect(ah, torch, synth, u8, desc=False)
     r = okz.detect_and_compute(synth.to_float(u8, 384), 320, desc=False)
     assert_points_equal(pts, r.points)
@@ -137,7 +141,7 @@ def test_batch_equals_single(ah, torch, synth):
     """blockIdx.z batching: B different images in one launch sequence == B single calls"""
     w, h, B, mp = 400, 300, 5, 2000
     p = ah.iAlignUp(w, 128)
-    imgs = [synth.scene(w, h, 100 + i) for i in range(B)]
+    imgs = [_mg().case_scene(w, h, 100 + i) for i in range(B)]
     singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in imgs]
     stack = torch.from_numpy(np.stack([synth.to_float(u, p) for u in imgs])).cuda()
     det = ah.Akazer()
@@ -165,7 +169,7 @@ def test_batch_equals_single(ah, torch, synth):
 
 
 def test_repeat_calls_are_deterministic(ah, torch, synth):
-    u8 = synth.scene(640, 360, 13)
+    u8 = _mg().case_scene(640, 360, 13)
     a = gpu_detect(ah, torch, synth, u8)
     b = gpu_detect(ah, torch, synth, u8)
     assert a.tobytes() == b.tobytes()

@@ -134,7 +134,7 @@ def test_oracle_synth_frozen(okz, golden):
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
     for name, w, h, seed, kw in mg.SYNTH_CASES:
-        r = mg.run_oracle(synth.scene(w, h, seed), **kw)
+        r = mg.run_oracle(mg.case_scene(w, h, seed), **kw)
         g = golden.synth[name + "_pts"]
         assert len(g) > 20 and r.points.tobytes() == g.tobytes(), name
 
