@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""bench.py -- detect + describe + match throughput of the HIP AKAZE path on MI355X.
+
+Contract (one JSON line on rank 0):
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload = BASELINE.json configs[1]: 1920x1080 grayscale pairs, 4 octaves x 4 sublevels, PM_G2, MLDB,
+max 10000 points (main.cpp:156-166).  One "step" = one pass of the hot path over one batch of
+--pairs synthetic pairs per GPU: Akazer::detectAndCompute on both images of every pair + cuMatch,
+ending with host-visible keypoints / descriptors / matches (the reference's timed region,
+main.cpp:199-209, with its D2H copies).  Inputs are resident in HBM before the timer starts.
+Frames shard by independent pair across ranks (weak scaling, no data-path collective); RCCL is used
+only for the barrier, the max-over-ranks time and the trivial result-summary gather.
+
+Extra objects: "roofline" for the dominant kernel (the FED step, 12 B/px/step algorithmic)
+measured with HIP events on the launch stream inside this run; "cpu_baseline" = the CPU oracle
+(kind "port") timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _sub in ("cuda-akaze_amd", "oracle"):
+    sys.path.insert(0, os.path.join(ROOT, _sub))
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+
+
+def shard_pairs(total_pairs, world, rank):
+    """contiguous block partition of independent pairs over ranks"""
+    per = (total_pairs + world - 1) // world
+    lo = min(rank * per, total_pairs)
+    return lo, min(lo + per, total_pairs)
+
+
+def cpu_baseline(w, h, p, u8_pairs, budget_s=20.0):
+    """the oracle (CPU port of the reference algorithm, OpenMP) on the same 1080p pairs"""
+    import okz
+    from akaze_hip import synth
+    okz.build()
+    imgs = [(synth.to_float(a, p), synth.to_float(b, p)) for a, b in u8_pairs]
+    n, t0 = 0, time.time()
+    # warm-up pair (page-in, OpenMP pool)
+    okz.detect_and_compute(imgs[0][0], w)
+    t0 = time.time()
+    while True:
+        a, b = imgs[n % len(imgs)]
+        r1 = okz.detect_and_compute(a, w)
+        r2 = okz.detect_and_compute(b, w)
+        okz.match(r1.points, r2.points)
+        n += 1
+        el = time.time() - t0
+        if el > budget_s or n >= 40:
+            break
+    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    return {"value": round(n / el, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": f"{n} synthetic 1920x1080 pairs (detect+describe both images + match), {el:.1f} s, OpenMP oracle"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs", type=int, default=16, help="pairs per GPU per step (batch)")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--octaves", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and rank == 0:
+        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import akaze_hip as ah
+    from akaze_hip import synth
+    ah.check(ah.lib.hak_set_device(local_rank))
+
+    w, h = args.width, args.height
+    p = ah.iAlignUp(w, 128)
+    B = args.pairs
+    nimg = 2 * B
+    max_pts = 10000
+
+    # ---- synthetic inputs, resident in HBM (2 distinct seeded pairs per rank, cycled over the batch)
+    u8_pairs = [synth.pair(w, h, 1 + 2 * rank + i) for i in range(2)]
+    host = np.stack([synth.to_float(u8_pairs[(i // 2) % 2][i % 2], p) for i in range(nimg)])
+    d_imgs = torch.from_numpy(host).cuda()
+    del host
+
+    det = ah.Akazer()
+    det.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg)
+    stream = torch.cuda.current_stream()
+    ah.check(ah.lib.hak_set_stream(det.ctx, C.c_void_p(stream.cuda_stream)))
+    d_pts = torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda")
+    d_num = torch.zeros(nimg, dtype=torch.int32, device="cuda")
+    h_pts, h_num = C.c_void_p(), C.c_void_p()
+    ah.check(ah.lib.hak_host_alloc(C.byref(h_pts), nimg * max_pts * 104))
+    ah.check(ah.lib.hak_host_alloc(C.byref(h_num), nimg * 4))
+
+    def step():
+        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, d_imgs.data_ptr(), h * p, p, nimg,
+                                                     d_pts.data_ptr(), d_num.data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B))
+        ah.check(ah.lib.hak_download_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), nimg, h_pts, h_num))
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    counts = np.ctypeslib.as_array(C.cast(h_num, C.POINTER(C.c_int)), shape=(nimg,)).copy()
+    pts = np.ctypeslib.as_array(C.cast(h_pts, C.POINTER(C.c_uint8)), shape=(nimg * max_pts * 104,)).view(ah.POINT_DTYPE).reshape(nimg, max_pts)
+    nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(B)))
+    # ---- the trivial result gather: per-rank summary {pairs, keypoints, matches}
+    summary = torch.tensor([B, int(counts.sum()), nmatch], dtype=torch.int64, device="cuda")
+    if world > 1:
+        allsum = [torch.zeros_like(summary) for _ in range(world)]
+        dist.all_gather(allsum, summary)
+        summary = torch.stack(allsum).sum(0)
+    summary = summary.cpu().tolist()
+
+    # ---- roofline leg: same steps with per-launch HIP events on the launch stream
+    roof = None
+    if not args.no_roofline:
+        ah.check(ah.lib.hak_prof_reset(det.ctx))
+        ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
+        nprof = max(1, min(args.steps, 3))
+        for _ in range(nprof):
+            step()
+        ms, n = C.c_double(), C.c_int()
+        ah.check(ah.lib.hak_prof_read(det.ctx, ah.PROF["fed"], C.byref(ms), C.byref(n)))
+        ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
+        tr = det.traffic(int(counts.mean()))
+        bytes_per_launch = tr.fed_bytes * nimg / tr.fed_launches          # 12 B x px-steps x images / launches
+        avg_s = ms.value * 1e-3 / n.value
+        achieved = bytes_per_launch / avg_s / 1e9
+        cls = {}
+        for name, k in ah.PROF.items():
+            m2, n2 = C.c_double(), C.c_int()
+            ah.check(ah.lib.hak_prof_read(det.ctx, k, C.byref(m2), C.byref(n2)))
+            cls[name] = round(m2.value / nprof, 4)
+        roof = {"kernel": "k_fed_step", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
+                "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w, h, p, u8_pairs)
+
+    if rank == 0:
+        total_pairs = world * B * args.steps
+        out = {
+            "metric": "pairs_per_sec_detect_describe_match_1080p", "value": round(total_pairs / elapsed, 2),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"configs[1]: {w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
+                                   "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
+                       "pairs_per_step_per_gpu": B, "sharding": "independent pairs per rank, no data-path collective",
+                       "keypoints_per_image": round(summary[1] / (2.0 * summary[0]), 1),
+                       "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(out))
+    ah.lib.hak_host_free(h_pts)
+    ah.lib.hak_host_free(h_num)
+    det.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -51,7 +51,8 @@ def test_down_smooth(ah, okz, torch, sw, sh):
     dp = (dw + 63) // 64 * 64
     d_dst = torch.zeros((dh, dp), dtype=torch.float32, device="cuda")
     d_sm = torch.zeros((dh, dp), dtype=torch.float32, device="cuda")
-    ah.check(ah.lib.hak_op_down_smooth(dev(torch, a).data_ptr(), d_dst.data_ptr(), d_sm.data_ptr(), sw, sh, sp, dw, dh, dp))
+    d_a = dev(torch, a)
+    ah.check(ah.lib.hak_op_down_smooth(d_a.data_ptr(), d_dst.data_ptr(), d_sm.data_ptr(), sw, sh, sp, dw, dh, dp))
     o_dst, o_sm = okz.down_smooth(a, sw, dw, dh, dp)
     assert eq(d_dst, o_dst, dw) and eq(d_sm, o_sm, dw)
 
@@ -63,7 +64,8 @@ def test_kcontrast(ah, okz, torch, w, h):
     sm = okz.lowpass(a, w, 1.0, 2)
     kc, hmax = C.c_float(), C.c_float()
     hist = np.zeros(300, np.int32)
-    ah.check(ah.lib.hak_op_kcontrast(dev(torch, sm).data_ptr(), w, h, p, 0.7, C.byref(kc), C.byref(hmax),
+    d_sm = dev(torch, sm)
+    ah.check(ah.lib.hak_op_kcontrast(d_sm.data_ptr(), w, h, p, 0.7, C.byref(kc), C.byref(hmax),
                                      hist.ctypes.data_as(C.POINTER(C.c_int))))
     okc, ohmax, ohist = okz.kcontrast(okz.scharr_grad(sm, w), w, 0.7)
     assert np.float32(hmax.value) == ohmax
@@ -77,7 +79,8 @@ def test_flow(ah, okz, torch, w, h, diff):
     rng = np.random.default_rng(w + 2)
     a, p = plane(rng, w, h)
     d_dst = torch.zeros((h, p), dtype=torch.float32, device="cuda")
-    ah.check(ah.lib.hak_op_flow(dev(torch, a).data_ptr(), d_dst.data_ptr(), w, h, p, diff, 0.37))
+    d_a = dev(torch, a)
+    ah.check(ah.lib.hak_op_flow(d_a.data_ptr(), d_dst.data_ptr(), w, h, p, diff, 0.37))
     assert eq(d_dst, okz.flow(a, w, diff, 0.37), w)
 
 
@@ -90,7 +93,8 @@ def test_fed_steps(ah, okz, torch, w, h, taus):
     d_dst = torch.zeros((h, p), dtype=torch.float32, device="cuda")
     d_tmp = torch.zeros((h, p), dtype=torch.float32, device="cuda")
     t = np.array(taus, np.float32)
-    ah.check(ah.lib.hak_op_nld_steps(dev(torch, a).data_ptr(), dev(torch, g).data_ptr(), d_dst.data_ptr(),
+    d_a, d_g = dev(torch, a), dev(torch, g)          # keep both alive: a freed temporary's memory is reused
+    ah.check(ah.lib.hak_op_nld_steps(d_a.data_ptr(), d_g.data_ptr(), d_dst.data_ptr(),
                                      d_tmp.data_ptr(), w, h, p, t.ctypes.data_as(C.POINTER(C.c_float)), len(taus)))
     assert eq(d_dst, okz.nld_steps(a, g, w, taus), w)
 
@@ -101,7 +105,8 @@ def test_hessian(ah, okz, torch, w, h, step):
     rng = np.random.default_rng(w + 4)
     a, p = plane(rng, w, h)
     outs = [torch.zeros((h, p), dtype=torch.float32, device="cuda") for _ in range(3)]
-    ah.check(ah.lib.hak_op_hessian(dev(torch, a).data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
+    d_a = dev(torch, a)
+    ah.check(ah.lib.hak_op_hessian(d_a.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(),
                                    w, h, p, step))
     lx, ly, det = okz.hessian(a, w, step)
     assert eq(outs[0], lx, w) and eq(outs[1], ly, w) and eq(outs[2], det, w)
