@@ -1,0 +1,101 @@
+// akaze.cpp -- akaze::Akazer / initAkazeData / freeAkazeData / cuMatch over the C ABI.
+// Behavioural mirror of the reference's akaze.cpp:24-150 (same call contract and error style);
+// all device work happens behind hipakaze.h.
+#include "akaze.h"
+#include <cstdio>
+#include <cstdlib>
+
+namespace
+{
+    void die(const char* what)
+    {
+        fprintf(stderr, "hip-akaze: %s failed: %s\n", what, hak_last_error());
+        exit(-1);                                                     // cuda_utils.h:23
+    }
+}
+
+namespace akaze
+{
+    void initAkazeData(AkazeData& data, const int max_pts, const bool host, const bool dev)       // akaze.cpp:26-40
+    {
+        data.num_pts = 0;
+        data.max_pts = max_pts;
+        data.h_data = host ? (AkazePoint*)malloc(sizeof(AkazePoint) * (size_t)max_pts) : NULL;
+        data.d_data = NULL;
+        if (dev && hak_points_alloc(&data.d_data, max_pts)) die("initAkazeData");
+    }
+
+    void freeAkazeData(AkazeData& data)                                                          // akaze.cpp:43-52
+    {
+        if (data.d_data != NULL && hak_points_free(data.d_data)) die("freeAkazeData");
+        if (data.h_data != NULL) free(data.h_data);
+        data.d_data = NULL;
+        data.h_data = NULL;
+        data.num_pts = 0;
+        data.max_pts = 0;
+    }
+
+    void cuMatch(AkazeData& result1, AkazeData& result2)                                         // akaze.cpp:55-64
+    {
+        if (hak_match(NULL, result1.d_data, result1.num_pts, result2.d_data, result2.num_pts, result1.h_data))
+            die("cuMatch");
+    }
+
+    Akazer::Akazer() { hak_default_config(&cfg); }
+
+    Akazer::~Akazer() { hak_destroy(ctx); }                                                     // akaze.cpp:74-77
+
+    void Akazer::setMaxPoints(int max_pts) { cfg.max_pts = max_pts; hak_destroy(ctx); ctx = nullptr; }
+    void Akazer::setUpright(bool upright) { cfg.upright = upright ? 1 : 0; hak_destroy(ctx); ctx = nullptr; }
+
+    void Akazer::ensureContext(int w, int h)
+    {
+        if (ctx && ctx_w == w && ctx_h == h) return;
+        hak_destroy(ctx);
+        ctx = nullptr;
+        if (hak_create(&cfg, w, h, &ctx)) die("Akazer: hak_create");
+        ctx_w = w;
+        ctx_h = h;
+    }
+
+    void Akazer::init(int3 whp0, int _noctaves, int _max_scale, float _per, float _kcontrast, float _soffset, bool _reordering,
+                      float _derivative_factor, float _dthreshold, int _diffusivity, int _descriptor_pattern_size)
+    {
+        whp = whp0;                                                                             // akaze.cpp:83-95
+        cfg.noctaves = _noctaves;
+        cfg.max_scale = _max_scale;
+        cfg.per = _per;
+        cfg.kcontrast = _kcontrast;
+        cfg.soffset = _soffset;
+        cfg.reordering = _reordering ? 1 : 0;
+        cfg.derivative_factor = _derivative_factor;
+        cfg.dthreshold = _dthreshold;
+        cfg.diffusivity = _diffusivity;
+        cfg.descriptor_pattern_size = _descriptor_pattern_size;
+        cfg.batch = 1;
+        hak_destroy(ctx);
+        ctx = nullptr;
+        ensureContext(whp.x, whp.y);                  // arena allocated once for the init size ("reused", akaze.cpp:109-113)
+    }
+
+    void Akazer::detectAndCompute(float* image, AkazeData& result, int3 whp0, const bool desc)   // akaze.cpp:101-150
+    {
+        ensureContext(whp0.x, whp0.y);                // other size than init(): new arena (akaze.cpp:114-117)
+        if (result.max_pts < cfg.max_pts) {
+            // the reference clamps to result.max_pts (akaze.cpp:246, 451); rebuild the context for the smaller capacity
+            cfg.max_pts = result.max_pts;
+            hak_destroy(ctx);
+            ctx = nullptr;
+            ensureContext(whp0.x, whp0.y);
+        }
+        if (hak_detect_and_compute(ctx, image, whp0.z, result.d_data, result.max_pts, &result.num_pts, result.h_data, desc ? 1 : 0))
+            die("detectAndCompute");
+    }
+
+    void Akazer::fastDetectAndCompute(unsigned char*, AkazeData&, int3, const bool)
+    {
+        // integer 16.16 fixed-point path (akaze.cpp:153-201): SURVEY 8f.1, not built this round
+        fprintf(stderr, "hip-akaze: fastDetectAndCompute (integer FAST path) is not implemented\n");
+        exit(-1);
+    }
+}
