@@ -152,6 +152,7 @@ struct hak_ctx {
     bool prof_on = false;
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
+    int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
 };
 
 static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -264,6 +265,10 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     c->cfg = *cfg;
     if (c->cfg.batch < 1) c->cfg.batch = 1;
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
+    if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
+        int v = atoi(e);
+        c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
+    }
     if (build_plan(c, w, h)) { delete c; return 1; }
     const int B = c->cfg.batch;
     const HakLayout& L = c->L;
@@ -349,15 +354,15 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 { ProfScope ps(c, HAK_PROF_LOWPASS);
                   hak_launch_lowpass(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps_base, c->base_R); }
                 { ProfScope ps(c, HAK_PROF_HESSIAN);
-                  hak_launch_derivate(st, Lt, A + L.lx(o, s), A + L.ly(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-                  hak_launch_hessian(st, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+                  hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
                 continue;
             }
             const int n = lp.nsteps;
-            const float* fsrc;          // input of the first FED step
+            const int G = hak_fed_groups(n, c->max_fuse, oc.w);     // launches of this FED cycle
+            const float* fsrc;          // input of the first FED launch
             if (s == 0) {                                                         // akaze.cpp:369-392
-                // decimate Lt(o-1,0) so that the last of n ping-pong steps lands in Lt(o,0)
-                float* first = (n % 2 == 0) ? Lt : tmp;
+                // decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
+                float* first = (G % 2 == 0) ? Lt : tmp;
                 { ProfScope ps(c, HAK_PROF_DOWN);
                   hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1); }
                 fsrc = first;
@@ -369,21 +374,21 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             { ProfScope ps(c, HAK_PROF_FLOW);
               hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f); }
             {
-                // n explicit steps, ping-pong between Lt and tmp, ending in Lt
+                // the n explicit steps of the cycle in G fused launches, ping-pong Lt <-> tmp, ending in Lt
                 const float* src = fsrc;
-                for (int k = 0; k < n; k++) {
-                    float* dst;
-                    if (s == 0) dst = (src == Lt) ? tmp : Lt;
-                    else dst = ((n - k) % 2 == 1) ? Lt : tmp;
+                int done = 0;
+                for (int g = 0; g < G; g++) {
+                    const int ns = hak_fed_group_size(n, G, g);
+                    float* dst = ((G - g) % 2 == 1) ? Lt : tmp;
                     ProfScope ps(c, HAK_PROF_FED);
-                    hak_launch_fed_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, 0.5f * lp.tau[k]);   // akazed.cu:2515
+                    hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
                     c->fed_launches++;
+                    done += ns;
                     src = dst;
                 }
             }
             { ProfScope ps(c, HAK_PROF_HESSIAN);                                  // akaze.cpp:423
-              hak_launch_derivate(st, smooth, A + L.lx(o, s), A + L.ly(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-              hak_launch_hessian(st, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+              hak_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
         }
         { ProfScope ps(c, HAK_PROF_EXTREMA);                                      // akaze.cpp:431-433
           hak_launch_extrema(st, b, L, c->dtab, o, cfg.dthreshold); }
@@ -555,7 +560,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
         for (int s = 0; s < L.ms; s++) {
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             pxsteps += N * lp.nsteps;
-            launches += lp.nsteps;
+            launches += lp.nsteps ? hak_fed_groups(lp.nsteps, c->max_fuse, L.oct[o].w) : 0;
             if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue
             else if (s == 0) all += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 8.0 * N + 8.0 * N + 24.0 * N + 4.0 * N;
             else all += 44.0 * N;
@@ -643,10 +648,16 @@ extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst,
 {
     if (nsteps < 1) return fail("nsteps < 1");
     if (p % 4) return fail("pitch must be a multiple of 4");
+    int fuse = 4;
+    if (const char* e = getenv("HAK_FED_MAX_FUSE")) fuse = atoi(e);
+    const int G = hak_fed_groups(nsteps, fuse, w);
     const float* s = src;
-    for (int k = 0; k < nsteps; k++) {
-        float* d = ((nsteps - k) % 2 == 1) ? dst : tmp;
-        hak_launch_fed_step(nullptr, s, flow, d, 0, w, h, p, 1, 0.5f * tau[k]);
+    int done = 0;
+    for (int g = 0; g < G; g++) {
+        const int ns = hak_fed_group_size(nsteps, G, g);
+        float* d = ((G - g) % 2 == 1) ? dst : tmp;
+        hak_launch_fed_group(nullptr, s, flow, d, 0, w, h, p, 1, tau + done, ns);
+        done += ns;
         s = d;
     }
     HIP_TRY(hipDeviceSynchronize());
@@ -655,8 +666,7 @@ extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst,
 
 extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, int w, int h, int p, int step)
 {
-    hak_launch_derivate(nullptr, s, lx, ly, 0, w, h, p, 1, step);
-    hak_launch_hessian(nullptr, lx, ly, det, 0, w, h, p, 1, step);
+    hak_launch_hessian_level(nullptr, s, lx, ly, det, 0, w, h, p, 1, step);
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }

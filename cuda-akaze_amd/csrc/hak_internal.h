@@ -158,6 +158,14 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
                      int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
 void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
                          int w, int h, int p, int nimg, float stepfac);
+void hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                              int w, int h, int p, int nimg, int step);
+// fused FED groups (kernels_fed.hip)
+#define HAK_FED_MAX_FUSE 4
+int hak_fed_groups(int n, int max_fuse, int w);
+int hak_fed_group_size(int n, int G, int g);
+void hak_launch_fed_group(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+                          int w, int h, int p, int nimg, const float* tau, int ns);
 void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly, long stride,
                          int w, int h, int p, int nimg, int step);
 void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,

@@ -1,0 +1,296 @@
+// kernels_fed.hip -- the FED hot loop: NS explicit diffusion steps fused in one launch.
+//
+//   hNldStep/gNldStepNaive  akazed.cu:2509, 1241   (one step:  L' = fma(0.5*tau, sum_{E,W,S,N}(g+g_n)(L_n-L), L))
+//   loop over tau[k]        akaze.cpp:381-391, 408-420
+//
+// The conductivity g is fixed for all steps of a sublevel (akaze.cpp:379, 404), so the n steps of a
+// FED cycle are pipelined in time.  A wave owns a 256-px-wide strip (one float4 per lane, 1 KiB
+// contiguous per row) and streams down the rows.  For each fused level k < NS it keeps a 3-row
+// register window; when input row t arrives, level k produces row t-k from level k-1's window, so
+// L and g are read from HBM once and L' written once per NS steps (12 B/px per launch instead of
+// 12 B/px per step).  East/west neighbours come from the adjacent lane with one DPP wave shift;
+// no LDS, no barriers.  The strip's outer HX columns and the NS warm-up rows above/below a strip are
+// recomputed by the neighbouring wave (halo): efficiency (256-2HX)/256 x RY/(RY+2NS).
+//
+// The kernel is VALU-issue-bound (rocprof: 4 waves/SIMD x 26 % VALU-active), so the inner loop is
+// written for instruction count:
+//   * the pair sums (g+gE), (g+gS) are formed ONCE per g row (GH: 5 horizontal sums per lane,
+//     GV: 4 vertical sums) and reused by all NS levels and by both pixels that share the pair
+//     -- (g+gE) of pixel x and (g+gW) of pixel x+1 are the same IEEE sum;
+//   * the horizontal flux product P = (g[x-1]+g[x]) * (L[x]-L[x-1]) is shared: term_E(x-1) = P,
+//     term_W(x) = -P exactly, so  (tE + tW) = P[x+1] - P[x]  bit for bit;
+//   * the register windows rotate statically (loop unrolled by 6 with compile-time slots) instead
+//     of being shifted with v_mov;
+//   * border selects (reflect-101) are applied where a row / column IS a border, not per pixel.
+//
+// Bit-exactness: every level evaluates the reference's per-pixel expression in the reference's
+// order  ((tE + tW) + tS) + tN  then fma(stepfac, sum, L), and the reflect-101 rule (abs /
+// borderAdd, akazed.cu:1251-1254) is applied at EVERY level (mirroring level-0 rows instead would
+// swap the S and N terms and change roundings).
+#include "hak_internal.h"
+
+template <int NS>
+struct FedFacs { float f[NS]; };
+
+__device__ __forceinline__ float wave_shr1(float v)      // lane i <- lane i-1 (lane 0 keeps its own)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float wave_shl1(float v)      // lane i <- lane i+1 (lane 63 keeps its own)
+{
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+}
+
+constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
+
+// horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 0..4
+struct GHrow { float h0, h1, h2, h3, h4; };
+
+template <int NS>
+struct FedState {
+    static constexpr int GS = 6;        // slots of the g-sum ring (needs NS + 2 <= GS)
+    float4 Lw[NS][3];                   // level k (0 = input): ring of 3 rows, slot = (row - origin) mod 3
+    GHrow GH[GS];                       // ring: horizontal sums of g row r        at slot (r - origin) mod GS
+    float4 GV[GS];                      // ring: g[r] + g[r+1]                     at slot (r - origin) mod GS
+    float4 gprev;                       // g row t-1
+    float4 Lnext, Gnext;                // software prefetch of input row t+1
+};
+
+// one output row (4 px per lane) of one level
+template <bool XEDGE>
+__device__ __forceinline__ float4 fed_row(const float4 Lc, const float4 Ln, const float4 Ls, const GHrow& gh,
+                                          const float4 gvS, const float4 gvN, int x0, int w, float stepfac)
+{
+    float Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x);
+    if (XEDGE) {
+        // reflect-101 in x: abs(x-1) = 1 at x == 0; borderAdd(x,1,w) = w-2 at x == w-1 (w % 4 == 0 here,
+        // so x == w-1 is the lane's last component); the matching g-sums were folded into gh already
+        Ll = x0 == 0 ? Lc.y : Ll;
+        Lr = x0 + 3 == w - 1 ? Lc.z : Lr;
+    }
+    // d[j] = L[x0+j] - L[x0+j-1], P[j] = h[j] * d[j]
+    const float d0 = Lc.x - Ll, d1 = Lc.y - Lc.x, d2 = Lc.z - Lc.y, d3 = Lc.w - Lc.z, d4 = Lr - Lc.w;
+    const float P0 = gh.h0 * d0, P1 = gh.h1 * d1, P2 = gh.h2 * d2, P3 = gh.h3 * d3, P4 = gh.h4 * d4;
+    float4 o;
+    // ((tE + tW) + tS) + tN ; tE = P[e+1], tW = -P[e]
+    o.x = fmaf(stepfac, ((P1 - P0) + gvS.x * (Ls.x - Lc.x)) + gvN.x * (Ln.x - Lc.x), Lc.x);
+    o.y = fmaf(stepfac, ((P2 - P1) + gvS.y * (Ls.y - Lc.y)) + gvN.y * (Ln.y - Lc.y), Lc.y);
+    o.z = fmaf(stepfac, ((P3 - P2) + gvS.z * (Ls.z - Lc.z)) + gvN.z * (Ln.z - Lc.z), Lc.z);
+    o.w = fmaf(stepfac, ((P4 - P3) + gvS.w * (Ls.w - Lc.w)) + gvN.w * (Ln.w - Lc.w), Lc.w);
+    return o;
+}
+
+// One row-iteration.  Everything is computed unconditionally: a level-k row outside the range this
+// strip can produce exactly is garbage that no valid row ever reads (validity shrinks one row per
+// level exactly like the halo), so the body is branch-free except for the final store and the two
+// reflect-101 injections:  row -1 := row 1 (written when row 1 is produced) and row h := row h-2
+// (written at the iteration that would produce row h) -- for every level and for the g-sum ring.
+template <int NS, int U, bool YEDGE>
+__device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const float* __restrict__ L,
+                                         const float* __restrict__ G, float* __restrict__ D, const int p, const int xl,
+                                         const int x0, const int w, const int h,
+                                         const int ybeg, const int yend, const bool owns, const FedFacs<NS>& fac)
+{
+    constexpr int GS = FedState<NS>::GS;
+    // ---- level 0: input row t arrives (prefetched); request row t+1 (clamped: rows past the image are never used)
+    {
+        const float4 g = S.Gnext;
+        S.Lw[0][pmod(U, 3)] = S.Lnext;
+        const long nrow = (long)min(t + 1, h - 1) * p + xl;
+        S.Lnext = *reinterpret_cast<const float4*>(L + nrow);
+        S.Gnext = *reinterpret_cast<const float4*>(G + nrow);
+        const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
+        GHrow gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
+        gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                    // (g+gW) at x == 0 is (g+gE)
+        gh.h4 = x0 + 3 == w - 1 ? gh.h3 : gh.h4;            // (g+gE) at x == w-1 is (g+gW)
+        S.GH[pmod(U, GS)] = gh;
+        S.GV[pmod(U - 1, GS)] = make_float4(S.gprev.x + g.x, S.gprev.y + g.y, S.gprev.z + g.z, S.gprev.w + g.w);
+        S.gprev = g;
+        if (YEDGE && t == 1) {                              // abs(y-1) = 1: row -1 := row 1, GV[-1] := GV[0]
+            S.Lw[0][pmod(U - 2, 3)] = S.Lw[0][pmod(U, 3)];
+            S.GV[pmod(U - 2, GS)] = S.GV[pmod(U - 1, GS)];
+        }
+        if (YEDGE && t == h) {                              // borderAdd(y,1,h) = h-2: row h := row h-2, GV[h-1] := GV[h-2]
+            S.Lw[0][pmod(U, 3)] = S.Lw[0][pmod(U - 2, 3)];
+            S.GV[pmod(U - 1, GS)] = S.GV[pmod(U - 2, GS)];
+        }
+    }
+    // ---- levels 1..NS: level k produces row t-k from level k-1's ring (rows t-k-1, t-k, t-k+1)
+#pragma unroll
+    for (int k = 1; k <= NS; k++) {
+        const int rho = t - k;
+        const float4 out = fed_row<true>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
+                                          S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
+                                          S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
+        if (k < NS) {
+            S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
+            if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
+            if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
+        } else if (rho >= ybeg && rho < yend && owns) {
+            *reinterpret_cast<float4*>(D + (long)rho * p + x0) = out;
+        }
+    }
+}
+
+// requires w % 4 == 0 (true for every octave of BASELINE's configs); other widths: k_fed_generic
+template <int NS>
+__device__ __forceinline__ void fed_strip(const float* __restrict__ L, const float* __restrict__ G,
+                                          float* __restrict__ D, int w, int h, int p, const FedFacs<NS>& fac,
+                                          int x0, int ybeg, int yend, bool owns)
+{
+    const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
+    const int t0 = max(0, ybeg - NS);                       // first input row; level k is exact from row t0 + k (or 0)
+    const int tend = min(yend - 1, h - 1) + NS;             // iteration that emits the strip's last output row
+    FedState<NS> S;
+#pragma unroll
+    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < FedState<NS>::GS; i++) {
+        S.GH[i] = GHrow{0.f, 0.f, 0.f, 0.f, 0.f};
+        S.GV[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    S.gprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    S.Lnext = *reinterpret_cast<const float4*>(L + (long)t0 * p + xl);
+    S.Gnext = *reinterpret_cast<const float4*>(G + (long)t0 * p + xl);
+    for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 3 / mod 6: static per unrolled body
+        // the reflect injections can only fire while some level is at row 1 or row h
+        if (tb <= NS || tb + 5 >= h) {
+            fed_iter<NS, 0, true>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, true>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, true>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, true>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, true>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, true>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+        } else {
+            fed_iter<NS, 0, false>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, false>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, false>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, false>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, false>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, false>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+        }
+    }
+}
+
+template <int NS>
+__global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src, const float* __restrict__ flow,
+                                                   float* __restrict__ dst, long stride, int w, int h, int p,
+                                                   FedFacs<NS> fac, int ry, int xv, int hx)
+{
+    const float* L = src + (long)blockIdx.z * stride;
+    const float* G = flow + (long)blockIdx.z * stride;
+    float* D = dst + (long)blockIdx.z * stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> row bookkeeping in SGPRs
+    const int x0 = blockIdx.x * xv - hx + 4 * lane;         // first pixel of this lane (may lie outside the image)
+    const int ybeg = (blockIdx.y * 4 + wv) * ry;
+    if (ybeg >= h) return;                                  // wave-uniform
+    const int yend = min(ybeg + ry, h);
+    const bool owns = 4 * lane >= hx && 4 * lane < hx + xv && x0 < w && x0 >= 0;
+    fed_strip<NS>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
+}
+
+// any width (w % 4 != 0): ONE step per launch with the per-pixel form of the reference expression;
+// only odd-sized test images take this path
+__global__ __launch_bounds__(256) void k_fed_generic(const float* __restrict__ src, const float* __restrict__ flow,
+                                                     float* __restrict__ dst, long stride, int w, int h, int p,
+                                                     float stepfac, int ry)
+{
+    const float* L = src + (long)blockIdx.z * stride;
+    const float* G = flow + (long)blockIdx.z * stride;
+    float* D = dst + (long)blockIdx.z * stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> row bookkeeping in SGPRs
+    const int x0 = blockIdx.x * 248 - 4 + 4 * lane;
+    const int ybeg = (blockIdx.y * 4 + wv) * ry;
+    if (ybeg >= h) return;
+    const int yend = min(ybeg + ry, h);
+    const int xl = min(max(x0, 0), p - 4);
+    const bool owns = lane >= 1 && lane < 63 && x0 < w && x0 >= 0;
+    for (int y = ybeg; y < yend; y++) {
+        const int yn = y == 0 ? 1 : y - 1, ys = y == h - 1 ? h - 2 : y + 1;
+        const float4 Lc = *reinterpret_cast<const float4*>(L + (long)y * p + xl);
+        const float4 Gc = *reinterpret_cast<const float4*>(G + (long)y * p + xl);
+        const float4 Ln = *reinterpret_cast<const float4*>(L + (long)yn * p + xl);
+        const float4 Gn = *reinterpret_cast<const float4*>(G + (long)yn * p + xl);
+        const float4 Ls = *reinterpret_cast<const float4*>(L + (long)ys * p + xl);
+        const float4 Gs = *reinterpret_cast<const float4*>(G + (long)ys * p + xl);
+        const float Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x), Gl = wave_shr1(Gc.w), Gr = wave_shl1(Gc.x);
+        const float l[6] = {Ll, Lc.x, Lc.y, Lc.z, Lc.w, Lr}, g[6] = {Gl, Gc.x, Gc.y, Gc.z, Gc.w, Gr};
+        const float ln[4] = {Ln.x, Ln.y, Ln.z, Ln.w}, gn[4] = {Gn.x, Gn.y, Gn.z, Gn.w};
+        const float ls[4] = {Ls.x, Ls.y, Ls.z, Ls.w}, gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w};
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const int x = x0 + e;
+            float LW = l[e], GW = g[e], LE = l[e + 2], GE = g[e + 2];
+            if (x == 0) { LW = LE; GW = GE; }               // abs(x-1) = 1
+            if (x == w - 1) { LE = l[e]; GE = g[e]; }        // borderAdd(x,1,w) = w-2
+            const float Lx = l[e + 1], Gx = g[e + 1];
+            const float step = (Gx + GE) * (LE - Lx) + (Gx + GW) * (LW - Lx) + (Gx + gs[e]) * (ls[e] - Lx) +
+                               (Gx + gn[e]) * (ln[e] - Lx);                     // akazed.cu:1259-1262
+            o[e] = fmaf(stepfac, step, Lx);                                     // akazed.cu:1263
+        }
+        if (owns) {
+            float* drow = D + (long)y * p + x0;
+            if (x0 + 3 < w) *reinterpret_cast<float4*>(drow) = make_float4(o[0], o[1], o[2], o[3]);
+            else {
+                if (x0 < w) drow[0] = o[0];
+                if (x0 + 1 < w) drow[1] = o[1];
+                if (x0 + 2 < w) drow[2] = o[2];
+            }
+        }
+    }
+}
+
+template <int NS>
+static void launch_multi(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+                         int w, int h, int p, int nimg, const float* tau)
+{
+    FedFacs<NS> fac;
+    for (int k = 0; k < NS; k++) fac.f[k] = 0.5f * tau[k];          // akazed.cu:2515
+    const int hx = 4;                                               // x halo >= NS, multiple of 4 (float4 alignment)
+    const int xv = 256 - 2 * hx;
+    const int gx = (w + xv - 1) / xv;
+    // rows per wave: tall strips amortise the 2*NS warm-up rows; shrink while the grid cannot fill the chip
+    int ry = 64;
+    while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
+    k_fed_multi<NS><<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx);
+}
+
+// launches needed for n steps at width w when at most max_fuse steps are fused per launch
+int hak_fed_groups(int n, int max_fuse, int w)
+{
+    if (max_fuse < 1 || w % 4 != 0) max_fuse = 1;                   // odd widths: one step per launch
+    if (max_fuse > HAK_FED_MAX_FUSE) max_fuse = HAK_FED_MAX_FUSE;
+    return (n + max_fuse - 1) / max_fuse;
+}
+
+// steps of group g when n steps are split into G balanced groups (sizes differ by at most one)
+int hak_fed_group_size(int n, int G, int g)
+{
+    int done = 0, ns = 0;
+    for (int i = 0; i <= g; i++) { ns = (n - done + (G - i) - 1) / (G - i); done += ns; }
+    return ns;
+}
+
+// ns fused steps src -> dst (dst != src), tau[0..ns); ns must be 1 when w % 4 != 0
+void hak_launch_fed_group(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+                          int w, int h, int p, int nimg, const float* tau, int ns)
+{
+    if (w % 4 != 0) {
+        const int gx = (w + 247) / 248;
+        int ry = 16;
+        while (ry > 2 && (long)gx * ((h + ry - 1) / ry) * nimg < 2048) ry >>= 1;
+        dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
+        k_fed_generic<<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, 0.5f * tau[0], ry);
+        return;
+    }
+    switch (ns) {
+    case 1: launch_multi<1>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 2: launch_multi<2>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 3: launch_multi<3>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    default: launch_multi<4>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    }
+}
