@@ -145,6 +145,8 @@ struct hak_ctx {
     unsigned long long* maps = nullptr;
     unsigned long long* bitmap = nullptr;
     int* rowcount = nullptr;
+    unsigned long long* cand = nullptr;
+    long cand_cap = 0;
     HakImgState* state = nullptr;
     int* d_num = nullptr;           // [batch] counts for the synchronous entry points
     int* h_num = nullptr;           // pinned
@@ -279,6 +281,10 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     A((void**)&c->maps, sizeof(unsigned long long) * (size_t)L.oct[0].plane * B);
     A((void**)&c->bitmap, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
     A((void**)&c->rowcount, sizeof(int) * (size_t)L.oct[0].h * B);
+    // a 3x3 strict maximum occurs at most once per 2x2 block: the list can never overflow
+    c->cand_cap = 0;
+    for (int o = 0; o < L.noct; o++) c->cand_cap += (long)L.ms * ((L.oct[o].w + 1) / 2) * ((L.oct[o].h + 1) / 2);
+    A((void**)&c->cand, sizeof(unsigned long long) * (size_t)c->cand_cap * B);
     A((void**)&c->state, sizeof(HakImgState) * (size_t)B);
     A((void**)&c->d_num, sizeof(int) * (size_t)B);
     A((void**)&c->dtab, sizeof(HakTables));
@@ -301,7 +307,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->state, c->d_num, c->dtab};
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab};
     for (void* b : bufs) (void)hipFree(b);
     if (c->h_num) (void)hipHostFree(c->h_num);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -331,7 +337,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     hipStream_t st = c->stream;
     float* A = c->arena;
     const long S = L.arena;
-    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount};
+    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
     c->fed_launches = 0;
 
     hak_launch_reset_state(st, c->state, nimg);
@@ -354,7 +360,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 { ProfScope ps(c, HAK_PROF_LOWPASS);
                   hak_launch_lowpass(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps_base, c->base_R); }
                 { ProfScope ps(c, HAK_PROF_HESSIAN);
-                  hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+                  if (!hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                                                lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
+                      hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
                 continue;
             }
             const int n = lp.nsteps;
@@ -388,10 +396,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 }
             }
             { ProfScope ps(c, HAK_PROF_HESSIAN);                                  // akaze.cpp:423
-              hak_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size); }
+              if (!hak_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                                            lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
+                  hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
         }
-        { ProfScope ps(c, HAK_PROF_EXTREMA);                                      // akaze.cpp:431-433
-          hak_launch_extrema(st, b, L, c->dtab, o, cfg.dthreshold); }
+        // akaze.cpp:431-433 hCalcExtremaMap: fused into the per-level Hessian kernel above
     }
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
       hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts); }
@@ -666,7 +675,7 @@ extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst,
 
 extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, int w, int h, int p, int step)
 {
-    hak_launch_hessian_level(nullptr, s, lx, ly, det, 0, w, h, p, 1, step);
+    hak_launch_hessian_level(nullptr, s, lx, ly, det, 0, w, h, p, 1, step, nullptr, nullptr, nullptr, 0, 0, 0.f);
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }

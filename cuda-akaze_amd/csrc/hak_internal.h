@@ -35,6 +35,7 @@ struct HakImgState {
     int hist[HAK_NBINS];
     float kcontrast[HAK_MAX_OCTAVES];           // per octave: k0, k0*0.75, ...
     float ikc[HAK_MAX_OCTAVES];                 // 1/(k*k)
+    int ncand;                                  // entries in the image's extrema candidate list
     int total_pts;                              // NMS survivors before clamping to max_pts
     int num_pts;                                // min(total, max_pts)
 };
@@ -144,6 +145,8 @@ struct HakBatch {
     long map_stride;              // h0 * p0
     unsigned long long* bitmap;   // [nimg][h0][ceil(w0/64)] NMS survivor bits
     int* rowcount;                // [nimg][h0]
+    unsigned long long* cand;     // [nimg][cand_cap] extrema candidates: layer<<32 | y<<16 | x (full-res)
+    long cand_cap;
 };
 
 // scale space (kernels_scalespace.hip)
@@ -158,8 +161,11 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
                      int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
 void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
                          int w, int h, int p, int nimg, float stepfac);
-void hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
-                              int w, int h, int p, int nimg, int step);
+// derivate + determinant of one level, with the level's extrema search fused in when b != nullptr
+// (kernels_hessian.hip); returns false when the caller still has to run hak_launch_extrema_level
+bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                              int w, int h, int p, int nimg, int step,
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
 int hak_fed_groups(int n, int max_fuse, int w);
@@ -172,7 +178,8 @@ void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float*
                         int w, int h, int p, int nimg, int step);
 
 // detector tail (kernels_detect.hip)
-void hak_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, float dthreshold);
+void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
+                              int s, float dthreshold);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
                          hak_point* points, int max_pts, int* num_out);
 

@@ -18,73 +18,88 @@ __device__ __forceinline__ float key_resp(unsigned long long k) { return __uint_
 __device__ __forceinline__ int key_layer(unsigned long long k) { return (int)(0xFFFFFFFFu - (unsigned)k); }
 
 // ------------------------------------------------------------------ extrema
-// grid: (x tiles, y tiles, ms * nimg)
+// Stand-alone per-level extrema (used only when the dilation is too large for the fused
+// Hessian kernel, kernels_hessian.hip).  grid: (x tiles, y tiles, nimg)
 __global__ __launch_bounds__(256) void k_extrema(const float* __restrict__ base, long stride, unsigned long long* maps,
-                                                 long map_stride, HakLayout L, const HakTables* __restrict__ tab,
-                                                 int octave, float threshold)
+                                                 long map_stride, unsigned long long* cand, long cand_cap,
+                                                 HakImgState* state, HakLayout L, const HakTables* __restrict__ tab,
+                                                 int octave, int s, float threshold)
 {
-    const int s = blockIdx.z % L.ms, img = blockIdx.z / L.ms;
+    const int img = blockIdx.z;
     const HakOct oc = L.oct[octave];
     const float* det = base + (long)img * stride + L.det(octave, s);
-    unsigned long long* map = maps + (long)img * map_stride;
     const int layer = octave * L.ms + s;
     const float border = tab->borders[layer];
     const int psz = (int)tab->borders[octave * L.ms];               // akazed.cu:2572
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane;
     const int y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
-    if (x < psz || x >= oc.w) return;
     // akazed.cu:1346-1353
-    if ((int)(x - border + 0.5f) - 1 < 0 || (int)(x + border + 0.5f) + 1 >= oc.w) return;
-    for (int y = y0; y < blockIdx.y * 16 + 16 && y < oc.h; y += 4) {
-        if (y < psz) continue;
-        if ((int)(y - border + 0.5f) - 1 < 0 || (int)(y + border + 0.5f) + 1 >= oc.h) continue;
-        const float* vp = det + (long)y * oc.p + x;
-        const float* vp0 = vp - oc.p;
-        const float* vp2 = vp + oc.p;
-        float v = *vp;
-        if (v > threshold && v > *vp0 && v > *vp2 && v > vp[-1] && v > vp[1] &&
-            v > vp0[-1] && v > vp0[1] && v > vp2[-1] && v > vp2[1]) {
-            long oidx = (long)(y << octave) * L.oct[0].p + (x << octave);
-            unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)layer);
-            atomicMax(&map[oidx], key);
+    const bool xok = x >= psz && x < oc.w && (int)(x - border + 0.5f) - 1 >= 0 && (int)(x + border + 0.5f) + 1 < oc.w;
+    for (int y = y0; y < blockIdx.y * 16 + 16; y += 4) {
+        bool hit = false;
+        float v = 0.f;
+        if (xok && y >= psz && y < oc.h && (int)(y - border + 0.5f) - 1 >= 0 && (int)(y + border + 0.5f) + 1 < oc.h) {
+            const float* vp = det + (long)y * oc.p + x;
+            const float* vp0 = vp - oc.p;
+            const float* vp2 = vp + oc.p;
+            v = *vp;
+            hit = v > threshold && v > *vp0 && v > *vp2 && v > vp[-1] && v > vp[1] &&
+                  v > vp0[-1] && v > vp0[1] && v > vp2[-1] && v > vp2[1];
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            int cbase = 0;
+            if (lane == 0) cbase = atomicAdd(&state[img].ncand, __popcll(m));
+            cbase = __builtin_amdgcn_readfirstlane(cbase);
+            if (hit) {
+                const int fx = x << octave, fy = y << octave;
+                unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)layer);
+                atomicMax(&maps[(long)img * map_stride + (long)fy * L.oct[0].p + fx], key);
+                const long slot = cbase + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cand_cap)
+                    cand[(long)img * cand_cap + slot] = ((unsigned long long)layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+            }
         }
     }
 }
 
 // ---------------------------------------------------------------- NMS: mark
-// One lane per full-res pixel; a wave covers 64 consecutive pixels of a row so
-// the survivor mask of the wave is one u64 bitmap word.  (akazed.cu:1554-1613)
-__global__ __launch_bounds__(256) void k_nms_mark(const unsigned long long* __restrict__ maps, long map_stride,
+// Candidate-driven disc NMS (akazed.cu:1554-1613): one thread per candidate of the image's list.
+// A candidate proceeds only if it still owns its pixel of the key map (several levels can hit the
+// same full-resolution pixel; exactly one key wins).  Survivors set their bit in the bitmap and
+// bump the per-row count; order is restored by k_row_scan + k_emit.
+__global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __restrict__ maps, long map_stride,
+                                                  const unsigned long long* __restrict__ cand, long cand_cap,
+                                                  const HakImgState* __restrict__ state,
                                                   const HakTables* __restrict__ tab, int psz, int w, int h, int p,
                                                   unsigned long long* bitmap, int words_per_row, int* rowcount)
 {
-    const int img = blockIdx.z;
+    const int img = blockIdx.y;
     const unsigned long long* map = maps + (long)img * map_stride;
-    const int x = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int y = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (y >= h) return;                                             // wave-uniform
-    bool keep = false;
-    if (x >= psz && x + psz < w && y >= psz && y + psz < h) {
-        unsigned long long kc = map[(long)y * p + x];
-        if (kc != 0ull) {
-            const float rc = key_resp(kc);
-            const float fsz = tab->sizes[key_layer(kc)];
-            const int isz = (int)(fsz + 0.5f);
-            const int sqsz = (int)(fsz * fsz);
-            bool to_nms = false;
-            for (int i = -isz; i <= isz && !to_nms; i++)
-                for (int j = -isz; j <= isz; j++) {
-                    if ((i == 0 && j == 0) || i * i + j * j >= sqsz) continue;
-                    float rn = key_resp(map[(long)(y + i) * p + (x + j)]);
-                    if (rn > rc || (rn == rc && i <= 0 && j <= 0)) to_nms = true;
-                }
-            keep = !to_nms;
+    long n = state[img].ncand;
+    n = n < cand_cap ? n : cand_cap;
+    for (long i = blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const unsigned long long e = cand[(long)img * cand_cap + i];
+        const int x = (int)(e & 0xFFFFu), y = (int)((e >> 16) & 0xFFFFu), layer = (int)(e >> 32);
+        if (!(x >= psz && x + psz < w && y >= psz && y + psz < h)) continue;
+        const unsigned long long kc = map[(long)y * p + x];
+        if (key_layer(kc) != layer) continue;                       // another level won this pixel
+        const float rc = key_resp(kc);
+        const float fsz = tab->sizes[layer];
+        const int isz = (int)(fsz + 0.5f);
+        const int sqsz = (int)(fsz * fsz);
+        bool to_nms = false;
+        for (int di = -isz; di <= isz && !to_nms; di++)
+            for (int dj = -isz; dj <= isz; dj++) {
+                if ((di == 0 && dj == 0) || di * di + dj * dj >= sqsz) continue;
+                float rn = key_resp(map[(long)(y + di) * p + (x + dj)]);
+                if (rn > rc || (rn == rc && di <= 0 && dj <= 0)) to_nms = true;
+            }
+        if (!to_nms) {
+            atomicOr(&bitmap[((long)img * h + y) * words_per_row + (x >> 6)], 1ull << (x & 63));
+            atomicAdd(&rowcount[(long)img * h + y], 1);
         }
-    }
-    unsigned long long mask = __ballot(keep);
-    if ((threadIdx.x & 63) == 0) {
-        bitmap[((long)img * h + y) * words_per_row + blockIdx.x] = mask;
-        if (mask) atomicAdd(&rowcount[(long)img * h + y], __popcll(mask));
     }
 }
 
@@ -187,12 +202,13 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
     }
 }
 
-void hak_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
-                        float dthreshold)
+void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
+                              int s, float dthreshold)
 {
     const HakOct oc = L.oct[octave];
-    dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, L.ms * b.nimg);
-    k_extrema<<<grid, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, octave, dthreshold);
+    dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, b.nimg);
+    k_extrema<<<grid, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, b.cand, b.cand_cap, b.state, L, tab,
+                                    octave, s, dthreshold);
 }
 
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
@@ -201,8 +217,10 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
     const int words = (w + 63) / 64;
     (void)hipMemsetAsync(b.rowcount, 0, sizeof(int) * (size_t)b.nimg * h, st);
-    dim3 g1(words, (h + 3) / 4, b.nimg);
-    k_nms_mark<<<g1, 256, 0, st>>>(b.maps, b.map_stride, tab, psz, w, h, p, b.bitmap, words, b.rowcount);
+    (void)hipMemsetAsync(b.bitmap, 0, sizeof(unsigned long long) * (size_t)b.nimg * h * words, st);
+    dim3 g1(64, b.nimg);
+    k_nms_cand<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, tab, psz, w, h, p,
+                                   b.bitmap, words, b.rowcount);
     k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
     dim3 g3((h + 3) / 4, 1, b.nimg);
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts);

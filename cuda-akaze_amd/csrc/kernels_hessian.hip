@@ -1,0 +1,254 @@
+// kernels_hessian.hip -- derivatives + Hessian determinant + per-level extrema, one fused kernel.
+//
+//   hHessianDeterminant/gDerivate/gHessianDeterminant   akazed.cu:2531, 1267, 1299
+//   hCalcExtremaMap/gCalcExtremaMap                     akazed.cu:2563, 1334
+//
+// For dilation S in {1..4}:  smooth tile (+2S+1 halo) -> Lx, Ly tile (+S+1 halo, kept in LDS,
+// centre written out) -> det tile (+1 halo, in LDS, centre written out) -> 3x3 strict-maximum test
+// + threshold + border test -> atomicMax into the full-resolution key map and an entry in the
+// image's candidate list (the NMS then visits candidates instead of scanning the dense map).
+// HBM traffic: read smooth once (4 B/px), write Lx, Ly, det (12 B/px); nothing is re-read.
+//
+// The kernel is bytes-in-flight-bound when a block loads one tile and then computes with nothing
+// outstanding (rocprof: ~4 % VALU-active, waves waiting on memory), so a block is PERSISTENT over a
+// vertical run of tiles and prefetches the next tile's smooth values into registers while it works
+// on the current tile from LDS.  Mapping: lane = tile column, wave = tile row (mod 4): row indices
+// are wave-uniform (SALU), column indices are computed once per thread; INTERIOR tiles (no
+// reflection anywhere in the halo) address LDS with compile-time offsets only.
+//
+// Same per-pixel expressions and reflect-101 index rule as the reference (akazed.cu:1284-1295,
+// 1326-1330, 1346-1373).
+#include "hak_internal.h"
+
+#define HF_TX 64
+#define HF_E 1                                   // extra halo so the det tile has its 3x3 neighbourhood
+template <int S> struct HessGeo {
+    static constexpr int TY = S == 4 ? 28 : 32;                            // keeps LDS <= 40 KB: 4 blocks / CU
+    static constexpr int SW = HF_TX + 2 * HF_E + 4 * S, SH = TY + 2 * HF_E + 4 * S;   // smooth tile
+    static constexpr int DW = HF_TX + 2 * HF_E + 2 * S, DH = TY + 2 * HF_E + 2 * S;   // Lx / Ly tile
+    static constexpr int EW = HF_TX + 2 * HF_E, EH = TY + 2 * HF_E;                   // det tile
+    static constexpr int NR = (SH + 3) / 4;                                          // smooth rows per wave
+};
+
+template <int S>
+struct HessPrefetch { float a[HessGeo<S>::NR], b[HessGeo<S>::NR]; };                 // columns lane, 64+lane
+
+template <int S>
+__device__ __forceinline__ void hess_fetch(HessPrefetch<S>& P, const float* __restrict__ s, int w, int h, int p,
+                                           int x0, int y0, int lane, int wv)
+{
+    using G = HessGeo<S>;
+    const int sx0 = x0 - HF_E - 2 * S, sy0 = y0 - HF_E - 2 * S;
+    const int ca = hak_refl(sx0 + lane, w), cb = hak_refl(sx0 + 64 + lane, w);
+#pragma unroll
+    for (int i = 0; i < G::NR; i++) {
+        const int r = wv + 4 * i;
+        if (r < G::SH) {
+            const float* row = s + (long)hak_refl(sy0 + r, h) * p;
+            P.a[i] = row[ca];
+            if (lane < G::SW - 64) P.b[i] = row[cb];
+        }
+    }
+}
+
+template <int S>
+__device__ __forceinline__ void hess_commit(const HessPrefetch<S>& P, float* sm, int lane, int wv)
+{
+    using G = HessGeo<S>;
+#pragma unroll
+    for (int i = 0; i < G::NR; i++) {
+        const int r = wv + 4 * i;
+        if (r < G::SH) {
+            sm[r * G::SW + lane] = P.a[i];
+            if (lane < G::SW - 64) sm[r * G::SW + 64 + lane] = P.b[i];
+        }
+    }
+}
+
+struct HakExtremaArgs {
+    unsigned long long* maps;       // [nimg][map_stride]
+    long map_stride;
+    unsigned long long* cand;       // [nimg][cand_cap]
+    long cand_cap;
+    HakImgState* state;
+    int p0;                         // pitch of the full-resolution map
+    int octave, layer;
+    int psz;                        // (int)borders[octave*ms]     akazed.cu:2572
+    float border, threshold;
+};
+
+template <int S, bool INTERIOR>
+__device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ od,
+                                             int w, int h, int p, int x0, int y0, float fac1, float fac2,
+                                             float* sm, float* sx, float* sy, int lane, int wv,
+                                             const HakExtremaArgs& ex, int img)
+{
+    using G = HessGeo<S>;
+    constexpr int SW = G::SW, DW = G::DW, DH = G::DH, EW = G::EW, EH = G::EH, TY = G::TY;
+    const int sx0 = x0 - HF_E - 2 * S, sy0 = y0 - HF_E - 2 * S;     // image coordinates of sm[0][0]
+    const int dx0 = x0 - HF_E - S, dy0 = y0 - HF_E - S;             // image coordinates of sx[0][0]
+    const int ex0 = x0 - HF_E, ey0 = y0 - HF_E;                     // image coordinates of the det tile
+    // ---- Lx, Ly on the derivative tile, centre -> HBM.  Work items are the DH x DW tile positions
+    // flattened over the 256 threads (keeps every lane busy; a lane = column mapping would spend a
+    // whole extra pass on the few halo columns beyond 64).
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < DH * DW; idx += 256) {
+        const int r = idx / DW, c = idx - r * DW;
+        const int x = dx0 + c, y = dy0 + r;
+        if (!INTERIOR && (x < 0 || x >= w || y < 0 || y >= h)) continue;   // derivatives exist only inside the image
+        const int c1 = c + S;                                       // sm columns of x-S, x, x+S
+        const int c0 = INTERIOR ? c : hak_refl(x - S, w) - sx0;
+        const int c2 = INTERIOR ? c + 2 * S : hak_refl(x + S, w) - sx0;
+        const int r1 = (r + S) * SW;
+        const int r0 = INTERIOR ? r * SW : (hak_refl(y - S, h) - sy0) * SW;
+        const int r2 = INTERIOR ? (r + 2 * S) * SW : (hak_refl(y + S, h) - sy0) * SW;
+        const float ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
+        const float cl = sm[r1 + c0], cr = sm[r1 + c2];
+        const float ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
+        const float vx = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);           // akazed.cu:1294
+        const float vy = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);           // akazed.cu:1295
+        sx[idx] = vx;
+        sy[idx] = vy;
+        if (c >= S + HF_E && c < S + HF_E + HF_TX && r >= S + HF_E && r < S + HF_E + TY) {
+            ox[(long)y * p + x] = vx;
+            oy[(long)y * p + x] = vy;
+        }
+    }
+    __syncthreads();                                                // sm is dead from here: the det tile reuses it
+    // ---- determinant on the det tile (flattened the same way), centre -> HBM
+    float* dt = sm;
+    for (int idx = tid; idx < EH * EW; idx += 256) {
+        const int r = idx / EW, c = idx - r * EW;
+        const int x = ex0 + c, y = ey0 + r;
+        if (!INTERIOR && (x < 0 || x >= w || y < 0 || y >= h)) continue;
+        const int c1 = c + S;                                       // sx columns of x-S, x, x+S
+        const int c0 = INTERIOR ? c : hak_refl(x - S, w) - dx0;
+        const int c2 = INTERIOR ? c + 2 * S : hak_refl(x + S, w) - dx0;
+        const int r1 = (r + S) * DW;
+        const int r0 = INTERIOR ? r * DW : (hak_refl(y - S, h) - dy0) * DW;
+        const int r2 = INTERIOR ? (r + 2 * S) * DW : (hak_refl(y + S, h) - dy0) * DW;
+        const float xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
+        const float xcl = sx[r1 + c0], xcr = sx[r1 + c2];
+        const float xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
+        const float yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
+        const float yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
+        const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
+        const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
+        const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
+        const float d = dxx * dyy - dxy * dxy;                                    // akazed.cu:1330
+        dt[idx] = d;
+        if (c >= HF_E && c < HF_E + HF_TX && r >= HF_E && r < HF_E + TY) od[(long)y * p + x] = d;
+    }
+    if (ex.maps == nullptr) return;                                 // (uniform) determinant only
+    __syncthreads();
+    // ---- extrema of this level on the output tile (akazed.cu:1346-1373)
+    const int x = x0 + lane;
+    const bool xok = x >= ex.psz && (int)(x - ex.border + 0.5f) - 1 >= 0 && (int)(x + ex.border + 0.5f) + 1 < w;
+    for (int rr = wv; rr < TY; rr += 4) {
+        const int y = y0 + rr;
+        bool hit = false;
+        float v = 0.f;
+        if (xok && y >= ex.psz && (int)(y - ex.border + 0.5f) - 1 >= 0 && (int)(y + ex.border + 0.5f) + 1 < h) {
+            const float* vp = dt + (rr + HF_E) * EW + lane + HF_E;
+            v = *vp;
+            hit = v > ex.threshold && v > vp[-EW] && v > vp[EW] && v > vp[-1] && v > vp[1] &&
+                  v > vp[-EW - 1] && v > vp[-EW + 1] && v > vp[EW - 1] && v > vp[EW + 1];
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&ex.state[img].ncand, __popcll(m));
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (hit) {
+                const int fx = x << ex.octave, fy = y << ex.octave;
+                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)ex.layer);
+                atomicMax(&ex.maps[(long)img * ex.map_stride + (long)fy * ex.p0 + fx], key);
+                const long slot = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < ex.cand_cap)
+                    ex.cand[(long)img * ex.cand_cap + slot] = ((unsigned long long)ex.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+            }
+        }
+    }
+}
+
+// grid: (x tiles, y tile groups, images); a block walks `tiles_per_block` tiles downwards
+template <int S>
+__global__ __launch_bounds__(256) void k_hessian_fused(const float* __restrict__ src, float* __restrict__ lx,
+                                                       float* __restrict__ ly, float* __restrict__ det, long stride,
+                                                       int w, int h, int p, float fac1, float fac2, int tiles_per_block,
+                                                       HakExtremaArgs ex)
+{
+    using G = HessGeo<S>;
+    __shared__ float sm[G::SH * G::SW];
+    __shared__ float sx[G::DH * G::DW];
+    __shared__ float sy[G::DH * G::DW];
+    const float* s = src + (long)blockIdx.z * stride;
+    float* ox = lx + (long)blockIdx.z * stride;
+    float* oy = ly + (long)blockIdx.z * stride;
+    float* od = det + (long)blockIdx.z * stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = blockIdx.x * HF_TX;
+    const int ty0 = blockIdx.y * tiles_per_block;
+    const int ntiles = (h + G::TY - 1) / G::TY;
+    const int ty1 = min(ty0 + tiles_per_block, ntiles);
+    constexpr int HALO = HF_E + 2 * S;
+    HessPrefetch<S> P;
+    if (ty0 < ty1) hess_fetch<S>(P, s, w, h, p, x0, ty0 * G::TY, lane, wv);
+    for (int ty = ty0; ty < ty1; ty++) {
+        const int y0 = ty * G::TY;
+        __syncthreads();                                        // previous tile's readers of sm / sx / sy are done
+        hess_commit<S>(P, sm, lane, wv);
+        __syncthreads();
+        if (ty + 1 < ty1) hess_fetch<S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
+        const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
+        if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, blockIdx.z);
+        else hessian_tile<S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, blockIdx.z);
+    }
+}
+
+static void deriv_factors(float& fac1, float& fac2)
+{
+    float wv = 10.f / 3.f;                                   // akazed.cu:2537-2539
+    fac1 = 1.f / (2.f * (wv + 2.f));
+    fac2 = wv * fac1;
+}
+
+template <int S>
+static void launch_fused(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                         int w, int h, int p, int nimg, const HakExtremaArgs& ex)
+{
+    float f1, f2;
+    deriv_factors(f1, f2);
+    const int ntx = (w + HF_TX - 1) / HF_TX, nty = (h + HessGeo<S>::TY - 1) / HessGeo<S>::TY;
+    // tiles per persistent block: long runs while the grid still covers the chip several times
+    int tpb = 8;
+    while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
+    dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
+    k_hessian_fused<S><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb, ex);
+}
+
+// derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
+// extrema were handled here; false means the caller must run the stand-alone extrema kernel.
+bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                              int w, int h, int p, int nimg, int step,
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+{
+    HakExtremaArgs ex{};
+    if (b) {
+        const int layer = octave * L->ms + sub;
+        ex.maps = b->maps; ex.map_stride = b->map_stride; ex.cand = b->cand; ex.cand_cap = b->cand_cap;
+        ex.state = b->state; ex.p0 = L->oct[0].p; ex.octave = octave; ex.layer = layer;
+        ex.psz = (int)htab->borders[octave * L->ms]; ex.border = htab->borders[layer]; ex.threshold = dthreshold;
+    }
+    switch (step) {
+    case 1: launch_fused<1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 2: launch_fused<2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 3: launch_fused<3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 4: launch_fused<4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    default: break;
+    }
+    hak_launch_derivate(st, src, lx, ly, stride, w, h, p, nimg, step);      // dilation > 4: two direct passes
+    hak_launch_hessian(st, lx, ly, det, stride, w, h, p, nimg, step);
+    return false;
+}

@@ -153,6 +153,7 @@ __global__ __launch_bounds__(256) void k_reset_state(HakImgState* state)
     for (int i = threadIdx.x; i < HAK_NBINS; i += 256) st->hist[i] = 0;
     if (threadIdx.x == 0) {
         st->hmax_bits = __float_as_uint(0.03f);        // akazed.cu:2413
+        st->ncand = 0;
         st->total_pts = 0;
         st->num_pts = 0;
     }
@@ -412,160 +413,6 @@ __global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ lx, c
     }
 }
 
-// Fused derivate + determinant for dilation S in {1..4}: smooth tile with a 2S halo -> Lx, Ly on the
-// tile + S halo (kept in LDS, centre written out) -> det.  Reads smooth once and never re-reads
-// Lx / Ly from HBM: 16 B/px instead of 24.  Same per-pixel expressions and reflect-101 index rule
-// as k_derivate / k_hessian (akazed.cu:1284-1295, 1326-1330).
-//
-// Mapping: lane = tile column, wave = tile row (mod 4): row indices are wave-uniform (SALU), the
-// column indices are computed once per thread.  INTERIOR tiles (no reflection anywhere in the
-// halo) address LDS with compile-time offsets only.
-#define HF_TX 64
-#define HF_TY 32
-#define HF_SMAX 4
-
-// The kernel is bytes-in-flight-bound when each block loads one tile and then computes with nothing
-// outstanding (rocprof: ~4 % VALU-active, waves waiting on memory).  So a block is PERSISTENT over a
-// vertical run of tiles and prefetches the next tile's smooth values into registers while it works on
-// the current tile from LDS.
-template <int S>
-struct HessPrefetch {
-    static constexpr int SW = HF_TX + 4 * S, SH = HF_TY + 4 * S;
-    static constexpr int NR = (SH + 3) / 4;                     // rows per wave
-    float a[NR], b[NR];                                         // columns lane and 64+lane
-};
-
-template <int S>
-__device__ __forceinline__ void hess_fetch(HessPrefetch<S>& P, const float* __restrict__ s, int w, int h, int p,
-                                           int x0, int y0, int lane, int wv)
-{
-    constexpr int SH = HessPrefetch<S>::SH;
-    const int sx0 = x0 - 2 * S, sy0 = y0 - 2 * S;
-    const int ca = hak_refl(sx0 + lane, w), cb = hak_refl(sx0 + 64 + lane, w);
-#pragma unroll
-    for (int i = 0; i < HessPrefetch<S>::NR; i++) {
-        const int r = wv + 4 * i;
-        if (r < SH) {
-            const float* row = s + (long)hak_refl(sy0 + r, h) * p;
-            P.a[i] = row[ca];
-            if (lane < 4 * S) P.b[i] = row[cb];
-        }
-    }
-}
-
-template <int S>
-__device__ __forceinline__ void hess_commit(const HessPrefetch<S>& P, float* sm, int lane, int wv)
-{
-    constexpr int SW = HessPrefetch<S>::SW, SH = HessPrefetch<S>::SH;
-#pragma unroll
-    for (int i = 0; i < HessPrefetch<S>::NR; i++) {
-        const int r = wv + 4 * i;
-        if (r < SH) {
-            sm[r * SW + lane] = P.a[i];
-            if (lane < 4 * S) sm[r * SW + 64 + lane] = P.b[i];
-        }
-    }
-}
-
-template <int S, bool INTERIOR>
-__device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __restrict__ oy,
-                                             float* __restrict__ od, int w, int h, int p, int x0, int y0,
-                                             float fac1, float fac2, const float* sm, float* sx, float* sy,
-                                             int lane, int wv)
-{
-    constexpr int SW = HF_TX + 4 * S;                           // smooth tile
-    constexpr int DW = HF_TX + 2 * S, DH = HF_TY + 2 * S;       // derivative tile
-    const int sx0 = x0 - 2 * S, sy0 = y0 - 2 * S;               // image coordinates of sm[0][0]
-    const int dx0 = x0 - S, dy0 = y0 - S;                       // image coordinates of sx[0][0]
-    // ---- Lx, Ly on the derivative tile (columns lane and 64+lane), centre -> HBM
-#pragma unroll
-    for (int slot = 0; slot < 2; slot++) {
-        const int c = slot * 64 + lane;
-        if (slot == 1 && lane >= 2 * S) break;
-        const int x = dx0 + c;
-        if (!INTERIOR && (x < 0 || x >= w)) continue;           // derivatives exist only inside the image
-        const int c1 = c + S;                                   // sm column indices of x-S, x, x+S
-        const int c0 = INTERIOR ? c : hak_refl(x - S, w) - sx0;
-        const int c2 = INTERIOR ? c + 2 * S : hak_refl(x + S, w) - sx0;
-        const bool centre_col = c >= S && c < S + HF_TX;
-        for (int r = wv; r < DH; r += 4) {
-            const int y = dy0 + r;
-            if (!INTERIOR && (y < 0 || y >= h)) continue;
-            const int r1 = (r + S) * SW;
-            const int r0 = INTERIOR ? r * SW : (hak_refl(y - S, h) - sy0) * SW;
-            const int r2 = INTERIOR ? (r + 2 * S) * SW : (hak_refl(y + S, h) - sy0) * SW;
-            const float ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
-            const float cl = sm[r1 + c0], cr = sm[r1 + c2];
-            const float ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
-            const float vx = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);       // akazed.cu:1294
-            const float vy = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);       // akazed.cu:1295
-            sx[r * DW + c] = vx;
-            sy[r * DW + c] = vy;
-            if (centre_col && r >= S && r < S + HF_TY) {
-                ox[(long)y * p + x] = vx;
-                oy[(long)y * p + x] = vy;
-            }
-        }
-    }
-    __syncthreads();
-    // ---- determinant on the output tile
-    const int x = x0 + lane;
-    if (INTERIOR || x < w) {
-        const int c1 = lane + S;
-        const int c0 = INTERIOR ? lane : hak_refl(x - S, w) - dx0;
-        const int c2 = INTERIOR ? lane + 2 * S : hak_refl(x + S, w) - dx0;
-        for (int rr = wv; rr < HF_TY; rr += 4) {
-            const int y = y0 + rr;
-            if (!INTERIOR && y >= h) break;
-            const int r1 = (rr + S) * DW;
-            const int r0 = INTERIOR ? rr * DW : (hak_refl(y - S, h) - dy0) * DW;
-            const int r2 = INTERIOR ? (rr + 2 * S) * DW : (hak_refl(y + S, h) - dy0) * DW;
-            const float xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
-            const float xcl = sx[r1 + c0], xcr = sx[r1 + c2];
-            const float xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
-            const float yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
-            const float yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
-            const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
-            const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
-            const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
-            od[(long)y * p + x] = dxx * dyy - dxy * dxy;                          // akazed.cu:1330
-        }
-    }
-}
-
-// grid: (x tiles, y tile groups, images); a block walks `tiles_per_block` tiles downwards
-template <int S>
-__global__ __launch_bounds__(256) void k_hessian_fused(const float* __restrict__ src, float* __restrict__ lx,
-                                                       float* __restrict__ ly, float* __restrict__ det, long stride,
-                                                       int w, int h, int p, float fac1, float fac2, int tiles_per_block)
-{
-    __shared__ float sm[(HF_TY + 4 * S) * (HF_TX + 4 * S)];
-    __shared__ float sx[(HF_TY + 2 * S) * (HF_TX + 2 * S)];
-    __shared__ float sy[(HF_TY + 2 * S) * (HF_TX + 2 * S)];
-    const float* s = src + (long)blockIdx.z * stride;
-    float* ox = lx + (long)blockIdx.z * stride;
-    float* oy = ly + (long)blockIdx.z * stride;
-    float* od = det + (long)blockIdx.z * stride;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * HF_TX;
-    const int ty0 = blockIdx.y * tiles_per_block;
-    const int ntiles = (h + HF_TY - 1) / HF_TY;
-    const int ty1 = min(ty0 + tiles_per_block, ntiles);
-    HessPrefetch<S> P;
-    if (ty0 < ty1) hess_fetch<S>(P, s, w, h, p, x0, ty0 * HF_TY, lane, wv);
-    for (int ty = ty0; ty < ty1; ty++) {
-        const int y0 = ty * HF_TY;
-        __syncthreads();                                        // previous tile's readers of sm / sx / sy are done
-        hess_commit<S>(P, sm, lane, wv);
-        __syncthreads();
-        if (ty + 1 < ty1) hess_fetch<S>(P, s, w, h, p, x0, y0 + HF_TY, lane, wv);   // in flight during the compute below
-        const bool interior = x0 - 2 * S >= 0 && x0 + HF_TX + 2 * S <= w && y0 - 2 * S >= 0 && y0 + HF_TY + 2 * S <= h;
-        if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv);
-        else hessian_tile<S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv);
-    }
-}
-
 static void deriv_factors(float& fac1, float& fac2)
 {
     float wv = 10.f / 3.f;                                   // akazed.cu:2537-2539
@@ -580,30 +427,6 @@ void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly,
     deriv_factors(f1, f2);
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
     k_derivate<<<grid, 256, 0, st>>>(src, lx, ly, stride, w, h, p, step, f1, f2);
-}
-
-// derivate + determinant of one level: fused kernel when the dilation fits its tile, else two passes
-void hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
-                              int w, int h, int p, int nimg, int step)
-{
-    if (step >= 1 && step <= HF_SMAX) {
-        float f1, f2;
-        deriv_factors(f1, f2);
-        const int ntx = (w + HF_TX - 1) / HF_TX, nty = (h + HF_TY - 1) / HF_TY;
-        // tiles per persistent block: long runs while the grid still covers the chip several times
-        int tpb = 8;
-        while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
-        dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
-        switch (step) {
-        case 1: k_hessian_fused<1><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb); break;
-        case 2: k_hessian_fused<2><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb); break;
-        case 3: k_hessian_fused<3><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb); break;
-        default: k_hessian_fused<4><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb); break;
-        }
-        return;
-    }
-    hak_launch_derivate(st, src, lx, ly, stride, w, h, p, nimg, step);
-    hak_launch_hessian(st, lx, ly, det, stride, w, h, p, nimg, step);
 }
 
 void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
