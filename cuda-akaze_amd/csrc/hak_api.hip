@@ -375,12 +375,16 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                   hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1); }
                 fsrc = first;
             } else {                                                              // akaze.cpp:393-421
-                { ProfScope ps(c, HAK_PROF_LOWPASS);
-                  hak_launch_lowpass(st, A + L.lt(o, s - 1), S, oc.p, smooth, S, oc.w, oc.h, oc.p, nimg, c->taps1, 2); }
                 fsrc = A + L.lt(o, s - 1);
             }
-            { ProfScope ps(c, HAK_PROF_FLOW);
-              hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f); }
+            if (s == 0) {
+                ProfScope ps(c, HAK_PROF_FLOW);
+                hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
+            } else {                                                              // akaze.cpp:403-404 in one pass
+                ProfScope ps(c, HAK_PROF_LOWPASS);
+                hak_launch_smooth_flow(st, fsrc, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
+                                       c->state, o, 0.f);
+            }
             {
                 // the n explicit steps of the cycle in G fused launches, ping-pong Lt <-> tmp, ending in Lt
                 const float* src = fsrc;

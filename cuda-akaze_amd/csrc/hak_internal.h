@@ -166,6 +166,10 @@ void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, fl
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
+// sigma=1 low-pass + conductivity fused (kernels_smoothflow.hip)
+void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, float* flow, long stride,
+                            int w, int h, int p, int nimg, const float* taps, int diffusivity,
+                            const HakImgState* state, int octave, float fixed_ikc);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
 int hak_fed_groups(int n, int max_fuse, int w);

@@ -92,6 +92,7 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
     // flattened over the 256 threads (keeps every lane busy; a lane = column mapping would spend a
     // whole extra pass on the few halo columns beyond 64).
     const int tid = threadIdx.x;
+#pragma unroll 4
     for (int idx = tid; idx < DH * DW; idx += 256) {
         const int r = idx / DW, c = idx - r * DW;
         const int x = dx0 + c, y = dy0 + r;
@@ -117,6 +118,7 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
     __syncthreads();                                                // sm is dead from here: the det tile reuses it
     // ---- determinant on the det tile (flattened the same way), centre -> HBM
     float* dt = sm;
+#pragma unroll 3
     for (int idx = tid; idx < EH * EW; idx += 256) {
         const int r = idx / EW, c = idx - r * EW;
         const int x = ex0 + c, y = ey0 + r;
