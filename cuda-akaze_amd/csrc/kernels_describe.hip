@@ -10,15 +10,42 @@
 //   * MLDB: sample i belongs to "thread" i % 64; a thread sums its samples in
 //     ascending order; threads are combined as (a_t + a_{t+32}) followed by the
 //     shuffle-down tree 1,2,4,8,16 (akazed.cu:1957-1981)
+//
+// The stage is gather-latency-bound (1323 + 218 scattered loads per keypoint), so (a) all gathers
+// of a phase are issued before any is consumed, and (b) the per-thread accumulator table is built
+// in two rounds over a half-size LDS table (2x2 + 3x3 cells, then 4x4 cells), which doubles the
+// number of keypoints a CU works on concurrently.
 #include "hak_internal.h"
 
-#define ACC_LD 65     // padded leading dimension of the per-thread accumulator table
+#define ACC_LD 65           // padded leading dimension of the per-thread accumulator table
+#define ACC_ROWS 48         // rows of one round: 13 cells x 3 (round A) or 16 cells x 3 (round B)
+#define MAX_SMP 7           // ceil(21*21 / 64) samples per lane for descriptor_pattern_size 10
+
+// reduce accumulator rows [0, nrows) of the table in the reference's order:
+// b_t = a_t + a_{t+32}; tree over t with strides 1,2,4,8,16; lane c owns row c
+__device__ __forceinline__ void reduce_rows(const float* acc, float* vals, int nrows, int out_base, int lane)
+{
+    if (lane < nrows) {
+        const float* a = acc + lane * ACC_LD;
+        // the same tree, evaluated 8 leaves at a time to keep the register footprint small:
+        // c_k = ((b0+b1)+(b2+b3)) + ((b4+b5)+(b6+b7)) with b_j = a[8k+j] + a[8k+j+32]; result (c0+c1)+(c2+c3)
+        float c[4];
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) {
+            const float* q = a + 8 * k;
+            const float b0 = q[0] + q[32], b1 = q[1] + q[33], b2 = q[2] + q[34], b3 = q[3] + q[35];
+            const float b4 = q[4] + q[36], b5 = q[5] + q[37], b6 = q[6] + q[38], b7 = q[7] + q[39];
+            c[k] = ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7));
+        }
+        vals[out_base + lane] = (c[0] + c[1]) + (c[2] + c[3]);
+    }
+}
 
 __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base, long stride, HakLayout L,
                                                  const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
                                                  hak_point* points, int max_pts, int patsize, int upright, int desc)
 {
-    __shared__ float acc[90 * ACC_LD];          // [cell*3+ch][thread]
+    __shared__ float acc[ACC_ROWS * ACC_LD];    // [cell*3+ch][thread], one round at a time
     __shared__ float vals[90];
     __shared__ float sdx[128], sdy[128];
     __shared__ int sbin[128];
@@ -31,11 +58,13 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
     const int npts = state[img].num_pts;
     const float* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
+    if (!desc) return;
 
     const int size2 = patsize;
     const int size3 = (int)ceilf(2.0f * patsize / 3.0f);            // akazed.cu:2682
     const int size4 = (int)ceilf(0.5f * patsize);                   // akazed.cu:2683
     const int winsize = max(3 * size3, 4 * size4);
+    const int nsmp = winsize * winsize;
 
     for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
@@ -48,33 +77,37 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         const float* dyd = arena + L.ly(o, s);
         float angle = 0.f;
 
-        if (!desc) {
-            continue;
-        }
-
         // ------------------------------------------------------ orientation
         if (!upright) {
             const int step = (int)(ptsize + 0.5f);
             const int x = (int)(ptx + 0.5f) >> o;
             const int y = (int)(pty + 0.5f) >> o;
-            // the 208 sample threads of the reference, 64 at a time; valid ones
-            // (r2 < 36) are compacted in ascending thread order through a ballot
+            // the 208 sample threads of the reference, 64 at a time: issue every gather first
+            float gdx[4], gdy[4];
+            int gr2[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const int tix = q * 64 + lane;
+                const int i = (tix & 15) - 6, j = (tix >> 4) - 6;
+                const int r2 = i * i + j * j;
+                gr2[q] = (tix < 208 && r2 < 36) ? r2 : -1;
+                const int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
+                const long pos = (long)yy * oc.p + xx;
+                gdx[q] = gr2[q] >= 0 ? dxd[pos] : 0.f;
+                gdy[q] = gr2[q] >= 0 ? dyd[pos] : 0.f;
+            }
+            // valid samples are compacted in ascending thread order through a ballot
             int nvalid = 0;
-            for (int t0 = 0; t0 < 208; t0 += 64) {
-                int tix = t0 + lane;
-                int i = (tix & 15) - 6;
-                int j = (tix >> 4) - 6;
-                int r2 = i * i + j * j;
-                bool ok = tix < 208 && r2 < 36;
-                unsigned long long m = __ballot(ok);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const bool ok = gr2[q] >= 0;
+                const unsigned long long m = __ballot(ok);
                 if (ok) {
-                    int slot = nvalid + __popcll(m & ((1ull << lane) - 1ull));
-                    float gw = tab->orient_w[r2];
-                    int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
-                    long pos = (long)yy * oc.p + xx;
-                    float dx = gw * dxd[pos];
-                    float dy = gw * dyd[pos];
-                    float ang = hak_atan2f(dy, dx);
+                    const int slot = nvalid + __popcll(m & ((1ull << lane) - 1ull));
+                    const float gw = tab->orient_w[gr2[q]];
+                    const float dx = gw * gdx[q];
+                    const float dy = gw * gdy[q];
+                    const float ang = hak_atan2f(dy, dx);
                     int a = (int)(ang * (21 / HAK_PI_D)) + 21;      // akazed.cu:1702
                     a = a > 41 ? 41 : a;
                     a = a < 0 ? 0 : a;
@@ -128,8 +161,9 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         }
 
         // ------------------------------------------------------------- MLDB
-        for (int i = lane; i < 90 * ACC_LD; i += 64) acc[i] = 0.f;
-        __syncthreads();
+        // phase 1: positions + all gathers of this lane's samples (i = lane, lane+64, ...)
+        float vim[MAX_SMP], vrx[MAX_SMP], vry[MAX_SMP];
+        int cx[MAX_SMP], cy[MAX_SMP];           // sample grid coordinates; cx < 0 marks "no sample"
         {
             const float iratio = 1.f / (1 << o);
             const int scale = (int)(ptsize + 0.5f);
@@ -137,63 +171,122 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
             const float yf = pty * iratio;
             float si, co;
             hak_sincosf(angle, &si, &co);
-            for (int i = lane; i < winsize * winsize; i += 64) {
-                int y = i / winsize;
-                int x = i - winsize * y;
-                int m = max(x, y);
-                if (m >= winsize) continue;
-                int l = x - size2;
-                int k = y - size2;
+            float gdx[MAX_SMP], gdy[MAX_SMP];
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) {
+                const int i = lane + 64 * n;
+                const int y = i / winsize;
+                const int x = i - winsize * y;
+                const bool ok = i < nsmp;
+                cx[n] = ok ? x : -1;
+                cy[n] = y;
+                const int l = x - size2;
+                const int k = y - size2;
                 int xp = (int)(xf + scale * (k * co - l * si) + 0.5f);  // akazed.cu:1921
                 int yp = (int)(yf + scale * (k * si + l * co) + 0.5f);  // akazed.cu:1922
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
-                long pos = (long)yp * oc.p + xp;
-                float im = imd[pos];
-                float dx = dxd[pos];
-                float dy = dyd[pos];
-                float rx = -dx * si + dy * co;
-                float ry = dx * co + dy * si;
-                if (m < 2 * size2) {
-                    int x2 = (x < size2 ? 0 : 1);
-                    int y2 = (y < size2 ? 0 : 1);
-                    int c = 3 * (y2 * 2 + x2);
-                    acc[c * ACC_LD + lane] += im;
-                    acc[(c + 1) * ACC_LD + lane] += rx;
-                    acc[(c + 2) * ACC_LD + lane] += ry;
-                }
-                if (m < 3 * size3) {
-                    int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2));
-                    int y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
-                    int c = 3 * (4 + y3 * 3 + x3);
-                    acc[c * ACC_LD + lane] += im;
-                    acc[(c + 1) * ACC_LD + lane] += rx;
-                    acc[(c + 2) * ACC_LD + lane] += ry;
-                }
-                if (m < 4 * size4) {
-                    int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
-                    int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
-                    int c = 3 * (4 + 9 + y4 * 4 + x4);
-                    acc[c * ACC_LD + lane] += im;
-                    acc[(c + 1) * ACC_LD + lane] += rx;
-                    acc[(c + 2) * ACC_LD + lane] += ry;
-                }
+                const long pos = (long)yp * oc.p + xp;
+                vim[n] = ok ? imd[pos] : 0.f;
+                gdx[n] = ok ? dxd[pos] : 0.f;
+                gdy[n] = ok ? dyd[pos] : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) {
+                vrx[n] = -gdx[n] * si + gdy[n] * co;
+                vry[n] = gdx[n] * co + gdy[n] * si;
+            }
+        }
+        // samples beyond MAX_SMP per lane (descriptor_pattern_size > 10) are handled by the tail loop below
+        // phase 2, round A: 2x2 cells (rows 0..11) and 3x3 cells (rows 12..38)
+        for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < MAX_SMP; n++) {
+            const int x = cx[n], y = cy[n];
+            if (x < 0) continue;
+            const int m = max(x, y);
+            if (m < 2 * size2) {
+                const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1));
+                acc[c * ACC_LD + lane] += vim[n];
+                acc[(c + 1) * ACC_LD + lane] += vrx[n];
+                acc[(c + 2) * ACC_LD + lane] += vry[n];
+            }
+            if (m < 3 * size3) {
+                const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2));
+                const int y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+                const int c = 3 * (4 + y3 * 3 + x3);
+                acc[c * ACC_LD + lane] += vim[n];
+                acc[(c + 1) * ACC_LD + lane] += vrx[n];
+                acc[(c + 2) * ACC_LD + lane] += vry[n];
+            }
+        }
+        for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {          // tail: only for pattern sizes > 10
+            const int y = i / winsize, x = i - winsize * y, m = max(x, y);
+            const float iratio = 1.f / (1 << o);
+            const int scale = (int)(ptsize + 0.5f);
+            float si, co;
+            hak_sincosf(angle, &si, &co);
+            const int l = x - size2, k = y - size2;
+            int xp = (int)(ptx * iratio + scale * (k * co - l * si) + 0.5f);
+            int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
+            xp = min(max(xp, 0), oc.w - 1);
+            yp = min(max(yp, 0), oc.h - 1);
+            const long pos = (long)yp * oc.p + xp;
+            const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+            const float rx = -dx * si + dy * co, ry = dx * co + dy * si;
+            if (m < 2 * size2) {
+                const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1));
+                acc[c * ACC_LD + lane] += im; acc[(c + 1) * ACC_LD + lane] += rx; acc[(c + 2) * ACC_LD + lane] += ry;
+            }
+            if (m < 3 * size3) {
+                const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+                const int c = 3 * (4 + y3 * 3 + x3);
+                acc[c * ACC_LD + lane] += im; acc[(c + 1) * ACC_LD + lane] += rx; acc[(c + 2) * ACC_LD + lane] += ry;
             }
         }
         __syncthreads();
-        // transposed reduction: lane c reduces accumulator row c (and c+64) in the
-        // reference's order: b_t = a_t + a_{t+32}; tree over t with strides 1,2,4,8,16
-        for (int c = lane; c < 90; c += 64) {
-            const float* a = acc + c * ACC_LD;
-            float v[32];
+        reduce_rows(acc, vals, 39, 0, lane);
+        __syncthreads();
+        // round B: 4x4 cells (table rows 0..47 <-> accumulator rows 39..86)
+        for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
+        __syncthreads();
 #pragma unroll
-            for (int t = 0; t < 32; t++) v[t] = a[t] + a[t + 32];
-#pragma unroll
-            for (int d = 1; d < 32; d <<= 1)
-#pragma unroll
-                for (int t = 0; t + d < 32; t += 2 * d) v[t] = v[t] + v[t + d];
-            vals[c] = v[0];
+        for (int n = 0; n < MAX_SMP; n++) {
+            const int x = cx[n], y = cy[n];
+            if (x < 0) continue;
+            if (max(x, y) < 4 * size4) {
+                const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
+                const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+                const int c = 3 * (y4 * 4 + x4);
+                acc[c * ACC_LD + lane] += vim[n];
+                acc[(c + 1) * ACC_LD + lane] += vrx[n];
+                acc[(c + 2) * ACC_LD + lane] += vry[n];
+            }
         }
+        for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {          // tail: only for pattern sizes > 10
+            const int y = i / winsize, x = i - winsize * y;
+            if (max(x, y) >= 4 * size4) continue;
+            const float iratio = 1.f / (1 << o);
+            const int scale = (int)(ptsize + 0.5f);
+            float si, co;
+            hak_sincosf(angle, &si, &co);
+            const int l = x - size2, k = y - size2;
+            int xp = (int)(ptx * iratio + scale * (k * co - l * si) + 0.5f);
+            int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
+            xp = min(max(xp, 0), oc.w - 1);
+            yp = min(max(yp, 0), oc.h - 1);
+            const long pos = (long)yp * oc.p + xp;
+            const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+            const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
+            const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+            const int c = 3 * (y4 * 4 + x4);
+            acc[c * ACC_LD + lane] += im;
+            acc[(c + 1) * ACC_LD + lane] += -dx * si + dy * co;
+            acc[(c + 2) * ACC_LD + lane] += dx * co + dy * si;
+        }
+        __syncthreads();
+        reduce_rows(acc, vals, 48, 39, lane);
         __syncthreads();
         if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
             unsigned int desc_r = 0;
@@ -213,7 +306,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
                          hak_point* points, int max_pts, int patsize, int upright, int desc)
 {
-    int gx = max_pts < 2048 ? max_pts : 2048;
+    int gx = max_pts < 4096 ? max_pts : 4096;
     dim3 grid(gx, b.nimg);
     k_describe<<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }
