@@ -353,12 +353,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             float* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
-                { ProfScope ps(c, HAK_PROF_LOWPASS);
-                  hak_launch_lowpass(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->taps1, 2); }
-                { ProfScope ps(c, HAK_PROF_CONTRAST);
-                  hak_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct); }
-                { ProfScope ps(c, HAK_PROF_LOWPASS);
-                  hak_launch_lowpass(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps_base, c->base_R); }
+                { ProfScope ps(c, HAK_PROF_CONTRAST);                              // akaze.cpp:329-332 in two passes over img
+                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps1,
+                                        c->taps_base, c->base_R, c->state, cfg.per, L.noct); }
                 { ProfScope ps(c, HAK_PROF_HESSIAN);
                   if (!hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
                                                 lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))

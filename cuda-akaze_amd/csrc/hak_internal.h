@@ -166,6 +166,10 @@ void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, fl
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
+// octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
+bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, long stride,
+                           int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
+                           HakImgState* state, float per, int noct);
 // sigma=1 low-pass + conductivity fused (kernels_smoothflow.hip)
 void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, float* flow, long stride,
                             int w, int h, int p, int nimg, const float* taps, int diffusivity,

@@ -1,0 +1,247 @@
+// kernels_base.hip -- octave-0 prologue: base level + contrast factor (akaze.cpp:325-333).
+//
+//   hLowPass(img -> smooth, var 1, ksz 5)         akazed.cu:2336, 204   (gConv2d<2>)
+//   hScharrContrast(smooth -> kcontrast)          akazed.cu:2410, 644, 827, 901
+//   hLowPass(img -> Lt(0,0), var soffset^2)       akazed.cu:2336, 204   (gConv2d<R>, R = 4 for soffset 1.6)
+//
+// The sigma=1 plane is only an intermediate of the contrast factor, so it is never written:
+//   pass A  reads the image once and produces Lt(0,0) AND the maximum Scharr magnitude of the
+//           sigma=1 image (one atomicMax per block);
+//   pass B  reads the image again, recomputes sigma=1 + gradient and fills the 300-bin histogram
+//           (needs the global maximum of pass A).
+// 12 B/px instead of the 24 B/px of four separate passes.  Both are persistent tile kernels with
+// register prefetch of the next tile (see kernels_hessian.hip for why).  As in
+// kernels_smoothflow.hip, tiles are loaded with reflect-101 indices and then indexed plainly.
+#include "hak_internal.h"
+
+#define BS_TX 64
+#define BS_TY 32
+
+struct BsTaps { float a[3]; float b[6]; };       // sigma=1 taps (R=2), base taps (R <= 5)
+
+// un-normalised Scharr magnitude at the centre of a 3x3 neighbourhood in a tile of width W (akazed.cu:664-666)
+template <int W>
+__device__ __forceinline__ float scharr_mag(const float* q)
+{
+    const float ul = q[-W - 1], uc = q[-W], ur = q[-W + 1];
+    const float cl = q[-1], cr = q[1];
+    const float ll = q[W - 1], lc = q[W], lr = q[W + 1];
+    const float dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
+    const float dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
+    return sqrtf(dx * dx + dy * dy);
+}
+
+template <int H>                                   // H = tile halo
+struct BsGeo {
+    static constexpr int RW = BS_TX + 2 * H, RH = BS_TY + 2 * H;    // raw tile
+    static constexpr int NPF = (RW * RH + 255) / 256;
+    static constexpr int PW = BS_TX + 2, PH = BS_TY + 6;            // sigma=1 row-pass tile (halo 1 in x, 3 in y)
+    static constexpr int SH = BS_TY + 2;                            // sigma=1 smooth tile (halo 1)
+};
+
+template <int H>
+__device__ __forceinline__ void bs_fetch(float (&pf)[BsGeo<H>::NPF], const float* __restrict__ s, int w, int h, int sp,
+                                         int x0, int y0, int tid)
+{
+    using G = BsGeo<H>;
+#pragma unroll
+    for (int i = 0; i < G::NPF; i++) {
+        const int idx = tid + 256 * i;
+        if (idx < G::RW * G::RH) {
+            const int r = idx / G::RW, c = idx - r * G::RW;
+            pf[i] = s[(long)hak_refl(y0 - H + r, h) * sp + hak_refl(x0 - H + c, w)];
+        }
+    }
+}
+
+// sigma=1 row pass (rows y0-3 .. y0+TY+2, columns x0-1 .. x0+TX) from a raw tile with halo H >= 3
+template <int H>
+__device__ __forceinline__ void bs_rowpass1(const float* raw, float* rowp, const BsTaps& t, int tid)
+{
+    using G = BsGeo<H>;
+    for (int idx = tid; idx < G::PH * G::PW; idx += 256) {
+        const int r = idx / G::PW, c = idx - r * G::PW;
+        const float* q = raw + (r + H - 3) * G::RW + c + H - 1;
+        float ws = q[0] * t.a[0];
+        ws += t.a[1] * (q[-1] + q[1]);
+        ws += t.a[2] * (q[-2] + q[2]);
+        rowp[idx] = ws;
+    }
+}
+
+// sigma=1 column pass -> smooth tile (rows y0-1 .. y0+TY, columns x0-1 .. x0+TX)
+template <int H>
+__device__ __forceinline__ void bs_colpass1(const float* rowp, float* sm, const BsTaps& t, int tid)
+{
+    using G = BsGeo<H>;
+    for (int idx = tid; idx < G::SH * G::PW; idx += 256) {
+        const int r = idx / G::PW, c = idx - r * G::PW;
+        const float* q = rowp + (r + 2) * G::PW + c;
+        float ws = q[0] * t.a[0];
+        ws += t.a[1] * (q[-G::PW] + q[G::PW]);
+        ws += t.a[2] * (q[-2 * G::PW] + q[2 * G::PW]);
+        sm[idx] = ws;
+    }
+}
+
+// ---- pass A: Lt(0,0) = G(base) * img, and max |Scharr(G(1) * img)|
+template <int R>
+__global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, long img_stride, int sp,
+                                                float* __restrict__ lt, long stride, int w, int h, int p,
+                                                BsTaps t, HakImgState* state, int tiles_per_block)
+{
+    constexpr int H = R < 3 ? 3 : R;
+    using G = BsGeo<H>;
+    __shared__ float raw[G::RH * G::RW];              // reused for the sigma=1 smooth tile
+    __shared__ float rowb[G::RH * BS_TX];             // base row pass (all tile rows, output columns)
+    __shared__ float rowp[G::PH * G::PW];             // sigma=1 row pass
+    __shared__ float wmax[4];
+    const float* s = img + (long)blockIdx.z * img_stride;
+    float* o = lt + (long)blockIdx.z * stride;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BS_TX;
+    const int ty0 = blockIdx.y * tiles_per_block;
+    const int ty1 = min(ty0 + tiles_per_block, (h + BS_TY - 1) / BS_TY);
+    float pf[G::NPF];
+    float tmax = 0.f;
+    if (ty0 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, ty0 * BS_TY, tid);
+    for (int ty = ty0; ty < ty1; ty++) {
+        const int y0 = ty * BS_TY;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < G::NPF; i++)
+            if (tid + 256 * i < G::RW * G::RH) raw[tid + 256 * i] = pf[i];
+        __syncthreads();
+        if (ty + 1 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, y0 + BS_TY, tid);
+        // base row pass on every raw row, output columns only (akazed.cu:227-239)
+        for (int idx = tid; idx < G::RH * BS_TX; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            const float* q = raw + r * G::RW + c + H;
+            float ws = q[0] * t.b[0];
+#pragma unroll
+            for (int k = 1; k <= R; k++) ws += t.b[k] * (q[-k] + q[k]);
+            rowb[idx] = ws;
+        }
+        bs_rowpass1<H>(raw, rowp, t, tid);
+        __syncthreads();
+        // base column pass -> Lt(0,0) (akazed.cu:283-288)
+        for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            const int x = x0 + c, y = y0 + r;
+            const float* q = rowb + (r + H) * BS_TX + c;
+            float ws = q[0] * t.b[0];
+#pragma unroll
+            for (int k = 1; k <= R; k++) ws += t.b[k] * (q[-k * BS_TX] + q[k * BS_TX]);
+            if (x < w && y < h) o[(long)y * p + x] = ws;
+        }
+        float* sm = raw;
+        bs_colpass1<H>(rowp, sm, t, tid);
+        __syncthreads();
+        for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            if (x0 + c < w && y0 + r < h) tmax = fmaxf(tmax, scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
+    if ((tid & 63) == 0) wmax[tid >> 6] = tmax;
+    __syncthreads();
+    if (tid == 0) {
+        const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > 0.f) atomicMax(&state[blockIdx.z].hmax_bits, __float_as_uint(m));   // D2: the intended reduction
+    }
+}
+
+// ---- pass B: 300-bin histogram of |Scharr(G(1) * img)|
+__global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, long img_stride, int sp,
+                                                int w, int h, BsTaps t, HakImgState* state, int tiles_per_block)
+{
+    constexpr int H = 3;
+    using G = BsGeo<H>;
+    __shared__ float raw[G::RH * G::RW];
+    __shared__ float rowp[G::PH * G::PW];
+    __shared__ int shist[HAK_NBINS];
+    const float* s = img + (long)blockIdx.z * img_stride;
+    const int tid = threadIdx.x;
+    const int x0 = blockIdx.x * BS_TX;
+    const int ty0 = blockIdx.y * tiles_per_block;
+    const int ty1 = min(ty0 + tiles_per_block, (h + BS_TY - 1) / BS_TY);
+    for (int i = tid; i < HAK_NBINS; i += 256) shist[i] = 0;
+    const float hmax = __uint_as_float(state[blockIdx.z].hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;                         // akazed.cu:2450
+    float pf[G::NPF];
+    if (ty0 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, ty0 * BS_TY, tid);
+    for (int ty = ty0; ty < ty1; ty++) {
+        const int y0 = ty * BS_TY;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < G::NPF; i++)
+            if (tid + 256 * i < G::RW * G::RH) raw[tid + 256 * i] = pf[i];
+        __syncthreads();
+        if (ty + 1 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, y0 + BS_TY, tid);
+        bs_rowpass1<H>(raw, rowp, t, tid);
+        __syncthreads();
+        float* sm = raw;
+        bs_colpass1<H>(rowp, sm, t, tid);
+        __syncthreads();
+        for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
+            const int r = idx >> 6, c = idx & 63;
+            if (x0 + c < w && y0 + r < h) {
+                const float g = scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1);
+                // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
+                int hi = (int)((double)g * (double)hfactor);
+                hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
+                atomicAdd(&shist[hi], 1);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < HAK_NBINS; i += 256)
+        if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
+}
+
+// host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371)
+// and ikc = 1/(k*k) (akazed.cu:2493), kept on the device
+__global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
+{
+    HakImgState* st = state + blockIdx.x;
+    if (threadIdx.x != 0) return;
+    const float hmax = __uint_as_float(st->hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;
+    int thresh = (int)((npix - st->hist[0]) * per);
+    int cumuv = 0, k = 1;
+    while (k < HAK_NBINS) {
+        if (cumuv >= thresh) break;
+        cumuv += st->hist[k];
+        k++;
+    }
+    float kc = k / hfactor;
+    for (int o = 0; o < noct; o++) {
+        if (o > 0) kc *= 0.75f;
+        st->kcontrast[o] = kc;
+        st->ikc[o] = 1.f / (kc * kc);
+    }
+}
+
+// img -> Lt(0,0) and the per-image contrast factors.  Returns false when R is not supported here.
+bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, long stride,
+                           int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
+                           HakImgState* state, float per, int noct)
+{
+    if (R < 2 || R > 5) return false;
+    BsTaps t;
+    for (int i = 0; i < 3; i++) t.a[i] = taps1[i];
+    for (int i = 0; i < 6; i++) t.b[i] = i <= R ? taps_base[i] : 0.f;
+    const int ntx = (w + BS_TX - 1) / BS_TX, nty = (h + BS_TY - 1) / BS_TY;
+    int tpb = 8;
+    while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
+    dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
+    switch (R) {
+    case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
+    case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
+    case 4: k_base_a<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
+    default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
+    }
+    k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb);
+    k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    return true;
+}
