@@ -251,6 +251,11 @@ static int build_plan(hak_ctx* c, int w, int h)
     }
     for (int r2 = 0; r2 < 36; r2++) c->htab.orient_w[r2] = hak_expf(-r2 * 0.08f);  // akazed.cu:1697
     hak_compare_indices(c->htab.comp1, c->htab.comp2);
+    for (int b = 0; b < 61; b++)
+        for (int i = 0; i < 8; i++) {
+            c->htab.comp_packed[b * 16 + 2 * i] = (unsigned char)c->htab.comp1[b * 8 + i];
+            c->htab.comp_packed[b * 16 + 2 * i + 1] = (unsigned char)c->htab.comp2[b * 8 + i];
+        }
     hak_gauss_taps(1.f, 2, c->taps1);
     int ksz = (int)(2 * ceilf((cfg.soffset - 0.8f) / 0.3f) + 3);                 // akaze.cpp:328
     c->base_R = ksz <= 5 ? 2 : ksz <= 7 ? 3 : ksz <= 9 ? 4 : 5;                   // akazed.cu:2345-2377

@@ -47,6 +47,7 @@ struct HakTables {
     int sigma_size[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
     float orient_w[36];                                // exp(-r2*0.08f)
     int comp1[488], comp2[488];                        // MLDB pair table (akazed.cu:65-159)
+    unsigned char comp_packed[64 * 16];                // per descriptor byte: 8 x (idx1, idx2) as bytes
 };
 
 // ---------------------------------------------------------------- device helpers

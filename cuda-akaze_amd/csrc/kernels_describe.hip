@@ -66,6 +66,10 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
     const int winsize = max(3 * size3, 4 * size4);
     const int nsmp = winsize * winsize;
 
+    // this lane's 8 comparison pairs (akazed.cu:65-159), packed as bytes: one 16-byte load
+    const uint4 cmp = reinterpret_cast<const uint4*>(tab->comp_packed)[lane];
+    const unsigned int cw[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
+
     for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
         const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
@@ -120,7 +124,8 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
             __syncthreads();
             if (lane < 42) {
                 float rx = 0.f, ry = 0.f;
-                for (int n = 0; n < nvalid; n++) {
+#pragma unroll 8
+                for (int n = 0; n < nvalid; n++) {                  // ascending sample order (D7)
                     if (sbin[n] == lane) { rx += sdx[n]; ry += sdy[n]; }
                 }
                 resx[lane] = rx;
@@ -137,13 +142,14 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 re8y[lane] = ay;
             }
             __syncthreads();
+            // first k maximising re8x^2 + re8y^2 (akazed.cu:1721-1730: strict '>' from maxr = 0)
+            float rk = 0.f;
+            if (lane < 42) rk = re8x[lane] * re8x[lane] + re8y[lane] * re8y[lane];
+            float rmax = rk;
+            for (int off = 32; off > 0; off >>= 1) rmax = fmaxf(rmax, __shfl_xor(rmax, off));
+            const unsigned long long mm = __ballot(lane < 42 && rk == rmax);
+            const int maxk = rmax > 0.f && mm ? __ffsll((long long)mm) - 1 : 0;
             if (lane == 0) {
-                float maxr = 0.0f;
-                int maxk = 0;
-                for (int k = 0; k < 42; k++) {
-                    float r = re8x[k] * re8x[k] + re8y[k] * re8y[k];
-                    if (r > maxr) { maxr = r; maxk = k; }
-                }
                 // dFastAtan2 akazed.cu:173-185
                 float yv = re8y[maxk], xv = re8x[maxk];
                 float absx = fabsf(xv), absy = fabsf(yv);
@@ -291,10 +297,11 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
             unsigned int desc_r = 0;
             const int nb = lane == 60 ? 6 : 8;
-            for (int i = 0; i < nb; ++i) {
-                int idx1 = tab->comp1[lane * 8 + i];
-                int idx2 = tab->comp2[lane * 8 + i];
-                desc_r |= (vals[idx1] > vals[idx2] ? 1u : 0u) << i;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned int pr = (cw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const int idx1 = pr & 0xFF, idx2 = pr >> 8;
+                if (i < nb) desc_r |= (vals[idx1] > vals[idx2] ? 1u : 0u) << i;
             }
             pt->features[lane] = (unsigned char)desc_r;
         }
