@@ -61,6 +61,16 @@ __device__ __forceinline__ int hak_refl(int i, int m)
     return i < m ? i : m - 1;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() lowers to
+// `s_waitcnt vmcnt(0) lgkmcnt(0); s_barrier`, i.e. it also drains every outstanding global load and
+// store of the wave -- which serialises a register prefetch and exposes the store latency at each
+// phase boundary of the persistent tile kernels.  Use this between phases that only exchange data
+// through LDS; global results are complete at kernel end as usual.
+__device__ __forceinline__ void hak_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // ------------------------------------------------- deterministic float32 math
 // Same operation sequence as the parity oracle's (oracle/okz_math.h): one IEEE
 // binary32 op per step, explicit fmaf only.  The reference's libdevice /

@@ -107,11 +107,11 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     if (ty0 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, ty0 * BS_TY, tid);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * BS_TY;
-        __syncthreads();
+        hak_lds_barrier();
 #pragma unroll
         for (int i = 0; i < G::NPF; i++)
             if (tid + 256 * i < G::RW * G::RH) raw[tid + 256 * i] = pf[i];
-        __syncthreads();
+        hak_lds_barrier();
         if (ty + 1 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, y0 + BS_TY, tid);
         // base row pass on every raw row, output columns only (akazed.cu:227-239)
         for (int idx = tid; idx < G::RH * BS_TX; idx += 256) {
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
             rowb[idx] = ws;
         }
         bs_rowpass1<H>(raw, rowp, t, tid);
-        __syncthreads();
+        hak_lds_barrier();
         // base column pass -> Lt(0,0) (akazed.cu:283-288)
         for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
         }
         float* sm = raw;
         bs_colpass1<H>(rowp, sm, t, tid);
-        __syncthreads();
+        hak_lds_barrier();
         for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
             if (x0 + c < w && y0 + r < h) tmax = fmaxf(tmax, scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1));
@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     }
     for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
     if ((tid & 63) == 0) wmax[tid >> 6] = tmax;
-    __syncthreads();
+    hak_lds_barrier();
     if (tid == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
         if (m > 0.f) atomicMax(&state[blockIdx.z].hmax_bits, __float_as_uint(m));   // D2: the intended reduction
@@ -172,17 +172,17 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
     if (ty0 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, ty0 * BS_TY, tid);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * BS_TY;
-        __syncthreads();
+        hak_lds_barrier();
 #pragma unroll
         for (int i = 0; i < G::NPF; i++)
             if (tid + 256 * i < G::RW * G::RH) raw[tid + 256 * i] = pf[i];
-        __syncthreads();
+        hak_lds_barrier();
         if (ty + 1 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, y0 + BS_TY, tid);
         bs_rowpass1<H>(raw, rowp, t, tid);
-        __syncthreads();
+        hak_lds_barrier();
         float* sm = raw;
         bs_colpass1<H>(rowp, sm, t, tid);
-        __syncthreads();
+        hak_lds_barrier();
         for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
             if (x0 + c < w && y0 + r < h) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
             }
         }
     }
-    __syncthreads();
+    hak_lds_barrier();
     for (int i = tid; i < HAK_NBINS; i += 256)
         if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
 }

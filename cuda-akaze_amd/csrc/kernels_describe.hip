@@ -121,7 +121,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 }
                 nvalid += __popcll(m);
             }
-            __syncthreads();
+            hak_lds_barrier();
             if (lane < 42) {
                 float rx = 0.f, ry = 0.f;
 #pragma unroll 8
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 resx[lane] = rx;
                 resy[lane] = ry;
             }
-            __syncthreads();
+            hak_lds_barrier();
             if (lane < 42) {                                        // akazed.cu:1708-1717
                 float ax = resx[lane], ay = resy[lane];
                 for (int k = lane + 1; k < lane + 7; k++) {
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 re8x[lane] = ax;
                 re8y[lane] = ay;
             }
-            __syncthreads();
+            hak_lds_barrier();
             // first k maximising re8x^2 + re8y^2 (akazed.cu:1721-1730: strict '>' from maxr = 0)
             float rk = 0.f;
             if (lane < 42) rk = re8x[lane] * re8x[lane] + re8y[lane] * re8y[lane];
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 r = (yv < 0 ? -r : r);
                 s_angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);    // akazed.cu:1734
             }
-            __syncthreads();
+            hak_lds_barrier();
             angle = s_angle;
         }
 
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         // samples beyond MAX_SMP per lane (descriptor_pattern_size > 10) are handled by the tail loop below
         // phase 2, round A: 2x2 cells (rows 0..11) and 3x3 cells (rows 12..38)
         for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
-        __syncthreads();
+        hak_lds_barrier();
 #pragma unroll
         for (int n = 0; n < MAX_SMP; n++) {
             const int x = cx[n], y = cy[n];
@@ -251,12 +251,12 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 acc[c * ACC_LD + lane] += im; acc[(c + 1) * ACC_LD + lane] += rx; acc[(c + 2) * ACC_LD + lane] += ry;
             }
         }
-        __syncthreads();
+        hak_lds_barrier();
         reduce_rows(acc, vals, 39, 0, lane);
-        __syncthreads();
+        hak_lds_barrier();
         // round B: 4x4 cells (table rows 0..47 <-> accumulator rows 39..86)
         for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
-        __syncthreads();
+        hak_lds_barrier();
 #pragma unroll
         for (int n = 0; n < MAX_SMP; n++) {
             const int x = cx[n], y = cy[n];
@@ -291,9 +291,9 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
             acc[(c + 1) * ACC_LD + lane] += -dx * si + dy * co;
             acc[(c + 2) * ACC_LD + lane] += dx * co + dy * si;
         }
-        __syncthreads();
+        hak_lds_barrier();
         reduce_rows(acc, vals, 48, 39, lane);
-        __syncthreads();
+        hak_lds_barrier();
         if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
             unsigned int desc_r = 0;
             const int nb = lane == 60 ? 6 : 8;
@@ -306,7 +306,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
             pt->features[lane] = (unsigned char)desc_r;
         }
         if (lane == 0) pt->angle = angle;
-        __syncthreads();
+        hak_lds_barrier();
     }
 }
 

@@ -115,7 +115,7 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             oy[(long)y * p + x] = vy;
         }
     }
-    __syncthreads();                                                // sm is dead from here: the det tile reuses it
+    hak_lds_barrier();                                                // sm is dead from here: the det tile reuses it
     // ---- determinant on the det tile (flattened the same way), centre -> HBM
     float* dt = sm;
 #pragma unroll 3
@@ -142,18 +142,19 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
         if (c >= HF_E && c < HF_E + HF_TX && r >= HF_E && r < HF_E + TY) od[(long)y * p + x] = d;
     }
     if (ex.maps == nullptr) return;                                 // (uniform) determinant only
-    __syncthreads();
+    hak_lds_barrier();
     // ---- extrema of this level on the output tile (akazed.cu:1346-1373)
     const int x = x0 + lane;
     const bool xok = x >= ex.psz && (int)(x - ex.border + 0.5f) - 1 >= 0 && (int)(x + ex.border + 0.5f) + 1 < w;
     for (int rr = wv; rr < TY; rr += 4) {
         const int y = y0 + rr;
         bool hit = false;
-        float v = 0.f;
-        if (xok && y >= ex.psz && (int)(y - ex.border + 0.5f) - 1 >= 0 && (int)(y + ex.border + 0.5f) + 1 < h) {
-            const float* vp = dt + (rr + HF_E) * EW + lane + HF_E;
-            v = *vp;
-            hit = v > ex.threshold && v > vp[-EW] && v > vp[EW] && v > vp[-1] && v > vp[1] &&
+        // threshold first: almost no pixel passes it, so the wave usually skips the neighbourhood test
+        const float* vp = dt + (rr + HF_E) * EW + lane + HF_E;
+        const float v = *vp;
+        if (__ballot(v > ex.threshold) == 0ull) continue;
+        if (v > ex.threshold && xok && y >= ex.psz && (int)(y - ex.border + 0.5f) - 1 >= 0 && (int)(y + ex.border + 0.5f) + 1 < h) {
+            hit = v > vp[-EW] && v > vp[EW] && v > vp[-1] && v > vp[1] &&
                   v > vp[-EW - 1] && v > vp[-EW + 1] && v > vp[EW - 1] && v > vp[EW + 1];
         }
         const unsigned long long m = __ballot(hit);
@@ -199,9 +200,9 @@ __global__ __launch_bounds__(256) void k_hessian_fused(const float* __restrict__
     if (ty0 < ty1) hess_fetch<S>(P, s, w, h, p, x0, ty0 * G::TY, lane, wv);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * G::TY;
-        __syncthreads();                                        // previous tile's readers of sm / sx / sy are done
+        hak_lds_barrier();                                        // previous tile's readers of sm / sx / sy are done
         hess_commit<S>(P, sm, lane, wv);
-        __syncthreads();
+        hak_lds_barrier();
         if (ty + 1 < ty1) hess_fetch<S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
         if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, blockIdx.z);

@@ -57,11 +57,11 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float* __restrict__ s
     if (ty0 < ty1) sf_fetch(pf, s, w, h, p, x0, ty0 * SF_TY, tid);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * SF_TY;
-        __syncthreads();                                    // previous tile's readers are done
+        hak_lds_barrier();                                    // previous tile's readers are done
 #pragma unroll
         for (int i = 0; i < SF_NPF; i++)
             if (tid + 256 * i < SF_RW * SF_RH) raw[tid + 256 * i] = pf[i];
-        __syncthreads();
+        hak_lds_barrier();
         if (ty + 1 < ty1) sf_fetch(pf, s, w, h, p, x0, y0 + SF_TY, tid);      // in flight during the compute below
         // ---- row pass (akazed.cu:227-239): rowp[r][c] <-> image column x0-1+c, raw column c+1+... (offset 2)
         for (int idx = tid; idx < SF_RH * SF_PW; idx += 256) {
@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float* __restrict__ s
             ws += t.k2 * (q[-2] + q[2]);
             rowp[idx] = ws;
         }
-        __syncthreads();
+        hak_lds_barrier();
         // ---- column pass (akazed.cu:283-288) -> smooth tile (halo 1) in LDS, centre -> HBM
         float* sm = raw;
         for (int idx = tid; idx < SF_SH * SF_PW; idx += 256) {
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_smooth_flow(const float* __restrict__ s
             const int x = x0 - 1 + c, y = y0 - 1 + r;
             if (c >= 1 && c <= SF_TX && r >= 1 && r <= SF_TY && x < w && y < h) osm[(long)y * p + x] = ws;
         }
-        __syncthreads();
+        hak_lds_barrier();
         // ---- Scharr + conductivity (akazed.cu:1088-1106) on the output tile
         for (int idx = tid; idx < SF_TY * SF_TX; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
