@@ -174,8 +174,15 @@ def main():
             m2, n2 = C.c_double(), C.c_int()
             ah.check(ah.lib.hak_prof_read(det.ctx, k, C.byref(m2), C.byref(n2)))
             cls[name] = round(m2.value / nprof, 4)
-        roof = {"kernel": "k_fed_step", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+        # HBM bytes per FED launch from the PMC passes committed under profiles/ (tools/pmc_traffic.py:
+        # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when not measured
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tfile) and (w, h, args.octaves, B) == (1920, 1080, 4, 16):
+            traffic = round(json.load(open(tfile))["fed_hbm_bytes_per_launch"])
+        roof = {"kernel": "k_fed_multi<NS> (fused FED steps, 12 B/px/step algorithmic)", "bound": "hbm",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
                 "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls}
 

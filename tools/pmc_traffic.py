@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes into per-kernel HBM traffic.
+
+Usage (on the GPU box, two separate passes as MI355X_MICROARCH.md prescribes -- FETCH_SIZE and
+WRITE_SIZE do not fit one pass):
+    rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcF -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+    rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcW -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
+    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW profiles/r01_pmc_traffic
+
+Units / corrections (MI355X_MICROARCH.md, HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports
+exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so reads are doubled for
+kernels whose loads are float4 streams (the FED kernel); WRITE_SIZE is exact for 16 B/lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import sys
+
+
+def load(dirname, counter):
+    tot = collections.defaultdict(float)
+    n = collections.Counter()
+    for path in glob.glob(dirname + "/*/*counter_collection.csv"):
+        for r in csv.DictReader(open(path)):
+            if r["Counter_Name"] != counter:
+                continue
+            k = r["Kernel_Name"].split("(")[0]
+            tot[k] += float(r["Counter_Value"]) * 1024.0
+            n[k] += 1
+    return tot, n
+
+
+def main():
+    fdir, wdir, out = sys.argv[1:4]
+    fetch, nf = load(fdir, "FETCH_SIZE")
+    write, nw = load(wdir, "WRITE_SIZE")
+    rows = []
+    for k in sorted(fetch, key=lambda k: -fetch[k]):
+        rows.append(dict(kernel=k, dispatches=nf[k], fetch_size_bytes=fetch[k], write_size_bytes=write.get(k, 0.0)))
+    fed = [r for r in rows if "k_fed_multi" in r["kernel"]]
+    launches = sum(r["dispatches"] for r in fed)
+    fed_fetch = sum(r["fetch_size_bytes"] for r in fed)
+    fed_write = sum(r["write_size_bytes"] for r in fed)
+    summary = dict(
+        note="FETCH_SIZE doubled (gfx950 reports half of a 16 B/lane streaming read); WRITE_SIZE as reported",
+        fed_launches=launches,
+        fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
+        fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows)
+    json.dump(summary, open(out + ".json", "w"), indent=1)
+    with open(out + ".csv", "w") as f:
+        f.write("kernel,dispatches,FETCH_SIZE_bytes,WRITE_SIZE_bytes\n")
+        for r in rows:
+            f.write(f"{r['kernel']},{r['dispatches']},{r['fetch_size_bytes']:.0f},{r['write_size_bytes']:.0f}\n")
+    print(json.dumps({k: v for k, v in summary.items() if k != "per_kernel"}))
+
+
+if __name__ == "__main__":
+    main()
