@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -112,6 +114,8 @@ def main():
     det.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg)
     stream = torch.cuda.current_stream()
     ah.check(ah.lib.hak_set_stream(det.ctx, C.c_void_p(stream.cuda_stream)))
+    if args.serial:
+        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0))
     d_pts = torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda")
     d_num = torch.zeros(nimg, dtype=torch.int32, device="cuda")
     h_pts, h_num = C.c_void_p(), C.c_void_p()
@@ -157,6 +161,9 @@ def main():
     # ---- roofline leg: same steps with per-launch HIP events on the launch stream
     roof = None
     if not args.no_roofline:
+        # per-kernel durations are only meaningful without overlap: the roofline leg runs the same steps
+        # strictly serially on one stream (the timed region above overlaps the octaves on separate streams)
+        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0))
         ah.check(ah.lib.hak_prof_reset(det.ctx))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
@@ -184,7 +191,8 @@ def main():
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
-                "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls}
+                "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls,
+                "mode": "serial leg (one stream); rocprof counterpart: profiles/*_serial_kernel_stats.csv from `bench.py --serial`"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -199,7 +207,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
-                       "pairs_per_step_per_gpu": B, "sharding": "independent pairs per rank, no data-path collective",
+                       "pairs_per_step_per_gpu": B, "octave_streams": "serial" if args.serial else "concurrent", "sharding": "independent pairs per rank, no data-path collective",
                        "keypoints_per_image": round(summary[1] / (2.0 * summary[0]), 1),
                        "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
             "roofline": roof, "cpu_baseline": cpu,

@@ -151,6 +151,11 @@ struct hak_ctx {
     int* d_num = nullptr;           // [batch] counts for the synchronous entry points
     int* h_num = nullptr;           // pinned
     hipStream_t own_stream = nullptr, stream = nullptr;
+    // octave o+1 depends only on Lt(o,0) (akaze.cpp:371-375), so each octave runs on its own stream and the
+    // latency-bound small-octave launches overlap octave 0's heavy kernels
+    hipStream_t oct_stream[HAK_MAX_OCTAVES] = {};      // [0] unused (= stream)
+    hipEvent_t ev_ready[HAK_MAX_OCTAVES] = {}, ev_done[HAK_MAX_OCTAVES] = {};
+    bool concurrent = true;
     bool prof_on = false;
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
@@ -160,8 +165,8 @@ struct hak_ctx {
 static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
 
 struct ProfScope {
-    hak_ctx* c; int k; hipEvent_t stop = nullptr;
-    ProfScope(hak_ctx* ctx, int klass) : c(ctx), k(klass)
+    hak_ctx* c; int k; hipEvent_t stop = nullptr; hipStream_t s;
+    ProfScope(hak_ctx* ctx, int klass, hipStream_t st = nullptr) : c(ctx), k(klass), s(st ? st : ctx->stream)
     {
         if (!c->prof_on) return;
         ProfClass& p = c->prof[k];
@@ -170,12 +175,12 @@ struct ProfScope {
             (void)hipEventCreate(&a); (void)hipEventCreate(&b);
             p.ev.push_back(a); p.ev.push_back(b);
         }
-        (void)hipEventRecord(p.ev[p.used], c->stream);
+        (void)hipEventRecord(p.ev[p.used], s);
         stop = p.ev[p.used + 1];
         p.used += 2;
         p.launches++;
     }
-    ~ProfScope() { if (stop) (void)hipEventRecord(stop, c->stream); }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
 };
 
 static int build_plan(hak_ctx* c, int w, int h)
@@ -296,6 +301,12 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_num, sizeof(int) * (size_t)B);
     if (e == hipSuccess) e = hipMemcpy(c->dtab, &c->htab, sizeof(HakTables), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    for (int o = 0; o < L.noct && e == hipSuccess; o++) {
+        if (o > 0) e = hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready[o], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming);
+    }
+    if (const char* s = getenv("HAK_SERIAL")) c->concurrent = atoi(s) == 0;
     if (e != hipSuccess) {
         fail(std::string("hak_create: ") + hipGetErrorString(e));
         hak_destroy(c);
@@ -310,6 +321,11 @@ extern "C" void hak_destroy(hak_ctx* c)
 {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (int o = 0; o < HAK_MAX_OCTAVES; o++) {
+        if (c->oct_stream[o]) { (void)hipStreamSynchronize(c->oct_stream[o]); (void)hipStreamDestroy(c->oct_stream[o]); }
+        if (c->ev_ready[o]) (void)hipEventDestroy(c->ev_ready[o]);
+        if (c->ev_done[o]) (void)hipEventDestroy(c->ev_done[o]);
+    }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
     void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab};
@@ -326,6 +342,14 @@ extern "C" int hak_set_stream(hak_ctx* c, void* s)
     return 0;
 }
 
+extern "C" int hak_set_concurrency(hak_ctx* c, int on)
+{
+    if (!c) return fail("null context");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->concurrent = on != 0;
+    return 0;
+}
+
 extern "C" int hak_sync(hak_ctx* c)
 {
     if (!c) return fail("null context");
@@ -339,7 +363,8 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
-    hipStream_t st = c->stream;
+    const hipStream_t main_st = c->stream;
+    hipStream_t st = main_st;
     float* A = c->arena;
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
@@ -351,6 +376,10 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
 
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
+        if (c->concurrent && o > 0) {                       // this octave's chain waits only for Lt(o-1,0)
+            st = c->oct_stream[o];
+            if (hipStreamWaitEvent(st, c->ev_ready[o - 1], 0) != hipSuccess) return fail("stream wait");
+        }
         float* smooth = A + L.smooth_off[o];
         float* flow = A + L.flow_off[o];
         float* tmp = A + L.tmp_off[o];
@@ -358,10 +387,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             float* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
-                { ProfScope ps(c, HAK_PROF_CONTRAST);                              // akaze.cpp:329-332 in two passes over img
+                { ProfScope ps(c, HAK_PROF_CONTRAST, st);                          // akaze.cpp:329-332 in two passes over img
                   hak_launch_base_level(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps1,
                                         c->taps_base, c->base_R, c->state, cfg.per, L.noct); }
-                { ProfScope ps(c, HAK_PROF_HESSIAN);
+                if (c->concurrent) (void)hipEventRecord(c->ev_ready[0], st);       // Lt(0,0) + contrast factors ready
+                { ProfScope ps(c, HAK_PROF_HESSIAN, st);
                   if (!hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
                                                 lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
                       hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
@@ -373,17 +403,17 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             if (s == 0) {                                                         // akaze.cpp:369-392
                 // decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
                 float* first = (G % 2 == 0) ? Lt : tmp;
-                { ProfScope ps(c, HAK_PROF_DOWN);
+                { ProfScope ps(c, HAK_PROF_DOWN, st);
                   hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1); }
                 fsrc = first;
             } else {                                                              // akaze.cpp:393-421
                 fsrc = A + L.lt(o, s - 1);
             }
             if (s == 0) {
-                ProfScope ps(c, HAK_PROF_FLOW);
+                ProfScope ps(c, HAK_PROF_FLOW, st);
                 hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
             } else {                                                              // akaze.cpp:403-404 in one pass
-                ProfScope ps(c, HAK_PROF_LOWPASS);
+                ProfScope ps(c, HAK_PROF_LOWPASS, st);
                 hak_launch_smooth_flow(st, fsrc, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
                                        c->state, o, 0.f);
             }
@@ -394,20 +424,26 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 for (int g = 0; g < G; g++) {
                     const int ns = hak_fed_group_size(n, G, g);
                     float* dst = ((G - g) % 2 == 1) ? Lt : tmp;
-                    ProfScope ps(c, HAK_PROF_FED);
+                    ProfScope ps(c, HAK_PROF_FED, st);
                     hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
                     c->fed_launches++;
                     done += ns;
                     src = dst;
                 }
+                if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
             }
-            { ProfScope ps(c, HAK_PROF_HESSIAN);                                  // akaze.cpp:423
+            { ProfScope ps(c, HAK_PROF_HESSIAN, st);                              // akaze.cpp:423
               if (!hak_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
                                             lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
                   hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
         }
         // akaze.cpp:431-433 hCalcExtremaMap: fused into the per-level Hessian kernel above
+        if (c->concurrent && o > 0) (void)hipEventRecord(c->ev_done[o], st);
     }
+    st = main_st;
+    if (c->concurrent)
+        for (int o = 1; o < L.noct; o++)
+            if (hipStreamWaitEvent(st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
       hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts); }
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131

@@ -82,6 +82,9 @@ void hak_destroy(hak_ctx* ctx);
 /* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own */
 int hak_set_stream(hak_ctx* ctx, void* hip_stream);
 int hak_sync(hak_ctx* ctx);
+/* 1 (default): octaves run on their own HIP streams (octave o+1 depends only on Lt(o,0), akaze.cpp:371-375);
+ * 0: one stream, strictly serial launches (used for per-kernel timing). Env HAK_SERIAL=1 presets 0. */
+int hak_set_concurrency(hak_ctx* ctx, int on);
 
 /* ---- Akazer::detectAndCompute (akaze.h:29, akaze.cpp:101-150), one image,
  * synchronous.  d_image: device float32, pitch elements per row.  d_points:
