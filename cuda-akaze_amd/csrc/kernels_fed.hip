@@ -28,8 +28,6 @@
 // borderAdd, akazed.cu:1251-1254) is applied at EVERY level (mirroring level-0 rows instead would
 // swap the S and N terms and change roundings).
 #include "hak_internal.h"
-#include <cstdlib>
-__device__ int g_fed_dbg;      // ablation mask (env HAK_DBG_FED; 0 in production): 1 no stores, 2 no loads, 4 no level math
 
 template <int NS>
 struct FedFacs { float f[NS]; };
@@ -92,7 +90,7 @@ template <int NS, int U, bool YEDGE>
 __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const float* __restrict__ L,
                                          const float* __restrict__ G, float* __restrict__ D, const int p, const int xl,
                                          const int x0, const int w, const int h,
-                                         const int ybeg, const int yend, const bool owns, const FedFacs<NS>& fac, const int dbg)
+                                         const int ybeg, const int yend, const bool owns, const FedFacs<NS>& fac)
 {
     constexpr int GS = FedState<NS>::GS;
     // ---- level 0: input row t arrives (prefetched); request row t+1 (clamped: rows past the image are never used)
@@ -103,10 +101,8 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
         // bytes in flight, not issue rate, bound this kernel (one row ahead = 2 KB per wave < latency x bandwidth):
         // keep PD rows of L and g outstanding per wave
         const long nrow = (long)min(t + PD, h - 1) * p + xl;
-        if (!(dbg & 2)) {
         S.Lq[pmod(U, PD)] = *reinterpret_cast<const float4*>(L + nrow);
         S.Gq[pmod(U, PD)] = *reinterpret_cast<const float4*>(G + nrow);
-        }
         const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
         GHrow gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
         gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                    // (g+gW) at x == 0 is (g+gE)
@@ -127,14 +123,14 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
 #pragma unroll
     for (int k = 1; k <= NS; k++) {
         const int rho = t - k;
-        const float4 out = (dbg & 4) ? S.Lw[k - 1][pmod(U - k, 3)] : fed_row<true>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
+        const float4 out = fed_row<true>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
                                           S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
                                           S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
         if (k < NS) {
             S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
-        } else if (rho >= ybeg && rho < yend && owns && !(dbg & 1)) {
+        } else if (rho >= ybeg && rho < yend && owns) {
             *reinterpret_cast<float4*>(D + (long)rho * p + x0) = out;
         }
     }
@@ -149,7 +145,6 @@ __device__ __forceinline__ void fed_strip(const float* __restrict__ L, const flo
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
     const int t0 = max(0, ybeg - NS);                       // first input row; level k is exact from row t0 + k (or 0)
     const int tend = min(yend - 1, h - 1) + NS;             // iteration that emits the strip's last output row
-    const int dbg = g_fed_dbg;
     FedState<NS> S;
 #pragma unroll
     for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -168,19 +163,19 @@ __device__ __forceinline__ void fed_strip(const float* __restrict__ L, const flo
     for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 3 / mod 6: static per unrolled body
         // the reflect injections can only fire while some level is at row 1 or row h
         if (tb <= NS || tb + 5 >= h) {
-            fed_iter<NS, 0, true>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 1, true>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 2, true>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 3, true>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 4, true>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 5, true>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
+            fed_iter<NS, 0, true>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, true>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, true>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, true>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, true>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, true>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         } else {
-            fed_iter<NS, 0, false>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 1, false>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 2, false>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 3, false>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 4, false>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
-            fed_iter<NS, 5, false>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac, dbg);
+            fed_iter<NS, 0, false>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, false>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, false>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, false>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, false>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, false>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         }
     }
 }
@@ -268,8 +263,6 @@ static void launch_multi(hipStream_t st, const float* src, const float* flow, fl
     // rows per wave: tall strips amortise the 2*NS warm-up rows; shrink while the grid cannot fill the chip
     int ry = 64;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
-    static int dbg_set = -1;
-    if (dbg_set < 0) { const char* e = getenv("HAK_DBG_FED"); dbg_set = e ? atoi(e) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fed_dbg), &dbg_set, sizeof(int)); }
     dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
     k_fed_multi<NS><<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx);
 }
