@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="one context: no overlap between consecutive steps")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
@@ -110,23 +111,52 @@ def main():
     d_imgs = torch.from_numpy(host).cuda()
     del host
 
-    det = ah.Akazer()
-    det.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg)
+    # two contexts, used alternately: while batch i runs on the GPU, batch i-1 is synchronised and downloaded
+    # (every step's work still completes inside the timed bracket)
+    NCTX = 1 if args.no_pipeline else 2
+    dets, d_pts_l, d_num_l, h_pts_l, h_num_l = [], [], [], [], []
     stream = torch.cuda.current_stream()
-    ah.check(ah.lib.hak_set_stream(det.ctx, C.c_void_p(stream.cuda_stream)))
-    if args.serial:
-        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0))
-    d_pts = torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda")
-    d_num = torch.zeros(nimg, dtype=torch.int32, device="cuda")
-    h_pts, h_num = C.c_void_p(), C.c_void_p()
-    ah.check(ah.lib.hak_host_alloc(C.byref(h_pts), nimg * max_pts * 104))
-    ah.check(ah.lib.hak_host_alloc(C.byref(h_num), nimg * 4))
+    for k in range(NCTX):
+        dk = ah.Akazer()
+        dk.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg)
+        if k == 0:
+            ah.check(ah.lib.hak_set_stream(dk.ctx, C.c_void_p(stream.cuda_stream)))
+        if args.serial:
+            ah.check(ah.lib.hak_set_concurrency(dk.ctx, 0))
+        dets.append(dk)
+        d_pts_l.append(torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda"))
+        d_num_l.append(torch.zeros(nimg, dtype=torch.int32, device="cuda"))
+        hp, hn = C.c_void_p(), C.c_void_p()
+        ah.check(ah.lib.hak_host_alloc(C.byref(hp), nimg * max_pts * 104))
+        ah.check(ah.lib.hak_host_alloc(C.byref(hn), nimg * 4))
+        h_pts_l.append(hp)
+        h_num_l.append(hn)
+    det, d_pts, d_num, h_pts, h_num = dets[0], d_pts_l[0], d_num_l[0], h_pts_l[0], h_num_l[0]
+
+    def enqueue(k):
+        ah.check(ah.lib.hak_detect_and_compute_batch(dets[k].ctx, d_imgs.data_ptr(), h * p, p, nimg,
+                                                     d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), B))
+
+    def download(k):
+        ah.check(ah.lib.hak_download_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), nimg,
+                                           h_pts_l[k], h_num_l[k]))
+
+    def run_steps(n):
+        """n steps = n batches through detect + describe + match + download"""
+        for i in range(n):
+            k = i % NCTX
+            enqueue(k)
+            if NCTX == 1:
+                download(k)
+            elif i > 0:
+                download(1 - k)
+        if NCTX == 2 and n > 0:
+            download((n - 1) % NCTX)
 
     def step():
-        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, d_imgs.data_ptr(), h * p, p, nimg,
-                                                     d_pts.data_ptr(), d_num.data_ptr(), 1))
-        ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B))
-        ah.check(ah.lib.hak_download_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), nimg, h_pts, h_num))
+        enqueue(0)
+        download(0)
 
     def fence():
         torch.cuda.synchronize()
@@ -134,12 +164,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    run_steps(args.warmup)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -207,15 +235,16 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
-                       "pairs_per_step_per_gpu": B, "octave_streams": "serial" if args.serial else "concurrent", "sharding": "independent pairs per rank, no data-path collective",
+                       "pairs_per_step_per_gpu": B, "octave_streams": "serial" if args.serial else "concurrent", "step_pipeline": NCTX, "sharding": "independent pairs per rank, no data-path collective",
                        "keypoints_per_image": round(summary[1] / (2.0 * summary[0]), 1),
                        "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    ah.lib.hak_host_free(h_pts)
-    ah.lib.hak_host_free(h_num)
-    det.close()
+    for k in range(NCTX):
+        ah.lib.hak_host_free(h_pts_l[k])
+        ah.lib.hak_host_free(h_num_l[k])
+        dets[k].close()
     if world > 1:
         dist.destroy_process_group()
 
