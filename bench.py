@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one context: no overlap between consecutive steps")
+    ap.add_argument("--pipeline", type=int, default=2, help="contexts used round-robin (batches in flight)")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
@@ -113,7 +114,7 @@ def main():
 
     # two contexts, used alternately: while batch i runs on the GPU, batch i-1 is synchronised and downloaded
     # (every step's work still completes inside the timed bracket)
-    NCTX = 1 if args.no_pipeline else 2
+    NCTX = 1 if args.no_pipeline else max(1, args.pipeline)
     dets, d_pts_l, d_num_l, h_pts_l, h_num_l = [], [], [], [], []
     stream = torch.cuda.current_stream()
     for k in range(NCTX):
@@ -145,14 +146,11 @@ def main():
     def run_steps(n):
         """n steps = n batches through detect + describe + match + download"""
         for i in range(n):
-            k = i % NCTX
-            enqueue(k)
-            if NCTX == 1:
-                download(k)
-            elif i > 0:
-                download(1 - k)
-        if NCTX == 2 and n > 0:
-            download((n - 1) % NCTX)
+            enqueue(i % NCTX)
+            if i >= NCTX - 1:
+                download((i - (NCTX - 1)) % NCTX)
+        for i in range(max(0, n - (NCTX - 1)), n):          # drain the batches still in flight
+            download(i % NCTX)
 
     def step():
         enqueue(0)

@@ -216,3 +216,50 @@ def test_match_10k_x_10k(ah, okz, torch, synth):
     # idempotence: matching again does not change anything
     again = gpu_match(ah, torch, got, train)
     assert again.tobytes() == got.tobytes()
+
+
+# ----------------------------------------------------------------- parameter space
+PARAM_CASES = [
+    dict(noctaves=2, max_scale=3),
+    dict(noctaves=3, max_scale=5),
+    dict(soffset=1.2),                      # base Gaussian radius 3 (ksz 7)
+    dict(soffset=2.0, derivative_factor=1.0),
+    dict(reordering=False),
+    dict(per=0.5, dthreshold=0.0005),
+    dict(diffusivity=0),                    # PM_G1   (deterministic exp shared with the oracle)
+    dict(diffusivity=2),                    # WEICKERT
+    dict(diffusivity=3),                    # CHARBONNIER
+    dict(descriptor_pattern_size=12),       # 24x24 sample grid: > 7 samples per lane (tail loop)
+    dict(descriptor_pattern_size=6),
+    dict(derivative_factor=2.5),            # sigma_size up to 6-7: dilation > 4 -> unfused derivative / extrema fallback
+]
+
+
+@pytest.mark.parametrize("kw", PARAM_CASES, ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()))
+def test_parameter_space_vs_oracle(ah, okz, torch, synth, kw):
+    w, h = 512, 384
+    u8 = _mg().case_scene(w, h, 31)
+    pts = gpu_detect(ah, torch, synth, u8, **kw)
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
+    assert len(r.points) > 10
+    assert_points_equal(pts, r.points)
+
+
+def test_serial_equals_concurrent_streams(ah, torch, synth):
+    w, h, mp = 640, 480, 4000
+    p = ah.iAlignUp(w, 128)
+    img = torch.from_numpy(synth.to_float(_mg().case_scene(w, h, 77), p)).cuda()
+    outs = []
+    for conc in (1, 0):
+        det = ah.Akazer()
+        det.init((w, h, p), max_pts=mp)
+        ah.check(ah.lib.hak_set_concurrency(det.ctx, conc))
+        data = ah.AkazeData()
+        ah.initAkazeData(data, mp, True, True)
+        for _ in range(3):                  # repeated calls reuse the streams / events
+            det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
+        outs.append(data.h_data[:data.num_pts].copy())
+        ah.freeAkazeData(data)
+        det.close()
+    assert len(outs[0]) > 50 and outs[0].tobytes() == outs[1].tobytes()
