@@ -81,6 +81,8 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="one context: no overlap between consecutive steps")
     ap.add_argument("--pipeline", type=int, default=2, help="contexts used round-robin (batches in flight)")
+    ap.add_argument("--upload", action="store_true",
+                    help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
@@ -173,6 +175,30 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- optional: PCIe-inclusive rate (never `value`): pinned uint8 batch -> H2D -> hak_ingest_u8 -> same steps
+    upload_rate = None
+    if args.upload:
+        h_u8 = torch.from_numpy(np.stack([u8_pairs[(i // 2) % 2][i % 2] for i in range(nimg)])).pin_memory()
+        d_u8 = torch.empty_like(h_u8, device="cuda")
+
+        def up_step(k):
+            d_u8.copy_(h_u8, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            ah.check(ah.lib.hak_ingest_u8(dets[k].ctx, d_u8.data_ptr(), h * w, w, d_imgs.data_ptr(), h * p, p, w, h, nimg))
+            enqueue(k)
+        for i in range(2):
+            up_step(i % NCTX); download(i % NCTX)
+        fence()
+        tu = time.perf_counter()
+        for i in range(args.steps):
+            up_step(i % NCTX)
+            if i >= NCTX - 1:
+                download((i - (NCTX - 1)) % NCTX)
+        for i in range(max(0, args.steps - (NCTX - 1)), args.steps):
+            download(i % NCTX)
+        fence()
+        upload_rate = world * B * args.steps / (time.perf_counter() - tu)
+
     counts = np.ctypeslib.as_array(C.cast(h_num, C.POINTER(C.c_int)), shape=(nimg,)).copy()
     pts = np.ctypeslib.as_array(C.cast(h_pts, C.POINTER(C.c_uint8)), shape=(nimg * max_pts * 104,)).view(ah.POINT_DTYPE).reshape(nimg, max_pts)
     nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(B)))
@@ -237,6 +263,7 @@ def main():
                        "keypoints_per_image": round(summary[1] / (2.0 * summary[0]), 1),
                        "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
             "roofline": roof, "cpu_baseline": cpu,
+            "upload_inclusive_pairs_per_s": None if upload_rate is None else round(upload_rate, 1),
         }
         print(json.dumps(out))
     for k in range(NCTX):

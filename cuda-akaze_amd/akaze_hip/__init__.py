@@ -82,6 +82,7 @@ SYMBOLS = {
     "hak_image_alloc": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _ip]),
     "hak_image_upload": (C.c_int, [_vp, C.c_int, _vp, C.c_int, C.c_int]),
     "hak_image_free": (C.c_int, [_vp]),
+    "hak_ingest_u8": (C.c_int, [_vp, _vp, C.c_long, C.c_int, _vp, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hak_host_alloc": (C.c_int, [C.POINTER(_vp), C.c_long]),
     "hak_host_free": (C.c_int, [_vp]),
     "hak_download_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp]),

@@ -528,6 +528,16 @@ extern "C" int hak_image_upload(float* d, int pitch, const float* hsrc, int w, i
     return 0;
 }
 extern "C" int hak_image_free(float* d) { HIP_TRY(hipFree(d)); return 0; }
+
+extern "C" int hak_ingest_u8(hak_ctx* c, const unsigned char* d_src, long src_stride, int src_pitch,
+                             float* d_dst, long dst_stride, int dst_pitch, int w, int h, int nimg)
+{
+    if (!d_src || !d_dst || w < 1 || h < 1 || nimg < 1 || src_pitch < w || dst_pitch < w) return fail("bad ingest argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    hak_launch_ingest_u8(c ? c->stream : nullptr, d_src, src_stride, src_pitch, d_dst, dst_stride, dst_pitch, w, h, nimg);
+    if (hipGetLastError() != hipSuccess) return fail("ingest launch failed");
+    return 0;
+}
 extern "C" int hak_host_alloc(void** p, long bytes) { HIP_TRY(hipHostMalloc(p, (size_t)bytes)); return 0; }
 extern "C" int hak_host_free(void* p) { HIP_TRY(hipHostFree(p)); return 0; }
 

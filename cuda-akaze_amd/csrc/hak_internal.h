@@ -196,6 +196,9 @@ void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly,
 void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
                         int w, int h, int p, int nimg, int step);
 
+void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, float* dst, long dst_stride,
+                          int dp, int w, int h, int nimg);
+
 // detector tail (kernels_detect.hip)
 void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
                               int s, float dthreshold);

@@ -437,3 +437,30 @@ void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float*
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
     k_hessian<<<grid, 256, 0, st>>>(lx, ly, det, stride, w, h, p, step, f1, f2);
 }
+
+// ------------------------------------------------------------------ ingest
+// uint8 -> float32 [0,1] as main.cpp:149: (float)(v * (1.0 / 255.0)); 4 pixels per thread
+__global__ __launch_bounds__(256) void k_ingest_u8(const unsigned char* __restrict__ src, long src_stride, int sp,
+                                                   float* __restrict__ dst, long dst_stride, int dp, int w, int h)
+{
+    const unsigned char* s = src + (long)blockIdx.z * src_stride;
+    float* d = dst + (long)blockIdx.z * dst_stride;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
+    if (x >= w) return;
+    const unsigned char* q = s + (long)y * sp + x;
+    float* o = d + (long)y * dp + x;
+    if (x + 3 < w && (sp & 3) == 0 && (dp & 3) == 0) {
+        const uchar4 v = *reinterpret_cast<const uchar4*>(q);
+        *reinterpret_cast<float4*>(o) = make_float4((float)(v.x * (1.0 / 255.0)), (float)(v.y * (1.0 / 255.0)),
+                                                    (float)(v.z * (1.0 / 255.0)), (float)(v.w * (1.0 / 255.0)));
+    } else {
+        for (int e = 0; e < 4 && x + e < w; e++) o[e] = (float)(q[e] * (1.0 / 255.0));
+    }
+}
+
+void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, float* dst, long dst_stride,
+                          int dp, int w, int h, int nimg)
+{
+    dim3 grid((w + 1023) / 1024, h, nimg);
+    k_ingest_u8<<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, dp, w, h);
+}

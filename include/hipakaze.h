@@ -118,6 +118,11 @@ int hak_points_free(hak_point* d_points);
 int hak_image_alloc(float** d_image, int w, int h, int* pitch);   /* pitch = iAlignUp(w,128), cuda_utils.h:160 */
 int hak_image_upload(float* d_image, int pitch, const float* h_image, int w, int h);
 int hak_image_free(float* d_image);
+/* uint8 -> float32 in [0,1] on the device, exactly main.cpp:149 (convertTo(CV_32FC1, 1.0/255.0)):
+ * dst = (float)(src * (1.0 / 255.0)).  nimg images, strides in elements; runs on the context's stream
+ * (ctx may be NULL = default stream).  Quarters the H2D traffic of the float upload at main.cpp:187-188. */
+int hak_ingest_u8(hak_ctx* ctx, const unsigned char* d_src, long src_stride, int src_pitch,
+                  float* d_dst, long dst_stride, int dst_pitch, int w, int h, int nimg);
 /* pinned host memory + the batched counterpart of the D2H copies at akaze.cpp:134-139 / 60-62:
  * counts first (one sync), then the first h_num_pts[i] records of every image, asynchronously,
  * then a final sync.  h_points is [nimg][max_pts]. */

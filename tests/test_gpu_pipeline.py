@@ -263,3 +263,17 @@ def test_serial_equals_concurrent_streams(ah, torch, synth):
         ah.freeAkazeData(data)
         det.close()
     assert len(outs[0]) > 50 and outs[0].tobytes() == outs[1].tobytes()
+
+
+def test_ingest_u8_matches_host_conversion(ah, torch, synth):
+    """on-device uint8 -> float32 equals main.cpp:149's host conversion bit for bit"""
+    for (w, h, sp, dp) in ((640, 33, 640, 640), (211, 17, 211, 256), (1920, 8, 2048, 1920)):
+        rng = np.random.default_rng(w)
+        u8 = rng.integers(0, 256, size=(3, h, sp), dtype=np.uint8)
+        d_src = torch.from_numpy(u8).cuda()
+        d_dst = torch.zeros((3, h, dp), dtype=torch.float32, device="cuda")
+        ah.check(ah.lib.hak_ingest_u8(None, d_src.data_ptr(), h * sp, sp, d_dst.data_ptr(), h * dp, dp, w, h, 3))
+        torch.cuda.synchronize()
+        got = d_dst.cpu().numpy()[:, :, :w]
+        want = np.stack([synth.to_float(u8[i, :, :w]) for i in range(3)])
+        assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
