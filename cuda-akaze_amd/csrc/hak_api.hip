@@ -704,6 +704,16 @@ extern "C" int hak_op_flow(const float* s, float* d, int w, int h, int p, int di
     return 0;
 }
 
+extern "C" int hak_op_smooth_flow(const float* s, float* sm, float* fl, int w, int h, int p, int diffusivity, float kcontrast)
+{
+    float taps[8];
+    hak_gauss_taps(1.f, 2, taps);
+    const float ikc = 1.f / (kcontrast * kcontrast);                              // akazed.cu:2493
+    hak_launch_smooth_flow(nullptr, s, sm, fl, 0, w, h, p, 1, taps, diffusivity, nullptr, 0, ikc);
+    HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
 extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst, float* tmp, int w, int h, int p,
                                 const float* tau, int nsteps)
 {

@@ -170,8 +170,6 @@ void hak_launch_contrast(hipStream_t st, const float* smooth, long stride, int w
 void hak_launch_reset_state(hipStream_t st, HakImgState* state, int nimg);
 void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, int w, int h, int p, int nimg,
                      int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
-void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
-                         int w, int h, int p, int nimg, float stepfac);
 // derivate + determinant of one level, with the level's extrema search fused in when b != nullptr
 // (kernels_hessian.hip); returns false when the caller still has to run hak_launch_extrema_level
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,

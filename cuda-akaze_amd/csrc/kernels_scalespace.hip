@@ -5,7 +5,7 @@
 //   hDownWithSmooth                akazed.cu:2389, 449   -> k_down_smooth
 //   hScharrContrast                akazed.cu:2410, 644, 827, 901 -> k_grad_max, k_grad_hist, k_kcontrast
 //   hFlow/gFlowNaive               akazed.cu:2487, 1068  -> k_flow
-//   hNldStep/gNldStepNaive         akazed.cu:2509, 1241  -> k_fed_step      (the FED hot loop)
+//   hNldStep/gNldStepNaive         akazed.cu:2509, 1241  -> kernels_fed.hip (the FED hot loop)
 //   hHessianDeterminant            akazed.cu:2531, 1267, 1299 -> k_derivate, k_hessian
 //
 // All kernels take the batch image in blockIdx.z.  Float evaluation order is
@@ -272,96 +272,6 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
 {
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
     k_flow<<<grid, 256, 0, st>>>(src, dst, stride, w, h, p, diffusivity, state, octave, fixed_ikc);
-}
-
-// ----------------------------------------------------------------- FED step
-// One explicit diffusion step  L' = fma(0.5*tau, sum_{E,W,S,N} (g+g_n)(L_n-L), L)
-// (akazed.cu:1259-1263).  HBM-bound: 12 B/px (read L, read g, write L').
-//
-// Mapping: a wave owns a 256-px-wide column strip (one float4 per lane =
-// 1 KiB contiguous per row) and walks RY rows with a 3-row register window,
-// so each row of L and g is loaded once per wave (+2 halo rows per strip);
-// east/west neighbours come from the adjacent lane by DPP/shuffle, and only
-// lanes 0/63 fetch their out-of-strip neighbour from memory.
-__device__ __forceinline__ float4 ld4(const float* __restrict__ base, long off)
-{
-    return *reinterpret_cast<const float4*>(base + off);
-}
-
-__device__ __forceinline__ float fed_px(float L, float g, float LE, float gE, float LW, float gW,
-                                        float LS, float gS, float LN, float gN, float stepfac)
-{
-    float step = (g + gE) * (LE - L) + (g + gW) * (LW - L) + (g + gS) * (LS - L) + (g + gN) * (LN - L);
-    return fmaf(stepfac, step, L);
-}
-
-__global__ __launch_bounds__(256) void k_fed_step(const float* __restrict__ src, const float* __restrict__ flow,
-                                                  float* __restrict__ dst, long stride, int w, int h, int p,
-                                                  float stepfac, int ry)
-{
-    const float* L = src + (long)blockIdx.z * stride;
-    const float* G = flow + (long)blockIdx.z * stride;
-    float* D = dst + (long)blockIdx.z * stride;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int x0 = (blockIdx.x * 64 + lane) * 4;
-    const int ybeg = (blockIdx.y * 4 + wv) * ry;
-    if (ybeg >= h) return;                                  // wave-uniform
-    const int yend = min(ybeg + ry, h);
-    const bool act = x0 < w;
-    const int xl = act ? x0 : 0;                            // keep every lane's loads in bounds
-    const bool need_l = lane == 0 && x0 > 0;
-    const bool need_r = lane == 63 && x0 + 4 < w;
-
-    int yp = ybeg - 1 < 0 ? 1 - ybeg : ybeg - 1;            // reflect-101 (abs)
-    int yn = ybeg + 1 < h ? ybeg + 1 : h + h - 3 - ybeg;    // borderAdd(y,1,h)
-    float4 Lp = ld4(L, (long)yp * p + xl), Gp = ld4(G, (long)yp * p + xl);
-    float4 Lc = ld4(L, (long)ybeg * p + xl), Gc = ld4(G, (long)ybeg * p + xl);
-    float4 Ln = ld4(L, (long)yn * p + xl), Gn = ld4(G, (long)yn * p + xl);
-
-    for (int y = ybeg; y < yend; y++) {
-        // prefetch the row after next while this one is computed
-        int y2 = y + 2 < h ? y + 2 : h + h - 4 - y;         // borderAdd(y+1,1,h)
-        y2 = y2 < 0 ? 0 : y2;
-        float4 Lf = Ln, Gf = Gn;
-        if (y + 1 < yend) { Lf = ld4(L, (long)y2 * p + xl); Gf = ld4(G, (long)y2 * p + xl); }
-
-        float Lw = __shfl_up(Lc.w, 1), Gw = __shfl_up(Gc.w, 1);
-        float Le = __shfl_down(Lc.x, 1), Ge = __shfl_down(Gc.x, 1);
-        if (need_l) { Lw = L[(long)y * p + x0 - 1]; Gw = G[(long)y * p + x0 - 1]; }
-        if (need_r) { Le = L[(long)y * p + x0 + 4]; Ge = G[(long)y * p + x0 + 4]; }
-
-        float l[6] = {Lw, Lc.x, Lc.y, Lc.z, Lc.w, Le};
-        float g[6] = {Gw, Gc.x, Gc.y, Gc.z, Gc.w, Ge};
-        float ln[4] = {Lp.x, Lp.y, Lp.z, Lp.w}, gn[4] = {Gp.x, Gp.y, Gp.z, Gp.w};
-        float ls[4] = {Ln.x, Ln.y, Ln.z, Ln.w}, gs[4] = {Gn.x, Gn.y, Gn.z, Gn.w};
-        float o[4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) {
-            int x = x0 + e;
-            float LW = l[e], GW = g[e], LE = l[e + 2], GE = g[e + 2];
-            if (x == 0) { LW = LE; GW = GE; }               // abs(x-1) = 1
-            if (x == w - 1) { LE = l[e]; GE = g[e]; }        // borderAdd(x,1,w) = w-2
-            o[e] = fed_px(l[e + 1], g[e + 1], LE, GE, LW, GW, ls[e], gs[e], ln[e], gn[e], stepfac);
-        }
-        if (act) {
-            float* drow = D + (long)y * p + x0;
-            if (x0 + 3 < w) *reinterpret_cast<float4*>(drow) = make_float4(o[0], o[1], o[2], o[3]);
-            else
-                for (int e = 0; e < 4 && x0 + e < w; e++) drow[e] = o[e];
-        }
-        Lp = Lc; Gp = Gc; Lc = Ln; Gc = Gn; Ln = Lf; Gn = Gf;
-    }
-}
-
-void hak_launch_fed_step(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
-                         int w, int h, int p, int nimg, float stepfac)
-{
-    int gx = (w + 255) / 256;
-    // rows per wave: deep strips when the batch already fills the chip, shallow otherwise
-    int ry = 8;
-    while (ry > 2 && (long)gx * ((h + 4 * ry - 1) / (4 * ry)) * nimg < 2048) ry >>= 1;
-    dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
-    k_fed_step<<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, stepfac, ry);
 }
 
 // ------------------------------------------------- derivatives + determinant

@@ -179,6 +179,8 @@ int hak_op_kcontrast(const float* d_smooth, int w, int h, int p, float per, floa
 int hak_op_flow(const float* d_src, float* d_dst, int w, int h, int p, int diffusivity, float kcontrast); /* hFlow 2487 */
 int hak_op_nld_steps(const float* d_src, const float* d_flow, float* d_dst, float* d_tmp,
                      int w, int h, int p, const float* tau, int nsteps);                                  /* hNldStep 2509, n steps */
+int hak_op_smooth_flow(const float* d_src, float* d_smooth, float* d_flow, int w, int h, int p,
+                       int diffusivity, float kcontrast);                                               /* hLowPass(var 1) + hFlow, akaze.cpp:403-404 */
 int hak_op_hessian(const float* d_src, float* d_lx, float* d_ly, float* d_det, int w, int h, int p, int step); /* hHessianDeterminant 2531 */
 
 #ifdef __cplusplus

@@ -110,3 +110,17 @@ def test_hessian(ah, okz, torch, w, h, step):
                                    w, h, p, step))
     lx, ly, det = okz.hessian(a, w, step)
     assert eq(outs[0], lx, w) and eq(outs[1], ly, w) and eq(outs[2], det, w)
+
+
+@pytest.mark.parametrize("w,h", SIZES + [(64, 32), (65, 33), (1000, 70)])
+@pytest.mark.parametrize("diff", [0, 1, 2, 3])
+def test_smooth_flow_fused(ah, okz, torch, w, h, diff):
+    """the fused sigma=1 low-pass + conductivity product kernel == oracle lowpass followed by oracle flow"""
+    rng = np.random.default_rng(w + 5)
+    a, p = plane(rng, w, h)
+    d_a = dev(torch, a)
+    d_sm = torch.zeros((h, p), dtype=torch.float32, device="cuda")
+    d_g = torch.zeros((h, p), dtype=torch.float32, device="cuda")
+    ah.check(ah.lib.hak_op_smooth_flow(d_a.data_ptr(), d_sm.data_ptr(), d_g.data_ptr(), w, h, p, diff, 0.41))
+    sm = okz.lowpass(a, w, 1.0, 2)
+    assert eq(d_sm, sm, w) and eq(d_g, okz.flow(sm, w, diff, 0.41), w)
