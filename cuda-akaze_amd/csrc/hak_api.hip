@@ -156,6 +156,13 @@ struct hak_ctx {
     hipStream_t oct_stream[HAK_MAX_OCTAVES] = {};      // [0] unused (= stream)
     hipEvent_t ev_ready[HAK_MAX_OCTAVES] = {}, ev_done[HAK_MAX_OCTAVES] = {};
     bool concurrent = true;
+    // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
+    bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
+    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int conc; hipStream_t st; };
+    static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
+    hipGraphExec_t graph_exec[NGRAPH] = {};
+    GraphKey gkey[NGRAPH] = {};
+    unsigned long graph_age[NGRAPH] = {}, graph_clock = 0;
     bool prof_on = false;
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
@@ -307,6 +314,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming);
     }
     if (const char* s = getenv("HAK_SERIAL")) c->concurrent = atoi(s) == 0;
+    if (const char* s = getenv("HAK_GRAPH")) c->use_graph = atoi(s) != 0;
     if (e != hipSuccess) {
         fail(std::string("hak_create: ") + hipGetErrorString(e));
         hak_destroy(c);
@@ -321,6 +329,7 @@ extern "C" void hak_destroy(hak_ctx* c)
 {
     if (!c) return;
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (int o = 0; o < HAK_MAX_OCTAVES; o++) {
         if (c->oct_stream[o]) { (void)hipStreamSynchronize(c->oct_stream[o]); (void)hipStreamDestroy(c->oct_stream[o]); }
         if (c->ev_ready[o]) (void)hipEventDestroy(c->ev_ready[o]);
@@ -452,13 +461,54 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     return 0;
 }
 
+// enqueue one detect+describe sequence: replay the captured graph when the arguments repeat, else capture it
+static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
+                      hak_point* d_points, int* d_num_pts, int desc)
+{
+    if (!c->use_graph || c->prof_on)
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    hak_ctx::GraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.img = d_images; key.stride = image_stride; key.pitch = pitch; key.nimg = nimg; key.pts = d_points;
+    key.num = d_num_pts; key.desc = desc; key.conc = c->concurrent ? 1 : 0; key.st = c->stream;
+    int slot = -1, victim = 0;
+    for (int i = 0; i < hak_ctx::NGRAPH; i++) {
+        if (c->graph_exec[i] && memcmp(&key, &c->gkey[i], sizeof(key)) == 0) slot = i;
+        if (c->graph_age[i] < c->graph_age[victim]) victim = i;
+    }
+    if (slot >= 0) {
+        c->graph_age[slot] = ++c->graph_clock;
+        if (hipGraphLaunch(c->graph_exec[slot], c->stream) != hipSuccess) return fail("hipGraphLaunch");
+        return 0;
+    }
+    slot = victim;                                              // least recently used (or empty) slot
+    if (c->graph_exec[slot]) { (void)hipGraphExecDestroy(c->graph_exec[slot]); c->graph_exec[slot] = nullptr; }
+    hipGraph_t graph = nullptr;
+    if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+        (void)hipGetLastError();
+        c->use_graph = false;                                   // e.g. legacy default stream: fall back to eager launches
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    }
+    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    const hipError_t e = hipStreamEndCapture(c->stream, &graph);
+    if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+    const hipError_t ei = hipGraphInstantiate(&c->graph_exec[slot], graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { c->graph_exec[slot] = nullptr; return fail(std::string("hipGraphInstantiate: ") + hipGetErrorString(ei)); }
+    c->gkey[slot] = key;
+    c->graph_age[slot] = ++c->graph_clock;
+    if (hipGraphLaunch(c->graph_exec[slot], c->stream) != hipSuccess) return fail("hipGraphLaunch");
+    return 0;
+}
+
 extern "C" int hak_detect_and_compute_batch(hak_ctx* c, const float* d_images, long image_stride, int pitch,
                                             int nimg, hak_point* d_points, int* d_num_pts, int desc)
 {
     if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
     if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    return run_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
 }
 
 extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitch, hak_point* d_points, int max_pts,
@@ -467,7 +517,7 @@ extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitc
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
     if (max_pts < c->cfg.max_pts) return fail("point array smaller than cfg.max_pts");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    if (enqueue_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
+    if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
     HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *num_pts = c->h_num[0];
