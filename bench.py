@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=16, help="pairs per GPU per step (batch)")
+    ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step (batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--octaves", type=int, default=4)
@@ -237,8 +237,9 @@ def main():
         # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when not measured
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and (w, h, args.octaves, B) == (1920, 1080, 4, 16):
-            traffic = round(json.load(open(tfile))["fed_hbm_bytes_per_launch"])
+        if os.path.exists(tfile) and (w, h, args.octaves) == (1920, 1080, 4):
+            # measured at 16 pairs per launch sequence; every FED launch covers the whole batch, so bytes scale with B
+            traffic = round(json.load(open(tfile))["fed_hbm_bytes_per_launch"] * B / 16.0)
         roof = {"kernel": "k_fed_multi<NS> (fused FED steps, 12 B/px/step algorithmic)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

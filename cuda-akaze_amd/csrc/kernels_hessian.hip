@@ -80,7 +80,7 @@ struct HakExtremaArgs {
 template <int S, bool INTERIOR>
 __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ od,
                                              int w, int h, int p, int x0, int y0, float fac1, float fac2,
-                                             float* sm, float* sx, float* sy, int lane, int wv,
+                                             float* __restrict__ sm, float* __restrict__ sx, float* __restrict__ sy, int lane, int wv,
                                              const HakExtremaArgs& ex, int img)
 {
     using G = HessGeo<S>;
