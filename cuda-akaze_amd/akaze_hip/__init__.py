@@ -75,6 +75,8 @@ SYMBOLS = {
     "hak_set_concurrency": (C.c_int, [_vp, C.c_int]),
     "hak_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
     "hak_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
+    "hak_fast_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
+    "hak_fast_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "hak_match": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "hak_match_batch": (C.c_int, [_vp, _vp, _vp, C.c_int]),
     "hak_points_alloc": (C.c_int, [C.POINTER(_vp), C.c_int]),
@@ -241,8 +243,16 @@ class Akazer:
         result.num_pts = n.value
 
     def fastDetectAndCompute(self, image, result, whp0, desc=True):
-        """akaze.h:30 -- integer FAST path: out of scope this round."""
-        raise HakError("fastDetectAndCompute (16.16 fixed-point path) is not implemented")
+        """akaze.h:30, akaze.cpp:153-201 -- integer FAST path.  ``image`` = device pointer to uint8, pitch whp0[2] bytes."""
+        w, h, p = whp0
+        if self._ctx is None or self._ctx_wh != (w, h):
+            self._make_ctx(w, h)
+        if result.max_pts < self._cfg.max_pts:
+            raise HakError("AkazeData smaller than the detector's max_pts")
+        n = C.c_int(0)
+        hptr = result.h_data.ctypes.data if result.h_data is not None else None
+        check(lib.hak_fast_detect_and_compute(self.ctx, image, p, result.d_data, result.max_pts, C.byref(n), hptr, int(desc)))
+        result.num_pts = n.value
 
     # -- introspection used by tests
     def plane(self, kind, octave, sublevel, img=0):

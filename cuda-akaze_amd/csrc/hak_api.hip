@@ -139,6 +139,7 @@ struct hak_ctx {
     HakTables* dtab = nullptr;
     std::vector<LevelPlan> plan;    // [noct*ms]
     float taps1[8], taps_base[8];
+    int itaps1[8], itaps_base[8];       // FAST path: (int)(tap * 65536 + 0.5f)   akazed.cu:3896
     int base_R = 4;
     int psz = 28;
     float* arena = nullptr;
@@ -273,6 +274,10 @@ static int build_plan(hak_ctx* c, int w, int h)
     c->base_R = ksz <= 5 ? 2 : ksz <= 7 ? 3 : ksz <= 9 ? 4 : 5;                   // akazed.cu:2345-2377
     if (ksz > 11) return fail("Kernels larger than 11 not implemented");
     hak_gauss_taps(cfg.soffset * cfg.soffset, c->base_R, c->taps_base);
+    for (int i = 0; i < 8; i++) {
+        c->itaps1[i] = i <= 2 ? (int)(c->taps1[i] * 65536 + 0.5f) : 0;
+        c->itaps_base[i] = i <= c->base_R ? (int)(c->taps_base[i] * 65536 + 0.5f) : 0;
+    }
     return 0;
 }
 
@@ -458,6 +463,87 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
       hak_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    return 0;
+}
+
+// ------------------------------------------------------- integer FAST path
+// Akazer::fastDetectAndCompute / fastDetect (akaze.cpp:153-201, 506-743): same orchestration on int32 planes.
+static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long image_stride, int pitch, int nimg,
+                               hak_point* d_points, int* d_num_pts, int desc)
+{
+    const hak_config& cfg = c->cfg;
+    const HakLayout& L = c->L;
+    hipStream_t st = c->stream;
+    int* A = reinterpret_cast<int*>(c->arena);
+    const long S = L.arena;
+    HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
+    const int idthreshold = 65;                                                   // akaze.cpp:559
+    hakf_launch_reset(st, c->state, nimg);
+    if (hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * nimg, st) != hipSuccess)
+        return fail("memset maps");
+    for (int o = 0; o < L.noct; o++) {
+        const HakOct oc = L.oct[o];
+        int* smooth = A + L.smooth_off[o];
+        int* flow = A + L.flow_off[o];
+        int* tmp = A + L.tmp_off[o];
+        for (int s = 0; s < L.ms; s++) {
+            const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
+            int* Lt = A + L.lt(o, s);
+            if (o == 0 && s == 0) {                                               // akaze.cpp:589-623
+                hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
+                hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
+                hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
+                hakf_launch_hessian(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+                continue;
+            }
+            const int n = lp.nsteps;
+            const int* src;
+            if (s == 0) {                                                         // akaze.cpp:640-662
+                int* first = (n % 2 == 0) ? Lt : tmp;
+                hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
+                src = first;
+            } else {                                                              // akaze.cpp:664-695
+                hakf_launch_conv_int(st, A + L.lt(o, s - 1), smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
+                src = A + L.lt(o, s - 1);
+            }
+            hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
+            for (int k = 0; k < n; k++) {                                         // ping-pong, last step lands in Lt
+                int* dst = ((n - k) % 2 == 1) ? Lt : tmp;
+                hakf_launch_nld_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau[k]);
+                src = dst;
+            }
+            hakf_launch_hessian(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+            hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+        }
+    }
+    hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts, 1);
+    hakf_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc);
+    if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    return 0;
+}
+
+extern "C" int hak_fast_detect_and_compute_batch(hak_ctx* c, const unsigned char* d_images, long image_stride, int pitch,
+                                                 int nimg, hak_point* d_points, int* d_num_pts, int desc)
+{
+    if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
+    if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
+    if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    return enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+}
+
+extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_image, int pitch, hak_point* d_points, int max_pts,
+                                           int* num_pts, hak_point* h_points, int desc)
+{
+    if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
+    if (max_pts < c->cfg.max_pts) return fail("point array smaller than cfg.max_pts");
+    if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    if (enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
+    HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    *num_pts = c->h_num[0];
+    if (h_points && *num_pts > 0)
+        HIP_TRY(hipMemcpy(h_points, d_points, sizeof(hak_point) * (size_t)*num_pts, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -35,6 +35,8 @@ struct HakImgState {
     int hist[HAK_NBINS];
     float kcontrast[HAK_MAX_OCTAVES];           // per octave: k0, k0*0.75, ...
     float ikc[HAK_MAX_OCTAVES];                 // 1/(k*k)
+    int ihmax;                                  // FAST path: max integer gradient magnitude (floored at 1)
+    int ikcontrast[HAK_MAX_OCTAVES];            // FAST path: integer contrast factor per octave
     int ncand;                                  // entries in the image's extrema candidate list
     int total_pts;                              // NMS survivors before clamping to max_pts
     int num_pts;                                // min(total, max_pts)
@@ -201,7 +203,24 @@ void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_str
 void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
                               int s, float dthreshold);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
-                         hak_point* points, int max_pts, int* num_out);
+                         hak_point* points, int max_pts, int* num_out, int fast = 0);
+
+// integer FAST path (kernels_fast.hip); planes are int32 in the same arena layout
+void hakf_launch_reset(hipStream_t st, HakImgState* state, int nimg);
+void hakf_launch_conv_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, int* dst, long dst_stride,
+                         int w, int h, int p, int nimg, const int* taps, int R);
+void hakf_launch_conv_int(hipStream_t st, const int* src, int* dst, long stride, int w, int h, int p, int nimg, const int* taps, int R);
+void hakf_launch_down_smooth(hipStream_t st, const int* src, int* dst, int* smooth, long stride, HakOct so, HakOct dd, int nimg,
+                             const int* taps);
+void hakf_launch_contrast(hipStream_t st, const int* smooth, long stride, int w, int h, int p, int nimg, HakImgState* state,
+                          float per, int noct);
+void hakf_launch_flow(hipStream_t st, const int* src, int* dst, long stride, int w, int h, int p, int nimg, int type,
+                      const HakImgState* state, int octave);
+void hakf_launch_nld_step(hipStream_t st, const int* src, const int* flow, int* dst, long stride, int w, int h, int p, int nimg, float tau);
+void hakf_launch_hessian(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride, int w, int h, int p, int nimg, int step);
+void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold);
+void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
+                          int patsize, int upright, int desc);
 
 // descriptors (kernels_describe.hip)
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,

@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __re
         if (!(x >= psz && x + psz < w && y >= psz && y + psz < h)) continue;
         const unsigned long long kc = map[(long)y * p + x];
         if (key_layer(kc) != layer) continue;                       // another level won this pixel
-        const float rc = key_resp(kc);
+        const unsigned rc = (unsigned)(kc >> 32);           // response word: unsigned order == order of positive floats / ints
         const float fsz = tab->sizes[layer];
         const int isz = (int)(fsz + 0.5f);
         const int sqsz = (int)(fsz * fsz);
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __re
         for (int di = -isz; di <= isz && !to_nms; di++)
             for (int dj = -isz; dj <= isz; dj++) {
                 if ((di == 0 && dj == 0) || di * di + dj * dj >= sqsz) continue;
-                float rn = key_resp(map[(long)(y + di) * p + (x + dj)]);
+                const unsigned rn = (unsigned)(map[(long)(y + di) * p + (x + dj)] >> 32);
                 if (rn > rc || (rn == rc && di <= 0 && dj <= 0)) to_nms = true;
             }
         if (!to_nms) {
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
                                               const unsigned long long* __restrict__ maps, long map_stride,
                                               HakLayout L, const HakTables* __restrict__ tab,
                                               const unsigned long long* __restrict__ bitmap, int words_per_row,
-                                              const int* __restrict__ rowstart, hak_point* points, int max_pts)
+                                              const int* __restrict__ rowstart, hak_point* points, int max_pts, int fast)
 {
     const int img = blockIdx.z;
     const int h = L.oct[0].h, p0 = L.oct[0].p;
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
                 float dst0 = idd * (dxy * dy - dyy * dx);
                 float dst1 = idd * (dxy * dx - dxx * dy);
                 bool weak = dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f;
-                if (!weak) {
+                if (!weak && !fast) {                               // FAST path refines on its int planes (kernels_fast.hip)
                     int ratio = 1 << o;
                     py = ratio * (yy + dst1);
                     px = ratio * (xx + dst0);
@@ -188,7 +188,10 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
                 pt->x = px;
                 pt->y = py;
                 pt->octave = layer;
-                pt->response = key_resp(k);                         // D8
+                pt->response = fast ? (float)(int)(k >> 32) : key_resp(k);   // D8
+                unsigned int* f32 = reinterpret_cast<unsigned int*>(pt->features);
+#pragma unroll
+                for (int q = 0; q < 16; q++) f32[q] = 0u;           // features + padding (written again by the describe kernel)
                 pt->size = tab->sizes[layer];
                 pt->angle = 0.f;
                 pt->match = -1;
@@ -212,7 +215,7 @@ void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout
 }
 
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
-                         hak_point* points, int max_pts, int* num_out)
+                         hak_point* points, int max_pts, int* num_out, int fast)
 {
     const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
     const int words = (w + 63) / 64;
@@ -223,5 +226,5 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
                                    b.bitmap, words, b.rowcount);
     k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
     dim3 g3((h + 3) / 4, 1, b.nimg);
-    k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts);
+    k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
 }

@@ -1,0 +1,487 @@
+// kernels_fast.hip -- the reference's integer "FAST" pipeline (namespace fastakaze, akazed.cu:2781-4367):
+// the float scale space / detector / descriptor in int32 with 16.16 fixed-point weights on uint8 input.
+//
+// Straightforward kernels (tile or direct-load), batch image in blockIdx.z; this path is a "next" scope
+// row: bit-exact first, not yet tuned like the float path.  32-bit products wrap
+// (two's complement) exactly as in the oracle (akaze_oracle_fast.c, F1).
+#include "hak_internal.h"
+
+#define FT_X 64
+#define FT_Y 16
+struct FkTaps { int k[8]; };
+
+__device__ __forceinline__ int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+__device__ __forceinline__ int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+
+// ---- separable Gaussian, T = unsigned char (akazed.cu:2990 gConv2d<R>, 2786 gConv2dR2) or int (2922)
+template <typename T, int R>
+__global__ __launch_bounds__(256) void kf_conv(const T* __restrict__ src, long src_stride, int sp, int* __restrict__ dst,
+                                               long dst_stride, int w, int h, int p, FkTaps t)
+{
+    constexpr int RW = FT_X + 2 * R, RH = FT_Y + 2 * R;
+    __shared__ int raw[RH][RW + 1];
+    __shared__ int rowp[RH][FT_X];
+    const T* s = src + (long)blockIdx.z * src_stride;
+    int* d = dst + (long)blockIdx.z * dst_stride;
+    const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y, tid = threadIdx.x;
+    for (int i = tid; i < RH * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        raw[r][c] = (int)s[(long)hak_refl(y0 - R + r, h) * sp + hak_refl(x0 - R + c, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * FT_X; i += 256) {
+        int r = i >> 6, c = i & 63;
+        int ws = wmul(t.k[0], raw[r][c + R]);
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws = wadd(ws, wmul(t.k[k], raw[r][c + R - k] + raw[r][c + R + k]));
+        rowp[r][c] = ws >> 16;
+    }
+    __syncthreads();
+    const int c = tid & 63, x = x0 + c;
+    if (x >= w) return;
+    for (int rr = tid >> 6; rr < FT_Y; rr += 4) {
+        int y = y0 + rr;
+        if (y >= h) break;
+        int ws = wmul(t.k[0], rowp[rr + R][c]);
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws = wadd(ws, wmul(t.k[k], rowp[rr + R - k][c] + rowp[rr + R + k][c]));
+        d[(long)y * p + x] = ws >> 16;
+    }
+}
+
+template <typename T>
+static void launch_conv(hipStream_t st, const T* src, long src_stride, int sp, int* dst, long dst_stride, int w, int h, int p,
+                        int nimg, const int* taps, int R)
+{
+    FkTaps t;
+    for (int i = 0; i < 8; i++) t.k[i] = i <= R ? taps[i] : 0;
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    switch (R) {
+    case 2: kf_conv<T, 2><<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, w, h, p, t); break;
+    case 3: kf_conv<T, 3><<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, w, h, p, t); break;
+    case 4: kf_conv<T, 4><<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, w, h, p, t); break;
+    default: kf_conv<T, 5><<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, w, h, p, t); break;
+    }
+}
+void hakf_launch_conv_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, int* dst, long dst_stride,
+                         int w, int h, int p, int nimg, const int* taps, int R)
+{ launch_conv<unsigned char>(st, src, src_stride, sp, dst, dst_stride, w, h, p, nimg, taps, R); }
+void hakf_launch_conv_int(hipStream_t st, const int* src, int* dst, long stride, int w, int h, int p, int nimg, const int* taps, int R)
+{ launch_conv<int>(st, src, stride, p, dst, stride, w, h, p, nimg, taps, R); }
+
+// ---- akazed.cu:3143 fastakaze::gDownWithSmooth
+__global__ __launch_bounds__(256) void kf_down_smooth(const int* __restrict__ src, int* __restrict__ dst, int* __restrict__ smooth,
+                                                      long stride, HakOct so, HakOct dd, FkTaps t)
+{
+    constexpr int RW = FT_X + 4, RH = FT_Y + 4;
+    __shared__ int dec[RH][RW + 1];
+    __shared__ int rowp[RH][FT_X];
+    const int* s = src + (long)blockIdx.z * stride;
+    int* d = dst + (long)blockIdx.z * stride;
+    int* sm = smooth + (long)blockIdx.z * stride;
+    const int x0 = blockIdx.x * FT_X, y0 = blockIdx.y * FT_Y, tid = threadIdx.x;
+    for (int i = tid; i < RH * RW; i += 256) {
+        int r = i / RW, c = i - r * RW;
+        dec[r][c] = s[(long)hak_refl(2 * (y0 - 2 + r), so.h) * so.p + hak_refl(2 * (x0 - 2 + c), so.w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * FT_X; i += 256) {
+        int r = i >> 6, c = i & 63;
+        rowp[r][c] = wadd(wadd(wmul(t.k[0], dec[r][c + 2]), wmul(t.k[1], dec[r][c + 1] + dec[r][c + 3])),
+                          wmul(t.k[2], dec[r][c] + dec[r][c + 4])) >> 16;
+    }
+    __syncthreads();
+    const int c = tid & 63, x = x0 + c;
+    if (x >= dd.w) return;
+    for (int rr = tid >> 6; rr < FT_Y; rr += 4) {
+        int y = y0 + rr;
+        if (y >= dd.h) break;
+        long o = (long)y * dd.p + x;
+        d[o] = dec[rr + 2][c + 2];
+        sm[o] = wadd(wadd(wmul(t.k[0], rowp[rr + 2][c]), wmul(t.k[1], rowp[rr + 1][c] + rowp[rr + 3][c])),
+                     wmul(t.k[2], rowp[rr][c] + rowp[rr + 4][c])) >> 16;
+    }
+}
+void hakf_launch_down_smooth(hipStream_t st, const int* src, int* dst, int* smooth, long stride, HakOct so, HakOct dd, int nimg,
+                             const int* taps)
+{
+    FkTaps t;
+    for (int i = 0; i < 8; i++) t.k[i] = i <= 2 ? taps[i] : 0;
+    dim3 grid((dd.w + FT_X - 1) / FT_X, (dd.h + FT_Y - 1) / FT_Y, nimg);
+    kf_down_smooth<<<grid, 256, 0, st>>>(src, dst, smooth, stride, so, dd, t);
+}
+
+// ---- Scharr (akazed.cu:3208-3232, 3406-3428)
+__device__ __forceinline__ void fscharr(const int* __restrict__ s, int x, int y, int w, int h, int p, int& dx, int& dy)
+{
+    const int x0 = x - 1 < 0 ? 1 - x : x - 1, x2 = x + 1 < w ? x + 1 : w + w - 3 - x;
+    const int y0 = y - 1 < 0 ? 1 - y : y - 1, y2 = y + 1 < h ? y + 1 : h + h - 3 - y;
+    const int* r0 = s + (long)y0 * p;
+    const int* r1 = s + (long)y * p;
+    const int* r2 = s + (long)y2 * p;
+    dx = 10 * (r1[x2] - r1[x0]) + 3 * (r0[x2] + r2[x2] - r0[x0] - r2[x0]);
+    dy = 10 * (r2[x] - r0[x]) + 3 * (r2[x0] + r2[x2] - r0[x0] - r0[x2]);
+}
+__device__ __forceinline__ int fgrad(int dx, int dy) { return (int)(sqrtf((float)wadd(wmul(dx, dx), wmul(dy, dy))) + 0.5f); }
+
+__global__ __launch_bounds__(256) void kf_reset(HakImgState* state)
+{
+    HakImgState* st = state + blockIdx.x;
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) st->hist[i] = 0;
+    if (threadIdx.x == 0) { st->ihmax = 1; st->ncand = 0; st->total_pts = 0; st->num_pts = 0; }    // akazed.cu:4101
+}
+__global__ __launch_bounds__(256) void kf_grad_max(const int* __restrict__ smooth, long stride, int w, int h, int p, HakImgState* state)
+{
+    const int* s = smooth + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    int m = 0;
+    if (x < w)
+        for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+            int dx, dy;
+            fscharr(s, x, y, w, h, p, dx, dy);
+            m = max(m, fgrad(dx, dy));
+        }
+    for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0 && m > 1) atomicMax(&state[blockIdx.z].ihmax, m);
+}
+__global__ __launch_bounds__(256) void kf_grad_hist(const int* __restrict__ smooth, long stride, int w, int h, int p, HakImgState* state)
+{
+    __shared__ int shist[HAK_NBINS];
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) shist[i] = 0;
+    __syncthreads();
+    const int* s = smooth + (long)blockIdx.z * stride;
+    const int hfactor = (int)(HAK_NBINS / (float)state[blockIdx.z].ihmax * 65536 + 0.5f);     // akazed.cu:4133
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    if (x < w)
+        for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+            int dx, dy;
+            fscharr(s, x, y, w, h, p, dx, dy);
+            int hi = wmul(fgrad(dx, dy), hfactor) >> 16;                                       // akazed.cu:3319
+            hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : (hi < 0 ? 0 : hi);
+            atomicAdd(&shist[hi], 1);
+        }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256)
+        if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
+}
+__global__ void kf_kcontrast(HakImgState* state, int npix, float per, int noct)
+{
+    HakImgState* st = state + blockIdx.x;
+    if (threadIdx.x != 0) return;
+    int thresh = (int)((npix - st->hist[0]) * per);
+    int cumuv = 0, k = 1;
+    while (k < HAK_NBINS) {
+        if (cumuv >= thresh) break;
+        cumuv += st->hist[k];
+        k++;
+    }
+    int kc = k * st->ihmax / HAK_NBINS;                                                          // akazed.cu:4162
+    for (int o = 0; o < noct; o++) {
+        if (o > 0) kc = (int)(kc * 0.75f + 0.5f);                                                // akaze.cpp:642
+        st->ikcontrast[o] = kc;
+        st->ikc[o] = 1.f / (kc * kc);                                                            // akazed.cu:4215
+    }
+}
+void hakf_launch_contrast(hipStream_t st, const int* smooth, long stride, int w, int h, int p, int nimg, HakImgState* state,
+                          float per, int noct)
+{
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    kf_grad_max<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
+    kf_grad_hist<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
+    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+}
+void hakf_launch_reset(hipStream_t st, HakImgState* state, int nimg) { kf_reset<<<nimg, 256, 0, st>>>(state); }
+
+// ---- akazed.cu:3406 gFlowNaive (conductivity as 16.16 int)
+__global__ __launch_bounds__(256) void kf_flow(const int* __restrict__ src, int* __restrict__ dst, long stride, int w, int h, int p,
+                                               int type, const HakImgState* state, int octave)
+{
+    const int* s = src + (long)blockIdx.z * stride;
+    int* d = dst + (long)blockIdx.z * stride;
+    const float ikc = state[blockIdx.z].ikc[octave];
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+        int dx, dy;
+        fscharr(s, x, y, w, h, p, dx, dy);
+        const float dif2 = wadd(wmul(dx, dx), wmul(dy, dy)) * ikc;
+        float g;
+        if (type == HAK_PM_G2) g = 1.f / (1.f + dif2);
+        else if (type == HAK_PM_G1) g = hak_expf(-dif2);
+        else if (type == HAK_WEICKERT) { float d2 = dif2 * dif2; g = 1.f - hak_expf(-3.315f / (d2 * d2)); }
+        else g = 1.f / sqrtf(1.f + dif2);
+        d[(long)y * p + x] = (int)(g * 65536 + 0.5f);
+    }
+}
+void hakf_launch_flow(hipStream_t st, const int* src, int* dst, long stride, int w, int h, int p, int nimg, int type,
+                      const HakImgState* state, int octave)
+{
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    kf_flow<<<grid, 256, 0, st>>>(src, dst, stride, w, h, p, type, state, octave);
+}
+
+// ---- akazed.cu:3448 gNldStepNaive
+__global__ __launch_bounds__(256) void kf_nld_step(const int* __restrict__ src, const int* __restrict__ flow, int* __restrict__ dst,
+                                                   long stride, int w, int h, int p, int stepfac)
+{
+    const int* s = src + (long)blockIdx.z * stride;
+    const int* f = flow + (long)blockIdx.z * stride;
+    int* d = dst + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    const int x0 = x - 1 < 0 ? 1 - x : x - 1, x2 = x + 1 < w ? x + 1 : w + w - 3 - x;
+    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+        const long r0 = (long)(y - 1 < 0 ? 1 - y : y - 1) * p, r1 = (long)y * p, r2 = (long)(y + 1 < h ? y + 1 : h + h - 3 - y) * p;
+        const int L = s[r1 + x], F = f[r1 + x];
+        const int step = wadd(wadd(wadd(wmul(F + f[r1 + x2], s[r1 + x2] - L), wmul(F + f[r1 + x0], s[r1 + x0] - L)),
+                                   wmul(F + f[r2 + x], s[r2 + x] - L)), wmul(F + f[r0 + x], s[r0 + x] - L)) >> 16;
+        d[r1 + x] = wadd(wmul(stepfac, step) >> 16, L);
+    }
+}
+void hakf_launch_nld_step(hipStream_t st, const int* src, const int* flow, int* dst, long stride, int w, int h, int p, int nimg, float tau)
+{
+    const int stepfac = (int)(0.5f * tau * 65536 + 0.5f);                                         // akazed.cu:4237
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    kf_nld_step<<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, stepfac);
+}
+
+// ---- akazed.cu:3339 gDerivate, 3371 gHessianDeterminant
+__global__ __launch_bounds__(256) void kf_derivate(const int* __restrict__ src, int* __restrict__ lx, int* __restrict__ ly, long stride,
+                                                   int w, int h, int p, int step, int fac1, int fac2)
+{
+    const int* s = src + (long)blockIdx.z * stride;
+    int* ox = lx + (long)blockIdx.z * stride;
+    int* oy = ly + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
+    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+        const int* r0 = s + (long)hak_refl(y - step, h) * p;
+        const int* r1 = s + (long)y * p;
+        const int* r2 = s + (long)hak_refl(y + step, h) * p;
+        const int ul = r0[x0], uc = r0[x], ur = r0[x2], cl = r1[x0], cr = r1[x2], ll = r2[x0], lc = r2[x], lr = r2[x2];
+        ox[(long)y * p + x] = wadd(wmul(fac1, ur + lr - ul - ll), wmul(fac2, cr - cl)) >> 16;
+        oy[(long)y * p + x] = wadd(wmul(fac1, lr + ll - ur - ul), wmul(fac2, lc - uc)) >> 16;
+    }
+}
+__global__ __launch_bounds__(256) void kf_hessian(const int* __restrict__ lx, const int* __restrict__ ly, int* __restrict__ det, long stride,
+                                                  int w, int h, int p, int step, int fac1, int fac2)
+{
+    const int* dx = lx + (long)blockIdx.z * stride;
+    const int* dy = ly + (long)blockIdx.z * stride;
+    int* o = det + (long)blockIdx.z * stride;
+    const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
+    if (x >= w) return;
+    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
+    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+        const long o0 = (long)hak_refl(y - step, h) * p, o1 = (long)y * p, o2 = (long)hak_refl(y + step, h) * p;
+        const int dxx = wadd(wmul(fac1, dx[o0 + x2] + dx[o2 + x2] - dx[o0 + x0] - dx[o2 + x0]), wmul(fac2, dx[o1 + x2] - dx[o1 + x0])) >> 16;
+        const int dxy = wadd(wmul(fac1, dx[o2 + x2] + dx[o2 + x0] - dx[o0 + x2] - dx[o0 + x0]), wmul(fac2, dx[o2 + x] - dx[o0 + x])) >> 16;
+        const int dyy = wadd(wmul(fac1, dy[o2 + x2] + dy[o2 + x0] - dy[o0 + x2] - dy[o0 + x0]), wmul(fac2, dy[o2 + x] - dy[o0 + x])) >> 16;
+        o[o1 + x] = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
+    }
+}
+void hakf_launch_hessian(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride, int w, int h, int p, int nimg, int step)
+{
+    float wv = 10.f / 3.f;                                                                        // akazed.cu:4177-4181
+    float fac1 = 1.f / (2.f * (wv + 2.f)), fac2 = wv * fac1;
+    const int f1 = (int)(fac1 * 65536 + 0.5f), f2 = (int)(fac2 * 65536 + 0.5f);
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    kf_derivate<<<grid, 256, 0, st>>>(src, lx, ly, stride, w, h, p, step, f1, f2);
+    kf_hessian<<<grid, 256, 0, st>>>(lx, ly, det, stride, w, h, p, step, f1, f2);
+}
+
+// ---- akazed.cu:3476 gCalcExtremaMap (int): key = response << 32 | ~layer, candidates appended
+__global__ __launch_bounds__(256) void kf_extrema(const int* __restrict__ base, long stride, unsigned long long* maps, long map_stride,
+                                                  unsigned long long* cand, long cand_cap, HakImgState* state, HakLayout L,
+                                                  const HakTables* __restrict__ tab, int octave, int s, int threshold)
+{
+    const int img = blockIdx.z;
+    const HakOct oc = L.oct[octave];
+    const int* det = base + (long)img * stride + L.det(octave, s);
+    const int layer = octave * L.ms + s;
+    const float border = tab->borders[layer];
+    const int psz = (int)tab->borders[octave * L.ms];
+    const int lane = threadIdx.x & 63;
+    const int x = blockIdx.x * 64 + lane, y0 = blockIdx.y * 16 + (threadIdx.x >> 6);
+    const bool xok = x >= psz && x < oc.w && (int)(x - border + 0.5f) - 1 >= 0 && (int)(x + border + 0.5f) + 1 < oc.w;
+    for (int y = y0; y < blockIdx.y * 16 + 16; y += 4) {
+        bool hit = false;
+        int v = 0;
+        if (xok && y >= psz && y < oc.h && (int)(y - border + 0.5f) - 1 >= 0 && (int)(y + border + 0.5f) + 1 < oc.h) {
+            const int* vp = det + (long)y * oc.p + x;
+            v = *vp;
+            hit = v > threshold && v > vp[-oc.p] && v > vp[oc.p] && v > vp[-1] && v > vp[1] && v > vp[-oc.p - 1] &&
+                  v > vp[-oc.p + 1] && v > vp[oc.p - 1] && v > vp[oc.p + 1];
+        }
+        const unsigned long long m = __ballot(hit);
+        if (m) {
+            int cbase = 0;
+            if (lane == 0) cbase = atomicAdd(&state[img].ncand, __popcll(m));
+            cbase = __builtin_amdgcn_readfirstlane(cbase);
+            if (hit) {
+                const int fx = x << octave, fy = y << octave;
+                const unsigned long long key = ((unsigned long long)(unsigned)v << 32) | (0xFFFFFFFFu - (unsigned)layer);
+                atomicMax(&maps[(long)img * map_stride + (long)fy * L.oct[0].p + fx], key);
+                const long slot = cbase + __popcll(m & ((1ull << lane) - 1ull));
+                if (slot < cand_cap) cand[(long)img * cand_cap + slot] = ((unsigned long long)layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+            }
+        }
+    }
+}
+void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold)
+{
+    const HakOct oc = L.oct[octave];
+    dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, b.nimg);
+    kf_extrema<<<grid, 256, 0, st>>>(reinterpret_cast<const int*>(b.base), b.stride, b.maps, b.map_stride, b.cand, b.cand_cap, b.state, L,
+                                     tab, octave, s, threshold);
+}
+
+// ---- refine (akazed.cu:3600) + orientation (3649) + MLDB (3723), one wave per keypoint
+__device__ __forceinline__ float fast_atan2(float y, float x)                                     // akazed.cu:173-185 (0/0 -> 0)
+{
+    const float absx = fabsf(x), absy = fabsf(y);
+    const float mn = absx < absy ? absx : absy, mx = absx < absy ? absy : absx;
+    const float a = mx > 0.f ? mn / mx : 0.f;
+    const float s = a * a;
+    float r = fmaf(fmaf(fmaf(-0.0464964749f, s, 0.15931422f), s, -0.327622764f), s * a, a);
+    r = (absy > absx ? HAK_HPI_F - r : r);
+    r = (x < 0 ? (float)(HAK_PI_D - r) : r);
+    r = (y < 0 ? -r : r);
+    return r;
+}
+
+__global__ __launch_bounds__(64) void kf_describe(const int* __restrict__ base, long stride, HakLayout L,
+                                                  const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
+                                                  hak_point* points, int max_pts, int patsize, int upright, int desc)
+{
+    __shared__ int acc[90];
+    __shared__ float sdx[128], sdy[128];
+    __shared__ int sbin[128];
+    __shared__ float resx[42], resy[42], re8x[42], re8y[42];
+    __shared__ float s_angle;
+    const int img = blockIdx.y, lane = threadIdx.x;
+    const int npts = state[img].num_pts;
+    const int* arena = base + (long)img * stride;
+    hak_point* pts = points + (long)img * max_pts;
+    const int size2 = patsize, size3 = (int)ceilf(2.0f * patsize / 3.0f), size4 = (int)ceilf(0.5f * patsize);
+    const int winsize = max(3 * size3, 4 * size4);
+    for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
+        hak_point* pt = pts + pi;
+        const int layer = pt->octave, o = layer / L.ms, s = layer - o * L.ms;
+        const HakOct oc = L.oct[o];
+        const int* imd = arena + L.lt(o, s);
+        const int* detd = arena + L.det(o, s);
+        const int* dxd = arena + L.lx(o, s);
+        const int* dyd = arena + L.ly(o, s);
+        // refine (lane 0), result broadcast through LDS
+        __shared__ float s_xy[2];
+        if (lane == 0) {
+            float px = pt->x, py = pt->y;
+            const int y = (int)py >> o, x = (int)px >> o, p = oc.p;
+            const long idx = (long)y * p + x;
+            const int v2 = detd[idx] + detd[idx];
+            const int dx = (detd[idx + 1] - detd[idx - 1]) >> 1, dy = (detd[idx + p] - detd[idx - p]) >> 1;
+            const int dxx = detd[idx + 1] + detd[idx - 1] - v2, dyy = detd[idx + p] + detd[idx - p] - v2;
+            const int dxy = (detd[idx + p + 1] + detd[idx - p - 1] - detd[idx - p + 1] - detd[idx + p - 1]) >> 2;
+            const int dd = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
+            const float idd = dd != 0 ? (1.f / dd) : 0.f;
+            const float dst0 = idd * wadd(wmul(dxy, dy), -wmul(dyy, dx));
+            const float dst1 = idd * wadd(wmul(dxy, dx), -wmul(dxx, dy));
+            if (!(dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f)) {
+                const int ratio = 1 << o;
+                py = ratio * (y + dst1);
+                px = ratio * (x + dst0);
+                pt->x = px;
+                pt->y = py;
+            }
+            s_xy[0] = px; s_xy[1] = py;
+        }
+        if (lane < 90) acc[lane] = 0;
+        if (lane + 64 < 90) acc[lane + 64] = 0;
+        __syncthreads();
+        const float ptx = s_xy[0], pty = s_xy[1], ptsize = pt->size;
+        float angle = 0.f;
+        if (desc && !upright) {
+            const int step = (int)(ptsize + 0.5f);
+            const int x = (int)(ptx + 0.5f) >> o, y = (int)(pty + 0.5f) >> o;
+            int nvalid = 0;
+            for (int t0 = 0; t0 < 208; t0 += 64) {
+                const int tix = t0 + lane, i = (tix & 15) - 6, j = (tix >> 4) - 6, r2 = i * i + j * j;
+                const bool ok = tix < 208 && r2 < 36;
+                const unsigned long long m = __ballot(ok);
+                if (ok) {
+                    const int slot = nvalid + __popcll(m & ((1ull << lane) - 1ull));
+                    const long pos = (long)min(max(y + step * j, 0), oc.h - 1) * oc.p + min(max(x + step * i, 0), oc.w - 1);
+                    const float gw = tab->orient_w[r2];
+                    const float dx = gw * dxd[pos], dy = gw * dyd[pos];
+                    int a = (int)(fast_atan2(dy, dx) * (21 / HAK_PI_D)) + 21;                     // akazed.cu:3685-3686
+                    a = a > 41 ? 41 : (a < 0 ? 0 : a);
+                    sdx[slot] = dx; sdy[slot] = dy; sbin[slot] = a;
+                }
+                nvalid += __popcll(m);
+            }
+            __syncthreads();
+            if (lane < 42) {
+                float rx = 0.f, ry = 0.f;
+                for (int n = 0; n < nvalid; n++)
+                    if (sbin[n] == lane) { rx += sdx[n]; ry += sdy[n]; }
+                resx[lane] = rx; resy[lane] = ry;
+            }
+            __syncthreads();
+            if (lane < 42) {
+                float ax = resx[lane], ay = resy[lane];
+                for (int k = lane + 1; k < lane + 7; k++) { ax += resx[k < 42 ? k : k - 42]; ay += resy[k < 42 ? k : k - 42]; }
+                re8x[lane] = ax; re8y[lane] = ay;
+            }
+            __syncthreads();
+            if (lane == 0) {
+                float maxr = 0.0f; int maxk = 0;
+                for (int k = 0; k < 42; k++) { const float r = re8x[k] * re8x[k] + re8y[k] * re8y[k]; if (r > maxr) { maxr = r; maxk = k; } }
+                const float r = fast_atan2(re8y[maxk], re8x[maxk]);
+                s_angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);
+            }
+            __syncthreads();
+            angle = s_angle;
+        }
+        if (desc) {
+            const float iratio = 1.f / (1 << o);
+            const int scale = (int)(ptsize + 0.5f);
+            const float xf = ptx * iratio, yf = pty * iratio;
+            float si, co;
+            hak_sincosf(angle, &si, &co);
+            for (int i = lane; i < winsize * winsize; i += 64) {
+                const int y = i / winsize, x = i - winsize * y, m = max(x, y), l = x - size2, k = y - size2;
+                const int xp = min(max((int)(xf + scale * (k * co - l * si) + 0.5f), 0), oc.w - 1);
+                const int yp = min(max((int)(yf + scale * (k * si + l * co) + 0.5f), 0), oc.h - 1);
+                const long pos = (long)yp * oc.p + xp;
+                const int im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+                const int rx = (int)(-dx * si + dy * co), ry = (int)(dx * co + dy * si);          // akazed.cu:3777-3778
+                if (m < 2 * size2) { const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry); }
+                if (m < 3 * size3) {
+                    const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+                    const int c = 3 * (4 + y3 * 3 + x3); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry);
+                }
+                if (m < 4 * size4) {
+                    const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3)), y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+                    const int c = 3 * (13 + y4 * 4 + x4); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry);
+                }
+            }
+            __syncthreads();
+            if (lane < HAK_FLEN) {
+                unsigned int d = 0;
+                const int nb = lane == 60 ? 6 : 8;
+                for (int i = 0; i < nb; ++i) d |= (acc[tab->comp1[lane * 8 + i]] > acc[tab->comp2[lane * 8 + i]] ? 1u : 0u) << i;
+                pt->features[lane] = (unsigned char)d;
+            }
+            if (lane == 0) pt->angle = angle;
+        }
+        __syncthreads();
+    }
+}
+void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
+                          int patsize, int upright, int desc)
+{
+    dim3 grid(max_pts < 4096 ? max_pts : 4096, b.nimg);
+    kf_describe<<<grid, 64, 0, st>>>(reinterpret_cast<const int*>(b.base), b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
+}

@@ -92,10 +92,16 @@ namespace akaze
             die("detectAndCompute");
     }
 
-    void Akazer::fastDetectAndCompute(unsigned char*, AkazeData&, int3, const bool)
+    void Akazer::fastDetectAndCompute(unsigned char* image, AkazeData& result, int3 whp0, const bool desc)   // akaze.cpp:153-201
     {
-        // integer 16.16 fixed-point path (akaze.cpp:153-201): SURVEY 8f.1, not built this round
-        fprintf(stderr, "hip-akaze: fastDetectAndCompute (integer FAST path) is not implemented\n");
-        exit(-1);
+        ensureContext(whp0.x, whp0.y);
+        if (result.max_pts < cfg.max_pts) {
+            cfg.max_pts = result.max_pts;
+            hak_destroy(ctx);
+            ctx = nullptr;
+            ensureContext(whp0.x, whp0.y);
+        }
+        if (hak_fast_detect_and_compute(ctx, image, whp0.z, result.d_data, result.max_pts, &result.num_pts, result.h_data, desc ? 1 : 0))
+            die("fastDetectAndCompute");
     }
 }

@@ -101,6 +101,16 @@ int hak_detect_and_compute(hak_ctx* ctx, const float* d_image, int pitch,
 int hak_detect_and_compute_batch(hak_ctx* ctx, const float* d_images, long image_stride, int pitch,
                                  int nimg, hak_point* d_points, int* d_num_pts, int desc);
 
+/* ---- Akazer::fastDetectAndCompute (akaze.h:30, akaze.cpp:153-201, 506-743): the integer "FAST" path --
+ * uint8 image in [0,255] (pitch in bytes), the whole pipeline in int32 with 16.16 fixed-point weights
+ * (namespace fastakaze, akazed.cu:2781-4367), detector threshold fixed at 65 (akaze.cpp:559).  Same
+ * output contract as hak_detect_and_compute; `response` holds the integer determinant as a float. */
+int hak_fast_detect_and_compute(hak_ctx* ctx, const unsigned char* d_image, int pitch,
+                                hak_point* d_points, int max_pts, int* num_pts,
+                                hak_point* h_points, int desc);
+int hak_fast_detect_and_compute_batch(hak_ctx* ctx, const unsigned char* d_images, long image_stride, int pitch,
+                                      int nimg, hak_point* d_points, int* d_num_pts, int desc);
+
 /* ---- cuMatch (akaze.h:14; ctx may be NULL = default stream, akaze.cpp:55-64, akazed.cu:2144-2241): 1-NN
  * Hamming, accepted iff dist < 96 and the minimum is attained in exactly one
  * of the 16 residue classes j mod 16.  Fills match/distance/match_x/match_y

@@ -35,7 +35,8 @@ def default_params(**kw):
 
 
 def build(force=False):
-    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "akaze_oracle.c")):
+    srcs = [os.path.join(_HERE, f) for f in ("akaze_oracle.c", "akaze_oracle_fast.c", "okz_math.h")]
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < max(os.path.getmtime(s) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
     if os.path.isdir("/root/reference") and (force or not os.path.exists(REF_LIB)):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
@@ -205,3 +206,29 @@ def plane(r, kind, o, s):
     w, h, p = (int(v) for v in r.owhps[3 * o:3 * o + 3])
     base = int(r.offsets[o]) + (kind * r.ms + s) * int(r.osizes[o])
     return r.arena[base:base + h * p].reshape(h, p)[:, :w]
+
+
+# ------------------------------------------------------------------ integer FAST path (akaze_oracle_fast.c)
+def fast_detect_and_compute(u8, params=None, max_pts=10000, desc=True, keep_arena=False):
+    """u8: uint8 (h, w) image (dense).  Returns Result(points, kcontrast[, arena of int32])."""
+    params = params or default_params()
+    u8 = np.ascontiguousarray(u8)
+    h, w = u8.shape
+    p = (w + 127) // 128 * 128
+    L = lib()
+    L.fkz_arena_ints.restype = C.c_long
+    n = L.fkz_arena_ints(w, h, p, params.noctaves, params.max_scale)
+    arena = np.zeros(n, np.int32)
+    pts = np.zeros(max_pts, POINT_DTYPE)
+    kc = C.c_int()
+    num = L.fkz_detect_and_compute(u8.ctypes.data_as(C.c_void_p), w, h, w, p, C.byref(params), pts.ctypes.data_as(C.c_void_p),
+                                   max_pts, int(desc), arena.ctypes.data_as(C.c_void_p), C.byref(kc))
+    r = Result()
+    r.points = pts[:num].copy()
+    r.kcontrast = kc.value
+    owhps = np.zeros(24, np.int32); osizes = np.zeros(8, np.int32); offsets = np.zeros(9, np.int32)
+    r.noct = L.okz_layout(w, h, p, params.noctaves, params.max_scale, owhps.ctypes.data_as(_ip),
+                          osizes.ctypes.data_as(_ip), offsets.ctypes.data_as(_ip))
+    r.owhps, r.osizes, r.offsets, r.ms = owhps, osizes, offsets, params.max_scale
+    r.arena = arena if keep_arena else None
+    return r

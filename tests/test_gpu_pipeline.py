@@ -277,3 +277,50 @@ def test_ingest_u8_matches_host_conversion(ah, torch, synth):
         got = d_dst.cpu().numpy()[:, :, :w]
         want = np.stack([synth.to_float(u8[i, :, :w]) for i in range(3)])
         assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+# ----------------------------------------------------------------- integer FAST path
+def gpu_fast_detect(ah, torch, u8, max_pts=10000, desc=True, **kw):
+    h, w = u8.shape
+    p = ah.iAlignUp(w, 128)
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    img = torch.from_numpy(pad).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=max_pts, **kw)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, max_pts, True, True)
+    det.fastDetectAndCompute(img.data_ptr(), data, (w, h, p), desc)
+    pts = data.h_data[:data.num_pts].copy()
+    ah.freeAkazeData(data)
+    det.close()
+    return pts
+
+
+@pytest.mark.parametrize("name", ["left", "right"])
+def test_fast_path_reference_images(ah, okz, torch, golden, name):
+    u8 = golden.lr_u8[name]
+    pts = gpu_fast_detect(ah, torch, u8)
+    r = okz.fast_detect_and_compute(u8)
+    assert len(r.points) > 3000
+    assert_points_equal(pts, r.points)
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(noctaves=3, max_scale=3), dict(soffset=1.2), dict(diffusivity=3), dict(upright=True),
+                                dict(descriptor_pattern_size=8)],
+                         ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()) or "default")
+def test_fast_path_parameter_space(ah, okz, torch, kw):
+    u8 = _mg().case_scene(512, 384, 41)
+    pts = gpu_fast_detect(ah, torch, u8, **kw)
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    r = okz.fast_detect_and_compute(u8, okz.default_params(**okw))
+    assert len(r.points) > 10
+    assert_points_equal(pts, r.points)
+
+
+def test_fast_path_1080p(ah, okz, torch, synth):
+    u8 = synth.scene(1920, 1080, 1)
+    pts = gpu_fast_detect(ah, torch, u8)
+    r = okz.fast_detect_and_compute(u8)
+    assert len(r.points) > 1000
+    assert_points_equal(pts, r.points)
