@@ -6,6 +6,7 @@
                           as uint8 arrays -- data, not source
   left_right_oracle.npz   oracle result on them (demo parameters main.cpp:156-166): points + match fields
   synth_oracle.npz        oracle results on small seeded synthetic scenes (several sizes / parameter sets)
+  fast_oracle.npz         integer FAST-path oracle (akaze_oracle_fast.c) results on left/right and two synthetic scenes
 """
 import json
 import os
@@ -86,7 +87,24 @@ def synth_golden():
     np.savez_compressed(os.path.join(OUT, "synth_oracle.npz"), **out)
 
 
+def fast_golden():
+    lr = np.load(os.path.join(OUT, "left_right_u8.npz"))
+    out = {}
+    for name in ("left", "right"):
+        r = okz.fast_detect_and_compute(lr[name])
+        out[name + "_pts"] = r.points
+        out[name + "_kc"] = np.array([r.kcontrast], np.int32)
+        print("fast", name, len(r.points), r.kcontrast)
+    for name, w, h, seed, kw in SYNTH_CASES[:3]:
+        r = okz.fast_detect_and_compute(case_scene(w, h, seed), okz.default_params(**kw))
+        out[name + "_pts"] = r.points
+        out[name + "_kc"] = np.array([r.kcontrast], np.int32)
+        print("fast", name, len(r.points), r.kcontrast)
+    np.savez_compressed(os.path.join(OUT, "fast_oracle.npz"), **out)
+
+
 if __name__ == "__main__":
     fed_golden()
     pgm_golden()
     synth_golden()
+    fast_golden()

@@ -324,3 +324,46 @@ def test_fast_path_1080p(ah, okz, torch, synth):
     r = okz.fast_detect_and_compute(u8)
     assert len(r.points) > 1000
     assert_points_equal(pts, r.points)
+
+
+def test_fast_path_committed_goldens(ah, torch, golden):
+    g = np.load(os.path.join(golden.dir, "fast_oracle.npz"))
+    mg = _mg()
+    for name, w, h, seed, kw in mg.SYNTH_CASES[:3]:
+        pts = gpu_fast_detect(ah, torch, mg.case_scene(w, h, seed), **kw)
+        assert_points_equal(pts, g[name + "_pts"])
+
+
+def test_fast_path_clamp_nodesc_and_batch(ah, okz, torch):
+    u8 = _mg().case_scene(640, 480, 43)
+    full = okz.fast_detect_and_compute(u8)
+    assert len(full.points) > 300
+    # clamp: max_pts smaller than the number of NMS survivors keeps the first max_pts in raster order
+    pts = gpu_fast_detect(ah, torch, u8, max_pts=200)
+    assert_points_equal(pts, okz.fast_detect_and_compute(u8, max_pts=200).points)
+    # desc=False: refined keypoints only, angle 0 and features zero
+    nd = gpu_fast_detect(ah, torch, u8, desc=False)
+    want = okz.fast_detect_and_compute(u8, desc=False).points
+    assert_points_equal(nd, want)
+    assert not nd["features"].any()
+    # batch entry point: 3 different images in one call
+    imgs = [u8, _mg().case_scene(640, 480, 44), np.full((480, 640), 9, np.uint8)]
+    p = ah.iAlignUp(640, 128)
+    stack = np.zeros((3, 480, p), np.uint8)
+    for i, im in enumerate(imgs):
+        stack[i, :, :640] = im
+    d = torch.from_numpy(stack).cuda()
+    det = ah.Akazer()
+    det.init((640, 480, p), max_pts=2000, batch=3)
+    out = torch.zeros(3 * 2000 * ah.POINT_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    num = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ah.check(ah.lib.hak_fast_detect_and_compute_batch(det.ctx, d.data_ptr(), 480 * p, p, 3, out.data_ptr(), num.data_ptr(), 1))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    nums = num.cpu().numpy()
+    host = out.cpu().numpy().view(ah.POINT_DTYPE).reshape(3, 2000)
+    for i, im in enumerate(imgs):
+        r = okz.fast_detect_and_compute(im, max_pts=2000)
+        assert nums[i] == len(r.points)
+        assert_points_equal(host[i, :nums[i]], r.points) if nums[i] else None
+    assert nums[2] == 0
+    det.close()

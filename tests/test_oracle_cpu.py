@@ -163,3 +163,41 @@ def test_stage_properties(okz):
     rows = sum(full[i] * pad[:, i:i + w] for i in range(5))
     ref = sum(full[i] * rows[i:i + h, :] for i in range(5))
     assert np.abs(okz.lowpass(img, w, 1.0, 2)[:, :w] - ref).max() < 1e-6
+
+
+# ----------------------------------------------------------------- integer FAST path oracle (akaze_oracle_fast.c)
+def test_fast_oracle_fixed_point_kats(okz):
+    """16.16 weights: ik = (int)(k * 65536 + 0.5f) of the float taps (akazed.cu:3896-3921)"""
+    import ctypes as C
+    L = okz.lib()
+    ik = np.zeros(8, np.int32)
+    for var, R in ((1.0, 2), (1.6 * 1.6, 3), (1.2 * 1.2, 3), (2.0 * 2.0, 5)):
+        L.fkz_gauss_taps(C.c_float(var), R, ik.ctypes.data_as(C.POINTER(C.c_int)))
+        k = okz.gauss_taps(var, R)
+        want = (k.astype(np.float32) * np.float32(65536) + np.float32(0.5)).astype(np.int32)
+        assert np.array_equal(ik[:R + 1], want)
+        assert abs(int(ik[0]) + 2 * int(ik[1:R + 1].sum()) - 65536) <= R + 1
+    f1, f2 = C.c_int(), C.c_int()
+    L.fkz_deriv_factors(C.byref(f1), C.byref(f2))
+    a, b = okz.deriv_factors()
+    assert f1.value == int(np.float32(a) * np.float32(65536) + np.float32(0.5))
+    assert f2.value == int(np.float32(b) * np.float32(65536) + np.float32(0.5))
+
+
+def test_fast_oracle_is_frozen(okz, golden):
+    g = np.load(os.path.join(golden.dir, "fast_oracle.npz"))
+    for name, n, kc in (("left", 3733, 167), ("right", 4996, 244)):
+        r = okz.fast_detect_and_compute(golden.lr_u8[name])
+        assert len(r.points) == n and r.kcontrast == kc == int(g[name + "_kc"][0])
+        for f in ("x", "y", "octave", "response", "size", "angle", "features"):
+            assert np.array_equal(r.points[f], g[name + "_pts"][f]), f
+        # integer determinants above the fixed threshold 65 (akaze.cpp:559), stored as floats
+        resp = r.points["response"]
+        assert (resp == np.floor(resp)).all() and (resp > 65).all()
+
+
+def test_fast_oracle_flat_and_tiny_images(okz):
+    flat = np.full((128, 160), 77, np.uint8)
+    assert len(okz.fast_detect_and_compute(flat).points) == 0
+    r = okz.fast_detect_and_compute(np.zeros((96, 96), np.uint8))
+    assert len(r.points) == 0
