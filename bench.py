@@ -83,6 +83,8 @@ def main():
     ap.add_argument("--pipeline", type=int, default=2, help="contexts used round-robin (batches in flight)")
     ap.add_argument("--upload", action="store_true",
                     help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path")
+    ap.add_argument("--fast", action="store_true",
+                    help="also time the integer FAST path (fastDetectAndCompute, uint8 inputs) on the same pairs")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
@@ -199,6 +201,30 @@ def main():
         fence()
         upload_rate = world * B * args.steps / (time.perf_counter() - tu)
 
+    # ---- optional: the integer FAST path on the same pairs (secondary figure, never `value`)
+    fast_rate = None
+    if args.fast:
+        d_fu8 = torch.from_numpy(np.stack([np.pad(u8_pairs[(i // 2) % 2][i % 2], ((0, 0), (0, p - w))) for i in range(nimg)])).cuda()
+
+        def fast_enqueue(k):
+            ah.check(ah.lib.hak_fast_detect_and_compute_batch(dets[k].ctx, d_fu8.data_ptr(), h * p, p, nimg,
+                                                              d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), 1))
+            ah.check(ah.lib.hak_match_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), B))
+        for i in range(2):
+            fast_enqueue(i % NCTX); download(i % NCTX)
+        fence()
+        tf = time.perf_counter()
+        for i in range(args.steps):
+            fast_enqueue(i % NCTX)
+            if i >= NCTX - 1:
+                download((i - (NCTX - 1)) % NCTX)
+        for i in range(max(0, args.steps - (NCTX - 1)), args.steps):
+            download(i % NCTX)
+        fence()
+        fast_rate = world * B * args.steps / (time.perf_counter() - tf)
+        enqueue(0); download(0)                      # leave the float results in the host buffers for the summary
+        fence()
+
     counts = np.ctypeslib.as_array(C.cast(h_num, C.POINTER(C.c_int)), shape=(nimg,)).copy()
     pts = np.ctypeslib.as_array(C.cast(h_pts, C.POINTER(C.c_uint8)), shape=(nimg * max_pts * 104,)).view(ah.POINT_DTYPE).reshape(nimg, max_pts)
     nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(B)))
@@ -265,6 +291,7 @@ def main():
                        "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
             "roofline": roof, "cpu_baseline": cpu,
             "upload_inclusive_pairs_per_s": None if upload_rate is None else round(upload_rate, 1),
+            "fast_path_pairs_per_s": None if fast_rate is None else round(fast_rate, 1),
         }
         print(json.dumps(out))
     for k in range(NCTX):

@@ -39,6 +39,9 @@ POINT_DTYPE = np.dtype([
     ("match", "<i4"), ("distance", "<i4"), ("match_x", "<f4"), ("match_y", "<f4"),
 ])
 assert POINT_DTYPE.itemsize == 104
+MATCH_PAIR_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("distance", "<i4"), ("second", "<i4"),
+                             ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])      # hak_match_pair
+assert MATCH_PAIR_DTYPE.itemsize == 32
 
 
 class HakError(RuntimeError):
@@ -79,6 +82,8 @@ SYMBOLS = {
     "hak_fast_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "hak_match": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _vp]),
     "hak_match_batch": (C.c_int, [_vp, _vp, _vp, C.c_int]),
+    "hak_match_knn2": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp, _ip, _vp]),
+    "hak_match_knn2_batch": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _vp, _vp]),
     "hak_points_alloc": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "hak_points_free": (C.c_int, [_vp]),
     "hak_image_alloc": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int, _ip]),
@@ -301,3 +306,19 @@ def cuMatch(result1, result2, akazer=None):
     ctx = akazer.ctx if akazer is not None else None
     hptr = result1.h_data.ctypes.data if result1.h_data is not None else None
     check(lib.hak_match(ctx, result1.d_data, result1.num_pts, result2.d_data, result2.num_pts, hptr))
+
+
+def cuMatchKnn(result1, result2, ratio=(1, 1), cross_check=True, max_dist=0, akazer=None):
+    """Match post-processing (hipakaze.h hak_match_knn2): 2-NN ratio test of the reference's unused
+    gMatch (akazed.cu:2028-2122) + symmetric cross-check + device-side compaction.  Updates result1 like
+    cuMatch and returns the accepted matches (MATCH_PAIR_DTYPE, ascending query index)."""
+    import torch
+    ctx = akazer.ctx if akazer is not None else None
+    n1 = result1.num_pts
+    d_out = torch.zeros(max(n1, 1) * MATCH_PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    h_out = np.zeros(max(n1, 1), MATCH_PAIR_DTYPE)
+    cnt = C.c_int(0)
+    hptr = result1.h_data.ctypes.data if result1.h_data is not None else None
+    check(lib.hak_match_knn2(ctx, result1.d_data, n1, result2.d_data, result2.num_pts, int(ratio[0]), int(ratio[1]),
+                             int(cross_check), int(max_dist), hptr, d_out.data_ptr(), C.byref(cnt), h_out.ctypes.data))
+    return h_out[:cnt.value].copy()

@@ -168,6 +168,8 @@ struct hak_ctx {
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
+    int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
+    int* d_cnt = nullptr;
 };
 
 static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -342,7 +344,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab};
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt};
     for (void* b : bufs) (void)hipFree(b);
     if (c->h_num) (void)hipHostFree(c->h_num);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -639,6 +641,81 @@ extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num
     { ProfScope ps(c, HAK_PROF_MATCH);
       hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs); }
     if (hipGetLastError() != hipSuccess) return fail("match launch failed");
+    return 0;
+}
+
+// ----------------------------------------------------------- match post-processing
+static int knn_scratch(hak_ctx* c)
+{
+    if (c->knn) return 0;
+    const size_t npair = (size_t)(c->cfg.batch + 1) / 2;
+    HIP_TRY(hipMalloc((void**)&c->knn, sizeof(int4) * 2 * npair * (size_t)c->cfg.max_pts));
+    HIP_TRY(hipMalloc((void**)&c->d_cnt, sizeof(int) * npair));
+    return 0;
+}
+
+extern "C" int hak_match_knn2(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point* d_pts2, int n2, int ratio_num,
+                              int ratio_den, int cross_check, int max_dist, hak_point* h_pts1, hak_match_pair* d_out,
+                              int* count, hak_match_pair* h_out)
+{
+    if (!d_pts1 || (!d_pts2 && n2 > 0) || !count) return fail("null argument");
+    if (ratio_num <= 0 || ratio_den <= 0) return fail("ratio must be a positive fraction");
+    if (h_out && !d_out) return fail("h_out needs d_out");
+    *count = 0;
+    if (n1 <= 0) return 0;
+    if (max_dist <= 0) max_dist = HAK_MAX_DIST;
+    hipStream_t st = c ? c->stream : nullptr;
+    int4* scratch = nullptr;
+    int* d_cnt = nullptr;
+    const bool own = !c || n1 > c->cfg.max_pts || n2 > c->cfg.max_pts;
+    if (own) {
+        HIP_TRY(hipMalloc((void**)&scratch, sizeof(int4) * ((size_t)n1 + (size_t)(n2 > 0 ? n2 : 1))));
+        HIP_TRY(hipMalloc((void**)&d_cnt, sizeof(int)));
+    } else {
+        if (knn_scratch(c)) return 1;
+        scratch = c->knn;
+        d_cnt = c->d_cnt;
+    }
+    int4* fwd = scratch;
+    int4* rev = scratch + n1;
+    {
+        hak_launch_knn2(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, fwd, 0);
+        if (cross_check && n2 > 0) hak_launch_knn2(st, d_pts2, d_pts1, nullptr, nullptr, n2, n1, 0, 0, 1, rev, 0);
+        hak_launch_knn2_finish(st, d_pts1, d_pts2, nullptr, n1, 0, 0, 1, fwd, cross_check ? rev : nullptr, 0, ratio_num, ratio_den,
+                               cross_check ? 1 : 0, max_dist, d_out, 0, d_cnt);
+    }
+    int rc = 0;
+    if (hipGetLastError() != hipSuccess) rc = fail("knn2 launch failed");
+    if (!rc && hipMemcpyAsync(count, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail("count download");
+    if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail("sync");
+    if (!rc && h_out && *count > 0 &&
+        hipMemcpy(h_out, d_out, sizeof(hak_match_pair) * (size_t)*count, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail("match list download");
+    if (!rc && h_pts1 &&                                                          // akaze.cpp:58-63
+        hipMemcpy2D(&h_pts1[0].match, sizeof(hak_point), &d_pts1[0].match, sizeof(hak_point), 16, n1, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail("match field download");
+    if (own) { (void)hipFree(scratch); (void)hipFree(d_cnt); }
+    return rc;
+}
+
+extern "C" int hak_match_knn2_batch(hak_ctx* c, hak_point* d_points, const int* d_num_pts, int npairs, int ratio_num,
+                                    int ratio_den, int cross_check, int max_dist, hak_match_pair* d_out, int* d_counts)
+{
+    if (!c || !d_points || !d_num_pts || !d_counts || npairs < 1) return fail("bad argument");
+    if (2 * npairs > c->cfg.batch + 1) return fail("npairs exceeds the context's batch capacity");
+    if (ratio_num <= 0 || ratio_den <= 0) return fail("ratio must be a positive fraction");
+    if (max_dist <= 0) max_dist = HAK_MAX_DIST;
+    if (knn_scratch(c)) return 1;
+    const long mp = c->cfg.max_pts;
+    int4* fwd = c->knn;
+    int4* rev = c->knn + (size_t)((c->cfg.batch + 1) / 2) * mp;
+    { ProfScope ps(c, HAK_PROF_MATCH);
+      hak_launch_knn2(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs, fwd, mp);
+      if (cross_check)
+          hak_launch_knn2(c->stream, d_points + mp, d_points, d_num_pts + 1, d_num_pts, 0, 0, 2 * mp, 2 * mp, npairs, rev, mp);
+      hak_launch_knn2_finish(c->stream, d_points, d_points + mp, d_num_pts, 0, 2 * mp, 2 * mp, npairs, fwd, cross_check ? rev : nullptr,
+                             mp, ratio_num, ratio_den, cross_check ? 1 : 0, max_dist, d_out, mp, d_counts); }
+    if (hipGetLastError() != hipSuccess) return fail("knn2 launch failed");
     return 0;
 }
 

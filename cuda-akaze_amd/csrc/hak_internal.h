@@ -229,3 +229,8 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 // matcher (kernels_match.hip)
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs);
+void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
+                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride);
+void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,
+                            long stride2, int npairs, const int4* fwd, const int4* rev, long knn_stride, int ratio_num,
+                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count);

@@ -80,6 +80,133 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
     }
 }
 
+// ------------------------------------------------------------------ match post-processing
+// 2-NN search: for every point a of set A its nearest neighbour in B (smallest index among ties), the
+// distance d1 to it and the distance d2 to the nearest OTHER point of B (512 when B has fewer than two
+// points -- the initial score of the reference's unused gMatch, akazed.cu:2028-2122, whose accept rule
+// "d1 < d2 && d1 < MAX_DIST" is the ratio test with ratio 1).  Same 16 x 16 block mapping as k_match.
+__global__ __launch_bounds__(256) void k_knn2(const hak_point* ptsA_base, const hak_point* ptsB_base,
+                                              const int* __restrict__ nA_dev, const int* __restrict__ nB_dev,
+                                              int nA_host, int nB_host, long strideA, long strideB, int count_stride,
+                                              int4* __restrict__ out_base, long out_stride)
+{
+    __shared__ int sd1[MC][MQ], sd2[MC][MQ], si1[MC][MQ];
+    const int pair = blockIdx.y;
+    const int nA = nA_dev ? nA_dev[pair * count_stride] : nA_host;
+    const int nB = nB_dev ? nB_dev[pair * count_stride] : nB_host;
+    const hak_point* A = ptsA_base + (long)pair * strideA;
+    const hak_point* B = ptsB_base + (long)pair * strideB;
+    int4* out = out_base + (long)pair * out_stride;
+    const int q = threadIdx.x & (MQ - 1), c = threadIdx.x >> 4;
+    for (int q0 = blockIdx.x * MQ; q0 < nA; q0 += gridDim.x * MQ) {
+        const int qi = q0 + q;
+        unsigned int qd[16];
+        if (qi < nA) load_desc(A + qi, qd);
+        int best = 512, second = 512, besti = -1;
+        if (qi < nA)
+            for (int j = c; j < nB; j += MC) {
+                unsigned int td[16];
+                load_desc(B + j, td);
+                int dist = 0;
+#pragma unroll
+                for (int k = 0; k < 16; k += 2)
+                    dist += __popcll(((unsigned long long)(qd[k + 1] ^ td[k + 1]) << 32) | (qd[k] ^ td[k]));
+                if (dist < best) { second = best; best = dist; besti = j; }
+                else if (dist < second) second = dist;
+            }
+        sd1[c][q] = best; sd2[c][q] = second; si1[c][q] = besti;
+        __syncthreads();
+        if (c == 0 && qi < nA) {
+            int bc = -1;
+            for (int t = 0; t < MC; t++) {
+                if (si1[t][q] < 0) continue;
+                if (bc < 0 || sd1[t][q] < sd1[bc][q] || (sd1[t][q] == sd1[bc][q] && si1[t][q] < si1[bc][q])) bc = t;
+            }
+            int d2 = 512;
+            for (int t = 0; t < MC; t++) {
+                const int v = (t == bc) ? sd2[t][q] : sd1[t][q];
+                d2 = v < d2 ? v : d2;
+            }
+            out[qi] = bc < 0 ? make_int4(-1, 512, 512, 0) : make_int4(si1[bc][q], sd1[bc][q], d2, 0);
+        }
+        __syncthreads();
+    }
+}
+
+// accept rule + compaction in query order.  One 1024-thread block per pair walks the queries in chunks;
+// accepted matches are appended at the running base through a ballot/popcount block scan, so the output
+// order (ascending query index) is deterministic.
+__global__ __launch_bounds__(1024) void k_knn2_finish(hak_point* pts1_base, const hak_point* pts2_base,
+                                                      const int* __restrict__ n1_dev, int n1_host, long stride1, long stride2,
+                                                      int count_stride, const int4* __restrict__ fwd_base,
+                                                      const int4* __restrict__ rev_base, long knn_stride, int ratio_num,
+                                                      int ratio_den, int cross, int max_dist, hak_match_pair* out_base,
+                                                      long out_stride, int* __restrict__ out_count, int count_out_stride)
+{
+    __shared__ int wsum[16];
+    __shared__ int sbase;
+    const int pair = blockIdx.x;
+    const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
+    hak_point* pts1 = pts1_base + (long)pair * stride1;
+    const hak_point* pts2 = pts2_base + (long)pair * stride2;
+    const int4* fwd = fwd_base + (long)pair * knn_stride;
+    const int4* rev = rev_base ? rev_base + (long)pair * knn_stride : nullptr;
+    hak_match_pair* out = out_base ? out_base + (long)pair * out_stride : nullptr;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) sbase = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n1; i0 += 1024) {
+        const int i = i0 + threadIdx.x;
+        bool ok = false;
+        int4 f = make_int4(-1, 512, 512, 0);
+        if (i < n1) {
+            f = fwd[i];
+            ok = f.x >= 0 && f.y < max_dist && (long)f.y * ratio_den < (long)f.z * ratio_num;
+            if (ok && cross) ok = rev[f.x].x == i;
+            hak_point* p1 = pts1 + i;
+            if (ok) {
+                p1->match = f.x; p1->distance = f.y;
+                p1->match_x = pts2[f.x].x; p1->match_y = pts2[f.x].y;
+            } else {
+                p1->match = -1; p1->distance = -1; p1->match_x = -1.f; p1->match_y = -1.f;
+            }
+        }
+        const unsigned long long m = __ballot(ok);
+        if (lane == 0) wsum[wv] = __popcll(m);
+        __syncthreads();
+        int before = sbase;
+        for (int t = 0; t < wv; t++) before += wsum[t];
+        if (ok && out) {
+            const int pos = before + __popcll(m & ((1ull << lane) - 1ull));
+            hak_match_pair r;
+            r.query = i; r.train = f.x; r.distance = f.y; r.second = f.z;
+            r.x1 = pts1[i].x; r.y1 = pts1[i].y; r.x2 = pts2[f.x].x; r.y2 = pts2[f.x].y;
+            out[pos] = r;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { int tot = 0; for (int t = 0; t < 16; t++) tot += wsum[t]; sbase += tot; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && out_count) out_count[pair * count_out_stride] = sbase;
+}
+
+void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
+                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride)
+{
+    int gx = nA_dev ? 640 : (nA_host + MQ - 1) / MQ;
+    if (gx < 1) gx = 1;
+    if (gx > 4096) gx = 4096;
+    k_knn2<<<dim3(gx, npairs), 256, 0, st>>>(ptsA, ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB, 2, out, out_stride);
+}
+
+void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,
+                            long stride2, int npairs, const int4* fwd, const int4* rev, long knn_stride, int ratio_num,
+                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count)
+{
+    k_knn2_finish<<<npairs, 1024, 0, st>>>(pts1, pts2, n1_dev, n1_host, stride1, stride2, 2, fwd, rev, knn_stride, ratio_num,
+                                           ratio_den, cross, max_dist, out, out_stride, out_count, 1);
+}
+
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs)
 {

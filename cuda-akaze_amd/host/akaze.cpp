@@ -41,6 +41,19 @@ namespace akaze
             die("cuMatch");
     }
 
+    int cuMatchKnn(AkazeData& result1, AkazeData& result2, hak_match_pair* matches, int ratio_num, int ratio_den, bool cross_check)
+    {
+        int count = 0;
+        hak_match_pair* d_out = nullptr;
+        const int cap = result1.num_pts > 0 ? result1.num_pts : 1;
+        if (matches && hipMalloc((void**)&d_out, sizeof(hak_match_pair) * (size_t)cap) != hipSuccess) die("cuMatchKnn alloc");
+        if (hak_match_knn2(NULL, result1.d_data, result1.num_pts, result2.d_data, result2.num_pts, ratio_num, ratio_den,
+                           cross_check ? 1 : 0, 0, result1.h_data, d_out, &count, matches))
+            die("cuMatchKnn");
+        if (d_out) (void)hipFree(d_out);
+        return count;
+    }
+
     Akazer::Akazer() { hak_default_config(&cfg); }
 
     Akazer::~Akazer() { hak_destroy(ctx); }                                                     // akaze.cpp:74-77

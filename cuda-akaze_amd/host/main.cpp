@@ -116,6 +116,38 @@ int main(int argc, char** argv)
               << "Time of detection and computation: " << (t2 - t1) / nrepeats << std::endl
               << "Time of matching AKAZE keypoints:   " << (t3 - t2) << std::endl;
 
+    // match post-processing (build-side addition): ratio 4/5 + cross-check, compacted on the device
+    std::vector<hak_match_pair> good(akaze_data1.num_pts > 0 ? akaze_data1.num_pts : 1);
+    float t4 = timer.read();
+    int ngood = akaze::cuMatchKnn(akaze_data1, akaze_data2, good.data(), 4, 5, true);
+    float t5 = timer.read();
+    std::cout << "2-NN ratio 0.8 + cross-check matches: " << ngood << "  (" << t5 - t4 << " ms)" << std::endl;
+
+    // ---- the reference's second demo (main.cpp:227-300): the integer FAST path on the uint8 images
+    std::cout << "===== FAST (16.16 fixed-point) path =====" << std::endl;
+    unsigned char *fimg1 = NULL, *fimg2 = NULL;
+    CHECK(hipMalloc((void**)&fimg1, (size_t)whp1.y * whp1.z));
+    CHECK(hipMalloc((void**)&fimg2, (size_t)whp2.y * whp2.z));
+    CHECK(hipMemcpy2D(fimg1, whp1.z, l8.data(), w, w, h, hipMemcpyHostToDevice));
+    CHECK(hipMemcpy2D(fimg2, whp2.z, r8.data(), w, w, h, hipMemcpyHostToDevice));
+    float f1 = timer.read();
+    for (int i = 0; i < nrepeats; i++) {
+        detector->fastDetectAndCompute(fimg1, akaze_data1, whp1, true);
+        detector->fastDetectAndCompute(fimg2, akaze_data2, whp2, true);
+    }
+    float f2 = timer.read();
+    akaze::cuMatch(akaze_data1, akaze_data2);
+    float f3 = timer.read();
+    nmatch = 0;
+    for (int i = 0; i < akaze_data1.num_pts; i++) nmatch += akaze_data1.h_data[i].match >= 0;
+    std::cout << "Number of features1: " << akaze_data1.num_pts << std::endl
+              << "Number of features2: " << akaze_data2.num_pts << std::endl
+              << "Number of accepted matches: " << nmatch << std::endl
+              << "Time of detection and computation: " << (f2 - f1) / nrepeats << std::endl
+              << "Time of matching AKAZE keypoints:   " << (f3 - f2) << std::endl;
+    CHECK(hipFree(fimg1));
+    CHECK(hipFree(fimg2));
+
     akaze::freeAkazeData(akaze_data1);
     akaze::freeAkazeData(akaze_data2);
     CHECK(hipFree(img1));

@@ -14,6 +14,12 @@ namespace akaze
     void freeAkazeData(AkazeData& data);                                                        // akaze.h:12
     void cuMatch(AkazeData& result1, AkazeData& result2);                                       // akaze.h:14
 
+    // build-side addition: 2-NN ratio test (the reference's unused gMatch, akazed.cu:2028-2122) +
+    // symmetric cross-check; fills result1 like cuMatch and returns the accepted matches in query order
+    // (host array `matches`, capacity >= result1.num_pts; may be NULL to only count).
+    int cuMatchKnn(AkazeData& result1, AkazeData& result2, hak_match_pair* matches, int ratio_num = 1, int ratio_den = 1,
+                   bool cross_check = true);
+
     class Akazer
     {
     public:

@@ -121,6 +121,30 @@ int hak_match(hak_ctx* ctx, hak_point* d_pts1, int n1, const hak_point* d_pts2, 
  * counts read from d_num_pts[2k], d_num_pts[2k+1] on the device. Asynchronous. */
 int hak_match_batch(hak_ctx* ctx, hak_point* d_points, const int* d_num_pts, int npairs);
 
+/* ---- match post-processing.  The reference ships an unused 2-NN matcher (gMatch,
+ * akazed.cu:2028-2122: best and second-best score, accept iff best < second && best < MAX_DIST); this is
+ * that rule made well-defined, plus the usual symmetric cross-check and a device-side compaction:
+ *   j1(i) = nearest train point of query i (smallest index among ties), d1 its distance,
+ *   d2    = distance to the nearest OTHER train point (512 when n2 < 2, gMatch's initial score);
+ *   accept iff d1 < max_dist  and  d1 * ratio_den < d2 * ratio_num  (1/1 = gMatch's rule)
+ *          and (cross_check == 0 or the nearest query of train point j1(i) is i, ties to the smallest index).
+ * Writes match/distance/match_x/match_y of pts1 like cuMatch (rejected: -1; copied to h_pts1 when given) and appends the accepted
+ * matches, in ascending query order, to d_out (capacity >= n1; may be NULL); *count receives their number.
+ * ctx may be NULL (scratch is then allocated per call).  max_dist <= 0 selects 96 (akazed.cu:6). */
+typedef struct hak_match_pair {
+    int   query, train;      /* indices into pts1 / pts2 */
+    int   distance, second;  /* d1, d2 */
+    float x1, y1, x2, y2;    /* refined coordinates of both ends */
+} hak_match_pair;
+int hak_match_knn2(hak_ctx* ctx, hak_point* d_pts1, int n1, const hak_point* d_pts2, int n2,
+                   int ratio_num, int ratio_den, int cross_check, int max_dist, hak_point* h_pts1,
+                   hak_match_pair* d_out, int* count, hak_match_pair* h_out);
+/* batched over the pairs of a detect batch (layout as hak_match_batch): pair k's accepted matches go to
+ * d_out + k*max_pts, their number to d_counts[k].  Asynchronous on the context's stream. */
+int hak_match_knn2_batch(hak_ctx* ctx, hak_point* d_points, const int* d_num_pts, int npairs,
+                         int ratio_num, int ratio_den, int cross_check, int max_dist,
+                         hak_match_pair* d_out, int* d_counts);
+
 /* ---- memory helpers: initAkazeData/freeAkazeData (akaze.cpp:26-52) and the
  * image upload of main.cpp:172-188 */
 int hak_points_alloc(hak_point** d_points, int count);

@@ -640,6 +640,60 @@ void okz_match(OkzPoint* pts1, int n1, const OkzPoint* pts2, int n2)
     }
 }
 
+/* Match post-processing: the 2-NN rule of the reference's unused gMatch (akazed.cu:2028-2122:
+ * keep best and second-best score, accept iff best < second && best < MAX_DIST; its LDS reduction has no
+ * barriers and it writes pt2->match_y, so only the stated rule is restated here), generalised to a ratio
+ * num/den and an optional symmetric cross-check, with the accepted matches listed in query order.
+ * Parity for this row is pinned by numpy brute force (tests), not by reference output: the kernel is dead code. */
+typedef struct { int query, train, distance, second; float x1, y1, x2, y2; } OkzMatchPair;
+
+static void okz_nn2(const OkzPoint* a, const OkzPoint* B, int nB, int* j1, int* d1, int* d2)
+{
+    int best = 512, second = 512, bi = -1;
+    for (int j = 0; j < nB; j++) {
+        int dist = 0;
+        for (int b = 0; b < OKZ_FLEN; b++) dist += __builtin_popcount((unsigned)(a->features[b] ^ B[j].features[b]));
+        if (dist < best) { second = best; best = dist; bi = j; }
+        else if (dist < second) second = dist;
+    }
+    *j1 = bi; *d1 = best; *d2 = second;
+}
+
+int okz_match_knn2(OkzPoint* pts1, int n1, const OkzPoint* pts2, int n2, int ratio_num, int ratio_den, int cross,
+                   int max_dist, OkzMatchPair* out)
+{
+    int* acc = (int*)calloc((size_t)(n1 > 0 ? n1 : 1), 3 * sizeof(int));
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n1; i++) {
+        int j1, d1, d2;
+        okz_nn2(pts1 + i, pts2, n2, &j1, &d1, &d2);
+        int ok = j1 >= 0 && d1 < max_dist && (long)d1 * ratio_den < (long)d2 * ratio_num;
+        if (ok && cross) {
+            int i1, e1, e2;
+            okz_nn2(pts2 + j1, pts1, n1, &i1, &e1, &e2);
+            ok = i1 == i;
+        }
+        acc[3 * i] = ok ? j1 : -1; acc[3 * i + 1] = d1; acc[3 * i + 2] = d2;
+    }
+    int cnt = 0;
+    for (int i = 0; i < n1; i++) {
+        OkzPoint* p1 = pts1 + i;
+        int j = acc[3 * i];
+        if (j >= 0) {
+            p1->match = j; p1->distance = acc[3 * i + 1]; p1->match_x = pts2[j].x; p1->match_y = pts2[j].y;
+            if (out) {
+                OkzMatchPair r = {i, j, acc[3 * i + 1], acc[3 * i + 2], p1->x, p1->y, pts2[j].x, pts2[j].y};
+                out[cnt] = r;
+            }
+            cnt++;
+        } else {
+            p1->match = -1; p1->distance = -1; p1->match_x = -1; p1->match_y = -1;
+        }
+    }
+    free(acc);
+    return cnt;
+}
+
 /* --------------------------------------------------------- whole pipeline */
 
 /* akaze.cpp:204-237 allocMemory (sized by the effective octave count, D15).

@@ -175,6 +175,18 @@ def match(pts1, pts2):
     return pts1
 
 
+MATCH_PAIR_DTYPE = np.dtype([("query", "<i4"), ("train", "<i4"), ("distance", "<i4"), ("second", "<i4"),
+                             ("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4")])
+
+
+def match_knn2(pts1, pts2, ratio=(1, 1), cross=True, max_dist=96):
+    """2-NN ratio test + cross-check + compaction; pts1 updated in place, returns the accepted-match list"""
+    out = np.zeros(max(len(pts1), 1), MATCH_PAIR_DTYPE)
+    n = lib().okz_match_knn2(pts1.ctypes.data_as(C.c_void_p), len(pts1), pts2.ctypes.data_as(C.c_void_p), len(pts2),
+                             int(ratio[0]), int(ratio[1]), int(cross), int(max_dist), out.ctypes.data_as(C.c_void_p))
+    return out[:n].copy()
+
+
 class Result:
     pass
 

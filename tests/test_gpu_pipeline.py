@@ -367,3 +367,66 @@ def test_fast_path_clamp_nodesc_and_batch(ah, okz, torch):
         assert_points_equal(host[i, :nums[i]], r.points) if nums[i] else None
     assert nums[2] == 0
     det.close()
+
+
+# ----------------------------------------------------------------- match post-processing
+def _upload_points(ah, torch, pts):
+    t = torch.from_numpy(pts.view(np.uint8).reshape(-1).copy()).cuda() if len(pts) else torch.zeros(104, dtype=torch.uint8, device="cuda")
+    return t
+
+
+@pytest.mark.parametrize("n1,n2,ratio,cross", [(260, 300, (1, 1), False), (260, 300, (1, 1), True), (1000, 1700, (4, 5), True),
+                                               (1700, 1000, (3, 5), False), (5, 1, (1, 1), True), (5, 0, (1, 1), True),
+                                               (10000, 10000, (4, 5), True)])
+def test_knn2_matches_oracle(ah, okz, torch, synth, n1, n2, ratio, cross):
+    p2 = synth.random_descriptors(max(n2, 1), 3, ah.POINT_DTYPE)[:n2]
+    p1 = synth.random_descriptors(n1, 4, ah.POINT_DTYPE, planted_from=p2 if n2 else None, nplanted=min(n1, n2) // 2, maxflip=60)
+    if n1 > 8 and n2 > 12:
+        p1[7]["features"] = p1[3]["features"]
+        p2[11]["features"] = p2[5]["features"]
+    want_pts = p1.copy()
+    want = okz.match_knn2(want_pts, p2, ratio, cross)
+    d1, d2 = _upload_points(ah, torch, p1), _upload_points(ah, torch, p2)
+    d_out = torch.zeros(max(n1, 1) * 32, dtype=torch.uint8, device="cuda")
+    h_out = np.zeros(max(n1, 1), ah.MATCH_PAIR_DTYPE)
+    h_pts = p1.copy()
+    cnt = C.c_int(-1)
+    ah.check(ah.lib.hak_match_knn2(None, d1.data_ptr(), n1, d2.data_ptr(), n2, ratio[0], ratio[1], int(cross), 0,
+                                   h_pts.ctypes.data, d_out.data_ptr(), C.byref(cnt), h_out.ctypes.data))
+    assert cnt.value == len(want)
+    got = h_out[:cnt.value]
+    for f in ah.MATCH_PAIR_DTYPE.names:
+        assert np.array_equal(got[f], want[f]), f
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(h_pts[f], want_pts[f]), f
+
+
+def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth):
+    w, h = 640, 480
+    p = ah.iAlignUp(w, 128)
+    pairs = [synth.pair(w, h, 5), synth.pair(w, h, 6)]
+    host = np.stack([synth.to_float(pairs[i // 2][i % 2], p) for i in range(4)])
+    d = torch.from_numpy(host).cuda()
+    mp = 3000
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp, batch=4)
+    pts = torch.zeros(4 * mp * 104, dtype=torch.uint8, device="cuda")
+    num = torch.zeros(4, dtype=torch.int32, device="cuda")
+    out = torch.zeros(2 * mp * 32, dtype=torch.uint8, device="cuda")
+    cnt = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, d.data_ptr(), h * p, p, 4, pts.data_ptr(), num.data_ptr(), 1))
+    ah.check(ah.lib.hak_match_knn2_batch(det.ctx, pts.data_ptr(), num.data_ptr(), 2, 4, 5, 1, 0, out.data_ptr(), cnt.data_ptr()))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    nums, cnts = num.cpu().numpy(), cnt.cpu().numpy()
+    allp = pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(4, mp)
+    allo = out.cpu().numpy().view(ah.MATCH_PAIR_DTYPE).reshape(2, mp)
+    for k in range(2):
+        a, b = allp[2 * k, :nums[2 * k]].copy(), allp[2 * k + 1, :nums[2 * k + 1]].copy()
+        got_fields = {f: a[f].copy() for f in ("match", "distance", "match_x", "match_y")}
+        want = okz.match_knn2(a, b, (4, 5), True)
+        assert cnts[k] == len(want) and len(want) > 50
+        for f in ah.MATCH_PAIR_DTYPE.names:
+            assert np.array_equal(allo[k, :cnts[k]][f], want[f]), f
+        for f, v in got_fields.items():
+            assert np.array_equal(v, a[f]), f
+    det.close()

@@ -201,3 +201,49 @@ def test_fast_oracle_flat_and_tiny_images(okz):
     assert len(okz.fast_detect_and_compute(flat).points) == 0
     r = okz.fast_detect_and_compute(np.zeros((96, 96), np.uint8))
     assert len(r.points) == 0
+
+
+# ----------------------------------------------------------------- match post-processing
+def _brute_knn2(p1, p2, ratio, cross, max_dist):
+    f1, f2 = p1["features"], p2["features"]
+    d = np.unpackbits(f1[:, None, :] ^ f2[None, :, :], axis=2).sum(axis=2).astype(np.int64)
+    out = []
+    rev = d.argmin(axis=0)                      # first minimum = smallest query index
+    for i in range(len(p1)):
+        j1 = int(d[i].argmin())
+        d1 = int(d[i, j1])
+        rest = np.delete(d[i], j1)
+        d2 = int(rest.min()) if rest.size else 512
+        ok = d1 < max_dist and d1 * ratio[1] < d2 * ratio[0] and (not cross or rev[j1] == i)
+        if ok:
+            out.append((i, j1, d1, d2))
+    return out
+
+
+@pytest.mark.parametrize("ratio,cross", [((1, 1), False), ((1, 1), True), ((4, 5), True), ((3, 5), False)])
+def test_oracle_knn2_against_numpy_brute_force(okz, ratio, cross):
+    from akaze_hip import synth
+    p2 = synth.random_descriptors(300, 3, okz.POINT_DTYPE)
+    p1 = synth.random_descriptors(260, 4, okz.POINT_DTYPE, planted_from=p2, nplanted=150, maxflip=60)
+    p1[7]["features"] = p1[3]["features"]           # duplicate queries: the cross-check keeps only the first
+    p2[11]["features"] = p2[5]["features"]          # duplicate train points: d1 == d2 fails the ratio test
+    got = okz.match_knn2(p1, p2, ratio, cross)
+    want = _brute_knn2(p1, p2, ratio, cross, 96)
+    assert [(int(r["query"]), int(r["train"]), int(r["distance"]), int(r["second"])) for r in got] == want
+    assert len(want) > 20
+    acc = p1["match"] >= 0
+    assert acc.sum() == len(got) and np.array_equal(np.nonzero(acc)[0], got["query"])
+    assert np.array_equal(p1["match_x"][acc], p2["x"][got["train"]]) and (p1["distance"][~acc] == -1).all()
+    assert np.array_equal(got["x1"], p1["x"][got["query"]]) and np.array_equal(got["y2"], p2["y"][got["train"]])
+
+
+def test_oracle_knn2_edge_cases(okz):
+    from akaze_hip import synth
+    p1 = synth.random_descriptors(5, 1, okz.POINT_DTYPE)
+    assert len(okz.match_knn2(p1, p1[:0].copy())) == 0 and (p1["match"] == -1).all()
+    one = p1[:1].copy()
+    q = p1.copy()
+    got = okz.match_knn2(q, one, cross=False)        # single train point: d2 = 512, query 0 is identical (d1 = 0)
+    assert got[0]["query"] == 0 and got[0]["distance"] == 0 and got[0]["second"] == 512
+    got = okz.match_knn2(q, one, cross=True)
+    assert len(got) == 1
