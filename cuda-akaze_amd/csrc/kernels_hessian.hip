@@ -24,9 +24,11 @@
 #define HF_E 1                                   // extra halo so the det tile has its 3x3 neighbourhood
 template <int S> struct HessGeo {
     static constexpr int TY = S == 4 ? 28 : 32;                            // keeps LDS <= 40 KB: 4 blocks / CU
-    static constexpr int SW = HF_TX + 2 * HF_E + 4 * S, SH = TY + 2 * HF_E + 4 * S;   // smooth tile
-    static constexpr int DW = HF_TX + 2 * HF_E + 2 * S, DH = TY + 2 * HF_E + 2 * S;   // Lx / Ly tile
-    static constexpr int EW = HF_TX + 2 * HF_E, EH = TY + 2 * HF_E;                   // det tile
+    // tile extents (W* = columns in use); the LDS pitches SW / DW / EW are the widths rounded up to odd
+    static constexpr int WS = HF_TX + 2 * HF_E + 4 * S, SH = TY + 2 * HF_E + 4 * S;   // smooth tile
+    static constexpr int WD = HF_TX + 2 * HF_E + 2 * S, DH = TY + 2 * HF_E + 2 * S;   // Lx / Ly tile
+    static constexpr int WE = HF_TX + 2 * HF_E, EH = TY + 2 * HF_E;                   // det tile
+    static constexpr int SW = WS | 1, DW = WD | 1, EW = WE | 1;
     static constexpr int NR = (SH + 3) / 4;                                          // smooth rows per wave
 };
 
@@ -46,7 +48,7 @@ __device__ __forceinline__ void hess_fetch(HessPrefetch<S>& P, const float* __re
         if (r < G::SH) {
             const float* row = s + (long)hak_refl(sy0 + r, h) * p;
             P.a[i] = row[ca];
-            if (lane < G::SW - 64) P.b[i] = row[cb];
+            if (lane < G::WS - 64) P.b[i] = row[cb];
         }
     }
 }
@@ -60,7 +62,7 @@ __device__ __forceinline__ void hess_commit(const HessPrefetch<S>& P, float* sm,
         const int r = wv + 4 * i;
         if (r < G::SH) {
             sm[r * G::SW + lane] = P.a[i];
-            if (lane < G::SW - 64) sm[r * G::SW + 64 + lane] = P.b[i];
+            if (lane < G::WS - 64) sm[r * G::SW + 64 + lane] = P.b[i];
         }
     }
 }
@@ -88,63 +90,131 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
     const int sx0 = x0 - HF_E - 2 * S, sy0 = y0 - HF_E - 2 * S;     // image coordinates of sm[0][0]
     const int dx0 = x0 - HF_E - S, dy0 = y0 - HF_E - S;             // image coordinates of sx[0][0]
     const int ex0 = x0 - HF_E, ey0 = y0 - HF_E;                     // image coordinates of the det tile
-    // ---- Lx, Ly on the derivative tile, centre -> HBM.  Work items are the DH x DW tile positions
-    // flattened over the 256 threads (keeps every lane busy; a lane = column mapping would spend a
-    // whole extra pass on the few halo columns beyond 64).
-    const int tid = threadIdx.x;
-#pragma unroll 4
-    for (int idx = tid; idx < DH * DW; idx += 256) {
-        const int r = idx / DW, c = idx - r * DW;
-        const int x = dx0 + c, y = dy0 + r;
-        if (!INTERIOR && (x < 0 || x >= w || y < 0 || y >= h)) continue;   // derivatives exist only inside the image
-        const int c1 = c + S;                                       // sm columns of x-S, x, x+S
-        const int c0 = INTERIOR ? c : hak_refl(x - S, w) - sx0;
-        const int c2 = INTERIOR ? c + 2 * S : hak_refl(x + S, w) - sx0;
-        const int r1 = (r + S) * SW;
-        const int r0 = INTERIOR ? r * SW : (hak_refl(y - S, h) - sy0) * SW;
-        const int r2 = INTERIOR ? (r + 2 * S) * SW : (hak_refl(y + S, h) - sy0) * SW;
-        const float ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
-        const float cl = sm[r1 + c0], cr = sm[r1 + c2];
-        const float ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
-        const float vx = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);           // akazed.cu:1294
-        const float vy = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);           // akazed.cu:1295
-        sx[idx] = vx;
-        sy[idx] = vy;
-        if (c >= S + HF_E && c < S + HF_E + HF_TX && r >= S + HF_E && r < S + HF_E + TY) {
-            ox[(long)y * p + x] = vx;
-            oy[(long)y * p + x] = vy;
+    // Work mapping (the kernel was VALU-issue-bound on index arithmetic when tile positions were flattened
+    // over the block): every pass keeps ONE coordinate wave-uniform.
+    //   main pass  -- the 64 output columns: lane = column, rows dealt round-robin to the four waves; row
+    //                 indices, the reflect rule in y and the global row pointers are SALU work and an
+    //                 INTERIOR tile addresses LDS with one per-thread base plus immediates;
+    //   halo pass  -- the few columns either side that only feed the next stage: lane = ROW, one column per
+    //                 wave iteration (dealt from wave 3 downwards: those waves have the shorter row share).
+    // Odd LDS pitches (HessGeo) keep the lane = row accesses conflict-free.
+    const int x = x0 + lane;
+    const bool xin = INTERIOR || x < w;
+    // ---- Lx, Ly on the derivative tile, centre -> HBM
+    {
+        constexpr int CM = S + HF_E;                                // derivative-tile column of output column 0
+        const int c1 = lane + CM + S;                               // sm column of x
+        const int c0 = INTERIOR ? c1 - S : hak_refl(x - S, w) - sx0;
+        const int c2 = INTERIOR ? c1 + S : hak_refl(x + S, w) - sx0;
+#pragma unroll 2
+        for (int i = 0; i < (DH + 3) / 4; i++) {
+            const int r = wv + 4 * i;
+            if (r >= DH) break;
+            const int y = dy0 + r;
+            if (!INTERIOR && (y < 0 || y >= h)) continue;
+            const int r1 = (r + S) * SW;
+            const int r0 = INTERIOR ? r * SW : (hak_refl(y - S, h) - sy0) * SW;
+            const int r2 = INTERIOR ? (r + 2 * S) * SW : (hak_refl(y + S, h) - sy0) * SW;
+            if (xin) {
+                const float ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
+                const float cl = sm[r1 + c0], cr = sm[r1 + c2];
+                const float ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
+                const float vx = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);       // akazed.cu:1294
+                const float vy = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);       // akazed.cu:1295
+                sx[r * DW + CM + lane] = vx;
+                sy[r * DW + CM + lane] = vy;
+                if (r >= S + HF_E && r < S + HF_E + TY) {
+                    float* rx = ox + (long)y * p + x0;
+                    float* ry = oy + (long)y * p + x0;
+                    rx[lane] = vx;
+                    ry[lane] = vy;
+                }
+            }
+        }
+        // halo columns: lane = derivative-tile row
+        const int yr = dy0 + lane;
+        const bool rin = lane < DH && (INTERIOR || (yr >= 0 && yr < h));
+        const int q1 = (lane + S) * SW;
+        const int q0 = INTERIOR ? lane * SW : (hak_refl(yr - S, h) - sy0) * SW;
+        const int q2 = INTERIOR ? (lane + 2 * S) * SW : (hak_refl(yr + S, h) - sy0) * SW;
+        for (int k = 3 - wv; k < 2 * CM; k += 4) {
+            const int c = k < CM ? k : k + HF_TX;
+            const int xx = dx0 + c;
+            if (!INTERIOR && (xx < 0 || xx >= w)) continue;
+            const int h1 = c + S;
+            const int h0 = INTERIOR ? c : hak_refl(xx - S, w) - sx0;
+            const int h2 = INTERIOR ? c + 2 * S : hak_refl(xx + S, w) - sx0;
+            if (rin) {
+                const float ul = sm[q0 + h0], uc = sm[q0 + h1], ur = sm[q0 + h2];
+                const float cl = sm[q1 + h0], cr = sm[q1 + h2];
+                const float ll = sm[q2 + h0], lc = sm[q2 + h1], lr = sm[q2 + h2];
+                sx[lane * DW + c] = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);
+                sy[lane * DW + c] = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);
+            }
         }
     }
     hak_lds_barrier();                                                // sm is dead from here: the det tile reuses it
-    // ---- determinant on the det tile (flattened the same way), centre -> HBM
+    // ---- determinant on the det tile, centre -> HBM
     float* dt = sm;
-#pragma unroll 3
-    for (int idx = tid; idx < EH * EW; idx += 256) {
-        const int r = idx / EW, c = idx - r * EW;
-        const int x = ex0 + c, y = ey0 + r;
-        if (!INTERIOR && (x < 0 || x >= w || y < 0 || y >= h)) continue;
-        const int c1 = c + S;                                       // sx columns of x-S, x, x+S
-        const int c0 = INTERIOR ? c : hak_refl(x - S, w) - dx0;
-        const int c2 = INTERIOR ? c + 2 * S : hak_refl(x + S, w) - dx0;
-        const int r1 = (r + S) * DW;
-        const int r0 = INTERIOR ? r * DW : (hak_refl(y - S, h) - dy0) * DW;
-        const int r2 = INTERIOR ? (r + 2 * S) * DW : (hak_refl(y + S, h) - dy0) * DW;
-        const float xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
-        const float xcl = sx[r1 + c0], xcr = sx[r1 + c2];
-        const float xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
-        const float yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
-        const float yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
-        const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
-        const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
-        const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
-        const float d = dxx * dyy - dxy * dxy;                                    // akazed.cu:1330
-        dt[idx] = d;
-        if (c >= HF_E && c < HF_E + HF_TX && r >= HF_E && r < HF_E + TY) od[(long)y * p + x] = d;
+    {
+        const int c1 = lane + HF_E + S;                             // sx column of x
+        const int c0 = INTERIOR ? c1 - S : hak_refl(x - S, w) - dx0;
+        const int c2 = INTERIOR ? c1 + S : hak_refl(x + S, w) - dx0;
+#pragma unroll 2
+        for (int i = 0; i < (EH + 3) / 4; i++) {
+            const int r = wv + 4 * i;
+            if (r >= EH) break;
+            const int y = ey0 + r;
+            if (!INTERIOR && (y < 0 || y >= h)) continue;
+            const int r1 = (r + S) * DW;
+            const int r0 = INTERIOR ? r * DW : (hak_refl(y - S, h) - dy0) * DW;
+            const int r2 = INTERIOR ? (r + 2 * S) * DW : (hak_refl(y + S, h) - dy0) * DW;
+            if (xin) {
+                const float xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
+                const float xcl = sx[r1 + c0], xcr = sx[r1 + c2];
+                const float xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
+                const float yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
+                const float yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
+                const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
+                const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
+                const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
+                const float d = dxx * dyy - dxy * dxy;                                // akazed.cu:1330
+                dt[r * EW + HF_E + lane] = d;
+                if (r >= HF_E && r < HF_E + TY) {
+                    float* rd = od + (long)y * p + x0;
+                    rd[lane] = d;
+                }
+            }
+        }
+        // the two halo columns of the det tile: lane = det-tile row
+        const int yr = ey0 + lane;
+        const bool rin = lane < EH && (INTERIOR || (yr >= 0 && yr < h));
+        const int q1 = (lane + S) * DW;
+        const int q0 = INTERIOR ? lane * DW : (hak_refl(yr - S, h) - dy0) * DW;
+        const int q2 = INTERIOR ? (lane + 2 * S) * DW : (hak_refl(yr + S, h) - dy0) * DW;
+        for (int k = 3 - wv; k < 2 * HF_E; k += 4) {
+            const int c = k < HF_E ? k : k + HF_TX;
+            const int xx = ex0 + c;
+            if (!INTERIOR && (xx < 0 || xx >= w)) continue;
+            const int h1 = c + S;
+            const int h0 = INTERIOR ? c : hak_refl(xx - S, w) - dx0;
+            const int h2 = INTERIOR ? c + 2 * S : hak_refl(xx + S, w) - dx0;
+            if (rin) {
+                const float xul = sx[q0 + h0], xuc = sx[q0 + h1], xur = sx[q0 + h2];
+                const float xcl = sx[q1 + h0], xcr = sx[q1 + h2];
+                const float xll = sx[q2 + h0], xlc = sx[q2 + h1], xlr = sx[q2 + h2];
+                const float yul = sy[q0 + h0], yuc = sy[q0 + h1], yur = sy[q0 + h2];
+                const float yll = sy[q2 + h0], ylc = sy[q2 + h1], ylr = sy[q2 + h2];
+                const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
+                const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
+                const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
+                dt[lane * EW + c] = dxx * dyy - dxy * dxy;
+            }
+        }
     }
     if (ex.maps == nullptr) return;                                 // (uniform) determinant only
     hak_lds_barrier();
     // ---- extrema of this level on the output tile (akazed.cu:1346-1373)
-    const int x = x0 + lane;
     const bool xok = x >= ex.psz && (int)(x - ex.border + 0.5f) - 1 >= 0 && (int)(x + ex.border + 0.5f) + 1 < w;
     for (int rr = wv; rr < TY; rr += 4) {
         const int y = y0 + rr;
@@ -179,20 +249,29 @@ template <int S>
 __global__ __launch_bounds__(256) void k_hessian_fused(const float* __restrict__ src, float* __restrict__ lx,
                                                        float* __restrict__ ly, float* __restrict__ det, long stride,
                                                        int w, int h, int p, float fac1, float fac2, int tiles_per_block,
-                                                       HakExtremaArgs ex)
+                                                       int ntx, int nby, int nimg, HakExtremaArgs ex)
 {
     using G = HessGeo<S>;
     __shared__ float sm[G::SH * G::SW];
     __shared__ float sx[G::DH * G::DW];
     __shared__ float sy[G::DH * G::DW];
-    const float* s = src + (long)blockIdx.z * stride;
-    float* ox = lx + (long)blockIdx.z * stride;
-    float* oy = ly + (long)blockIdx.z * stride;
-    float* od = det + (long)blockIdx.z * stride;
+    // XCD-aware block order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
+    // its own L2.  Tiles that share halos (one image) are therefore given ids that are congruent mod 8, so a
+    // whole image is processed on one XCD and the halo re-reads hit that XCD's L2.
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nb = ntx * nby;
+    const int img = (j / nb) * 8 + xcd;
+    if (img >= nimg) return;
+    const int t = j - (j / nb) * nb;
+    const int bx = t % ntx, by = t / ntx;
+    const float* s = src + (long)img * stride;
+    float* ox = lx + (long)img * stride;
+    float* oy = ly + (long)img * stride;
+    float* od = det + (long)img * stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = blockIdx.x * HF_TX;
-    const int ty0 = blockIdx.y * tiles_per_block;
+    const int x0 = bx * HF_TX;
+    const int ty0 = by * tiles_per_block;
     const int ntiles = (h + G::TY - 1) / G::TY;
     const int ty1 = min(ty0 + tiles_per_block, ntiles);
     constexpr int HALO = HF_E + 2 * S;
@@ -205,8 +284,8 @@ __global__ __launch_bounds__(256) void k_hessian_fused(const float* __restrict__
         hak_lds_barrier();
         if (ty + 1 < ty1) hess_fetch<S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
-        if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, blockIdx.z);
-        else hessian_tile<S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, blockIdx.z);
+        if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
+        else hessian_tile<S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
     }
 }
 
@@ -227,8 +306,9 @@ static void launch_fused(hipStream_t st, const float* src, float* lx, float* ly,
     // tiles per persistent block: long runs while the grid still covers the chip several times
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
-    dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
-    k_hessian_fused<S><<<grid, 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb, ex);
+    const int nby = (nty + tpb - 1) / tpb;
+    const long nblocks = 8L * ((nimg + 7) / 8) * ntx * nby;
+    k_hessian_fused<S><<<dim3((unsigned)nblocks), 256, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb, ntx, nby, nimg, ex);
 }
 
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
