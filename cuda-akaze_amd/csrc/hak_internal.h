@@ -68,6 +68,21 @@ __device__ __forceinline__ int hak_refl(int i, int m)
 // store of the wave -- which serialises a register prefetch and exposes the store latency at each
 // phase boundary of the persistent tile kernels.  Use this between phases that only exchange data
 // through LDS; global results are complete at kernel end as usual.
+// XCD-aware block order.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each has its own
+// L2).  A 1-D grid of hak_xcd_grid() blocks is decoded so that all blocks of one image carry ids congruent mod 8:
+// an image's tiles (which share halos) then run on one XCD.  Returns false for the padding blocks (nimg % 8 != 0).
+__device__ __forceinline__ bool hak_xcd_decode(int nbx, int nby, int nimg, int& bx, int& by, int& img)
+{
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int nb = nbx * nby;
+    const int g = j / nb, t = j - g * nb;
+    img = g * 8 + xcd;
+    by = t / nbx;
+    bx = t - by * nbx;
+    return img < nimg;
+}
+static inline unsigned hak_xcd_grid(int nbx, int nby, int nimg) { return 8u * (unsigned)((nimg + 7) / 8) * (unsigned)nbx * (unsigned)nby; }
+
 __device__ __forceinline__ void hak_lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");

@@ -88,7 +88,7 @@ __device__ __forceinline__ void bs_colpass1(const float* rowp, float* sm, const 
 template <int R>
 __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, long img_stride, int sp,
                                                 float* __restrict__ lt, long stride, int w, int h, int p,
-                                                BsTaps t, HakImgState* state, int tiles_per_block)
+                                                BsTaps t, HakImgState* state, int tiles_per_block, int nbx, int nby, int nimg)
 {
     constexpr int H = R < 3 ? 3 : R;
     using G = BsGeo<H>;
@@ -96,11 +96,13 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     __shared__ float rowb[G::RH * BS_TX];             // base row pass (all tile rows, output columns)
     __shared__ float rowp[G::PH * G::PW];             // sigma=1 row pass
     __shared__ float wmax[4];
-    const float* s = img + (long)blockIdx.z * img_stride;
-    float* o = lt + (long)blockIdx.z * stride;
+    int bx, by, im;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
+    const float* s = img + (long)im * img_stride;
+    float* o = lt + (long)im * stride;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BS_TX;
-    const int ty0 = blockIdx.y * tiles_per_block;
+    const int x0 = bx * BS_TX;
+    const int ty0 = by * tiles_per_block;
     const int ty1 = min(ty0 + tiles_per_block, (h + BS_TY - 1) / BS_TY);
     float pf[G::NPF];
     float tmax = 0.f;
@@ -147,26 +149,28 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     hak_lds_barrier();
     if (tid == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.f) atomicMax(&state[blockIdx.z].hmax_bits, __float_as_uint(m));   // D2: the intended reduction
+        if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));   // D2: the intended reduction
     }
 }
 
 // ---- pass B: 300-bin histogram of |Scharr(G(1) * img)|
 __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, long img_stride, int sp,
-                                                int w, int h, BsTaps t, HakImgState* state, int tiles_per_block)
+                                                int w, int h, BsTaps t, HakImgState* state, int tiles_per_block, int nbx, int nby, int nimg)
 {
     constexpr int H = 3;
     using G = BsGeo<H>;
     __shared__ float raw[G::RH * G::RW];
     __shared__ float rowp[G::PH * G::PW];
     __shared__ int shist[HAK_NBINS];
-    const float* s = img + (long)blockIdx.z * img_stride;
+    int bx, by, im;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
+    const float* s = img + (long)im * img_stride;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * BS_TX;
-    const int ty0 = blockIdx.y * tiles_per_block;
+    const int x0 = bx * BS_TX;
+    const int ty0 = by * tiles_per_block;
     const int ty1 = min(ty0 + tiles_per_block, (h + BS_TY - 1) / BS_TY);
     for (int i = tid; i < HAK_NBINS; i += 256) shist[i] = 0;
-    const float hmax = __uint_as_float(state[blockIdx.z].hmax_bits);
+    const float hmax = __uint_as_float(state[im].hmax_bits);
     const float hfactor = HAK_NBINS / hmax;                         // akazed.cu:2450
     float pf[G::NPF];
     if (ty0 < ty1) bs_fetch<H>(pf, s, w, h, sp, x0, ty0 * BS_TY, tid);
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
     }
     hak_lds_barrier();
     for (int i = tid; i < HAK_NBINS; i += 256)
-        if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
+        if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
 }
 
 // host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371)
@@ -234,14 +238,15 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     const int ntx = (w + BS_TX - 1) / BS_TX, nty = (h + BS_TY - 1) / BS_TY;
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
-    dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
+    const int nby = (nty + tpb - 1) / tpb;
+    const unsigned grid = hak_xcd_grid(ntx, nby, nimg);
     switch (R) {
-    case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
-    case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
-    case 4: k_base_a<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
-    default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb); break;
+    case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    case 4: k_base_a<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
     }
-    k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb);
+    k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb, ntx, nby, nimg);
     k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
     return true;
 }

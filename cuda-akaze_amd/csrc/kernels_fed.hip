@@ -183,15 +183,17 @@ __device__ __forceinline__ void fed_strip(const float* __restrict__ L, const flo
 template <int NS>
 __global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src, const float* __restrict__ flow,
                                                    float* __restrict__ dst, long stride, int w, int h, int p,
-                                                   FedFacs<NS> fac, int ry, int xv, int hx)
+                                                   FedFacs<NS> fac, int ry, int xv, int hx, int nbx, int nby, int nimg)
 {
-    const float* L = src + (long)blockIdx.z * stride;
-    const float* G = flow + (long)blockIdx.z * stride;
-    float* D = dst + (long)blockIdx.z * stride;
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    const float* L = src + (long)img * stride;
+    const float* G = flow + (long)img * stride;
+    float* D = dst + (long)img * stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> row bookkeeping in SGPRs
-    const int x0 = blockIdx.x * xv - hx + 4 * lane;         // first pixel of this lane (may lie outside the image)
-    const int ybeg = (blockIdx.y * 4 + wv) * ry;
+    const int x0 = bx * xv - hx + 4 * lane;                 // first pixel of this lane (may lie outside the image)
+    const int ybeg = (by * 4 + wv) * ry;
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= hx && 4 * lane < hx + xv && x0 < w && x0 >= 0;
@@ -263,8 +265,8 @@ static void launch_multi(hipStream_t st, const float* src, const float* flow, fl
     // rows per wave: tall strips amortise the 2*NS warm-up rows; shrink while the grid cannot fill the chip
     int ry = 64;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
-    dim3 grid(gx, (h + 4 * ry - 1) / (4 * ry), nimg);
-    k_fed_multi<NS><<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx);
+    const int gy = (h + 4 * ry - 1) / (4 * ry);
+    k_fed_multi<NS><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx, gx, gy, nimg);
 }
 
 // launches needed for n steps at width w when at most max_fuse steps are fused per launch

@@ -41,17 +41,19 @@ __device__ __forceinline__ void sf_fetch(float (&pf)[SF_NPF], const float* __res
 __global__ __launch_bounds__(256) void k_smooth_flow(const float* __restrict__ src, float* __restrict__ smooth,
                                                      float* __restrict__ flow, long stride, int w, int h, int p,
                                                      SfTaps t, int type, const HakImgState* __restrict__ state,
-                                                     int octave, float fixed_ikc, int tiles_per_block)
+                                                     int octave, float fixed_ikc, int tiles_per_block, int nbx, int nby, int nimg)
 {
     __shared__ float raw[SF_RH * SF_RW];     // raw tile; reused for the smooth tile after the row pass
     __shared__ float rowp[SF_RH * SF_PW];
-    const float* s = src + (long)blockIdx.z * stride;
-    float* osm = smooth + (long)blockIdx.z * stride;
-    float* og = flow + (long)blockIdx.z * stride;
-    const float ikc = state ? state[blockIdx.z].ikc[octave] : fixed_ikc;
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    const float* s = src + (long)img * stride;
+    float* osm = smooth + (long)img * stride;
+    float* og = flow + (long)img * stride;
+    const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
     const int tid = threadIdx.x;
-    const int x0 = blockIdx.x * SF_TX;
-    const int ty0 = blockIdx.y * tiles_per_block;
+    const int x0 = bx * SF_TX;
+    const int ty0 = by * tiles_per_block;
     const int ty1 = min(ty0 + tiles_per_block, (h + SF_TY - 1) / SF_TY);
     float pf[SF_NPF];
     if (ty0 < ty1) sf_fetch(pf, s, w, h, p, x0, ty0 * SF_TY, tid);
@@ -118,6 +120,7 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
     const int ntx = (w + SF_TX - 1) / SF_TX, nty = (h + SF_TY - 1) / SF_TY;
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
-    dim3 grid(ntx, (nty + tpb - 1) / tpb, nimg);
-    k_smooth_flow<<<grid, 256, 0, st>>>(src, smooth, flow, stride, w, h, p, t, diffusivity, state, octave, fixed_ikc, tpb);
+    const int nby = (nty + tpb - 1) / tpb;
+    k_smooth_flow<<<hak_xcd_grid(ntx, nby, nimg), 256, 0, st>>>(src, smooth, flow, stride, w, h, p, t, diffusivity, state, octave,
+                                                                fixed_ikc, tpb, ntx, nby, nimg);
 }
