@@ -32,13 +32,15 @@
 template <int NS>
 struct FedFacs { float f[NS]; };
 
-__device__ __forceinline__ float wave_shr1(float v)      // lane i <- lane i-1 (lane 0 keeps its own)
+// bound_ctrl = 1 with a zero `old`: the end lane (no source) reads 0 -- lanes 0 and 63 are strip margin -- and the
+// compiler needs no copy of `v` to seed the destination (an `old = v` shift costs one extra v_mov each)
+__device__ __forceinline__ float wave_shr1(float v)      // lane i <- lane i-1 (lane 0 reads 0)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x138, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float wave_shl1(float v)      // lane i <- lane i+1 (lane 63 keeps its own)
+__device__ __forceinline__ float wave_shl1(float v)      // lane i <- lane i+1 (lane 63 reads 0)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x130, 0xf, 0xf, false));
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
 }
 
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
@@ -86,7 +88,7 @@ __device__ __forceinline__ float4 fed_row(const float4 Lc, const float4 Ln, cons
 // level exactly like the halo), so the body is branch-free except for the final store and the two
 // reflect-101 injections:  row -1 := row 1 (written when row 1 is produced) and row h := row h-2
 // (written at the iteration that would produce row h) -- for every level and for the g-sum ring.
-template <int NS, int U, bool YEDGE>
+template <int NS, int U, bool YEDGE, bool XE>
 __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const float* __restrict__ L,
                                          const float* __restrict__ G, float* __restrict__ D, const int p, const int xl,
                                          const int x0, const int w, const int h,
@@ -105,8 +107,10 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
         S.Gq[pmod(U, PD)] = *reinterpret_cast<const float4*>(G + nrow);
         const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
         GHrow gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
-        gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                    // (g+gW) at x == 0 is (g+gE)
-        gh.h4 = x0 + 3 == w - 1 ? gh.h3 : gh.h4;            // (g+gE) at x == w-1 is (g+gW)
+        if (XE) {                                           // only the strips that hold image column 0 or w-1
+            gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                // (g+gW) at x == 0 is (g+gE)
+            gh.h4 = x0 + 3 == w - 1 ? gh.h3 : gh.h4;        // (g+gE) at x == w-1 is (g+gW)
+        }
         S.GH[pmod(U, GS)] = gh;
         S.GV[pmod(U - 1, GS)] = make_float4(S.gprev.x + g.x, S.gprev.y + g.y, S.gprev.z + g.z, S.gprev.w + g.w);
         S.gprev = g;
@@ -123,7 +127,7 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
 #pragma unroll
     for (int k = 1; k <= NS; k++) {
         const int rho = t - k;
-        const float4 out = fed_row<true>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
+        const float4 out = fed_row<XE>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
                                           S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
                                           S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
         if (k < NS) {
@@ -137,7 +141,7 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
 }
 
 // requires w % 4 == 0 (true for every octave of BASELINE's configs); other widths: k_fed_generic
-template <int NS>
+template <int NS, bool XE>
 __device__ __forceinline__ void fed_strip(const float* __restrict__ L, const float* __restrict__ G,
                                           float* __restrict__ D, int w, int h, int p, const FedFacs<NS>& fac,
                                           int x0, int ybeg, int yend, bool owns)
@@ -163,19 +167,19 @@ __device__ __forceinline__ void fed_strip(const float* __restrict__ L, const flo
     for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 3 / mod 6: static per unrolled body
         // the reflect injections can only fire while some level is at row 1 or row h
         if (tb <= NS || tb + 5 >= h) {
-            fed_iter<NS, 0, true>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 1, true>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 2, true>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 3, true>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 4, true>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 5, true>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 0, true, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, true, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, true, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, true, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, true, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, true, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         } else {
-            fed_iter<NS, 0, false>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 1, false>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 2, false>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 3, false>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 4, false>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 5, false>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 0, false, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 1, false, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 2, false, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 3, false, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 4, false, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<NS, 5, false, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         }
     }
 }
@@ -197,7 +201,8 @@ __global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= hx && 4 * lane < hx + xv && x0 < w && x0 >= 0;
-    fed_strip<NS>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
+    if (bx == 0 || (bx + 1) * xv + hx >= w) fed_strip<NS, true>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
+    else fed_strip<NS, false>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
 }
 
 // any width (w % 4 != 0): ONE step per launch with the per-pixel form of the reference expression;
