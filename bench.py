@@ -264,8 +264,9 @@ def main():
         traffic = None
         tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
         if os.path.exists(tfile) and (w, h, args.octaves) == (1920, 1080, 4):
-            # measured at 16 pairs per launch sequence; every FED launch covers the whole batch, so bytes scale with B
-            traffic = round(json.load(open(tfile))["fed_hbm_bytes_per_launch"] * B / 16.0)
+            # every FED launch covers the whole batch, so bytes scale with B relative to the batch the passes ran at
+            tj = json.load(open(tfile))
+            traffic = round(tj["fed_hbm_bytes_per_launch"] * B / float(tj.get("pairs_per_launch_sequence", 16)))
         roof = {"kernel": "k_fed_multi<NS> (fused FED steps, 12 B/px/step algorithmic)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
