@@ -500,9 +500,13 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 continue;
             }
             const int n = lp.nsteps;
+            // FED cycle in G fused launches (the float path's streaming kernel instantiated for int32) when the width
+            // allows 16-byte rows, else one step per launch; ping-pong Lt <-> tmp so that the last launch lands in Lt
+            const bool fused = (oc.w % 4) == 0;
+            const int G = fused ? hak_fed_groups(n, c->max_fuse, oc.w) : n;
             const int* src;
             if (s == 0) {                                                         // akaze.cpp:640-662
-                int* first = (n % 2 == 0) ? Lt : tmp;
+                int* first = (G % 2 == 0) ? Lt : tmp;
                 hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
                 src = first;
             } else {                                                              // akaze.cpp:664-695
@@ -510,9 +514,13 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 src = A + L.lt(o, s - 1);
             }
             hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
-            for (int k = 0; k < n; k++) {                                         // ping-pong, last step lands in Lt
-                int* dst = ((n - k) % 2 == 1) ? Lt : tmp;
-                hakf_launch_nld_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau[k]);
+            int done = 0;
+            for (int g = 0; g < G; g++) {
+                const int ns = fused ? hak_fed_group_size(n, G, g) : 1;
+                int* dst = ((G - g) % 2 == 1) ? Lt : tmp;
+                if (fused) hakf_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
+                else hakf_launch_nld_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau[done]);
+                done += ns;
                 src = dst;
             }
             hakf_launch_hessian(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);

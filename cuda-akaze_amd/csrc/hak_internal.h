@@ -202,6 +202,8 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
                             const HakImgState* state, int octave, float fixed_ikc);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
+void hakf_launch_fed_group(hipStream_t st, const int* src, const int* flow, int* dst, long stride,
+                           int w, int h, int p, int nimg, const float* tau, int ns);
 int hak_fed_groups(int n, int max_fuse, int w);
 int hak_fed_group_size(int n, int G, int g);
 void hak_launch_fed_group(hipStream_t st, const float* src, const float* flow, float* dst, long stride,

@@ -28,43 +28,65 @@
 // borderAdd, akazed.cu:1251-1254) is applied at EVERY level (mirroring level-0 rows instead would
 // swap the S and N terms and change roundings).
 #include "hak_internal.h"
+#include <type_traits>
 
-template <int NS>
-struct FedFacs { float f[NS]; };
+// The same streaming kernel serves both pipelines: V = float (akaze) and V = int (fastakaze, 16.16 fixed point,
+// akazed.cu:3448-3470).  Integer arithmetic wraps (unsigned add / mul), so every regrouping used below for the float
+// path (shared pair sums, shared flux products, tE + tW = P[x+1] - P[x]) is exact for the int path as well.
+template <typename V> struct FedV;
+template <> struct FedV<float> { using V4 = float4; };
+template <> struct FedV<int> { using V4 = int4; };
+__device__ __forceinline__ float4 mk4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+__device__ __forceinline__ int4 mk4(int a, int b, int c, int d) { return make_int4(a, b, c, d); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ int vadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int vsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int vmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+// L' from the flux sum:  float: fma(0.5*tau, sum, L) (akazed.cu:1263);  int: ((stepfac * (sum >> 16)) >> 16) + L (akazed.cu:3468-3469)
+__device__ __forceinline__ float vstep(float f, float sum, float L) { return fmaf(f, sum, L); }
+__device__ __forceinline__ int vstep(int f, int sum, int L) { return vadd(vmul(f, sum >> 16) >> 16, L); }
+
+template <typename V, int NS>
+struct FedFacs { V f[NS]; };
 
 // bound_ctrl = 1 with a zero `old`: the end lane (no source) reads 0 -- lanes 0 and 63 are strip margin -- and the
 // compiler needs no copy of `v` to seed the destination (an `old = v` shift costs one extra v_mov each)
-__device__ __forceinline__ float wave_shr1(float v)      // lane i <- lane i-1 (lane 0 reads 0)
+__device__ __forceinline__ int wave_shr1(int v)          // lane i <- lane i-1 (lane 0 reads 0)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x138, 0xf, 0xf, true));
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
 }
-__device__ __forceinline__ float wave_shl1(float v)      // lane i <- lane i+1 (lane 63 reads 0)
+__device__ __forceinline__ int wave_shl1(int v)          // lane i <- lane i+1 (lane 63 reads 0)
 {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x130, 0xf, 0xf, true));
+    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
 }
+__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1(__float_as_int(v))); }
+__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(wave_shl1(__float_as_int(v))); }
 
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
 
 // horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 0..4
-struct GHrow { float h0, h1, h2, h3, h4; };
+template <typename V> struct GHrow { V h0, h1, h2, h3, h4; };
 
-template <int NS>
+template <typename V, int NS>
 struct FedState {
+    using V4 = typename FedV<V>::V4;
     static constexpr int GS = 6;        // slots of the g-sum ring (needs NS + 2 <= GS)
-    float4 Lw[NS][3];                   // level k (0 = input): ring of 3 rows, slot = (row - origin) mod 3
-    GHrow GH[GS];                       // ring: horizontal sums of g row r        at slot (r - origin) mod GS
-    float4 GV[GS];                      // ring: g[r] + g[r+1]                     at slot (r - origin) mod GS
-    float4 gprev;                       // g row t-1
+    V4 Lw[NS][3];                       // level k (0 = input): ring of 3 rows, slot = (row - origin) mod 3
+    GHrow<V> GH[GS];                    // ring: horizontal sums of g row r        at slot (r - origin) mod GS
+    V4 GV[GS];                          // ring: g[r] + g[r+1]                     at slot (r - origin) mod GS
+    V4 gprev;                           // g row t-1
     static constexpr int PD = 3;        // prefetch distance in rows (divides the unroll factor 6)
-    float4 Lq[PD], Gq[PD];              // software prefetch ring: rows t .. t+PD-1 in flight
+    V4 Lq[PD], Gq[PD];                  // software prefetch ring: rows t .. t+PD-1 in flight
 };
 
 // one output row (4 px per lane) of one level
-template <bool XEDGE>
-__device__ __forceinline__ float4 fed_row(const float4 Lc, const float4 Ln, const float4 Ls, const GHrow& gh,
-                                          const float4 gvS, const float4 gvN, int x0, int w, float stepfac)
+template <bool XEDGE, typename V, typename V4>
+__device__ __forceinline__ V4 fed_row(const V4 Lc, const V4 Ln, const V4 Ls, const GHrow<V>& gh,
+                                      const V4 gvS, const V4 gvN, int x0, int w, V stepfac)
 {
-    float Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x);
+    V Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x);
     if (XEDGE) {
         // reflect-101 in x: abs(x-1) = 1 at x == 0; borderAdd(x,1,w) = w-2 at x == w-1 (w % 4 == 0 here,
         // so x == w-1 is the lane's last component); the matching g-sums were folded into gh already
@@ -72,14 +94,14 @@ __device__ __forceinline__ float4 fed_row(const float4 Lc, const float4 Ln, cons
         Lr = x0 + 3 == w - 1 ? Lc.z : Lr;
     }
     // d[j] = L[x0+j] - L[x0+j-1], P[j] = h[j] * d[j]
-    const float d0 = Lc.x - Ll, d1 = Lc.y - Lc.x, d2 = Lc.z - Lc.y, d3 = Lc.w - Lc.z, d4 = Lr - Lc.w;
-    const float P0 = gh.h0 * d0, P1 = gh.h1 * d1, P2 = gh.h2 * d2, P3 = gh.h3 * d3, P4 = gh.h4 * d4;
-    float4 o;
+    const V d0 = vsub(Lc.x, Ll), d1 = vsub(Lc.y, Lc.x), d2 = vsub(Lc.z, Lc.y), d3 = vsub(Lc.w, Lc.z), d4 = vsub(Lr, Lc.w);
+    const V P0 = vmul(gh.h0, d0), P1 = vmul(gh.h1, d1), P2 = vmul(gh.h2, d2), P3 = vmul(gh.h3, d3), P4 = vmul(gh.h4, d4);
+    V4 o;
     // ((tE + tW) + tS) + tN ; tE = P[e+1], tW = -P[e]
-    o.x = fmaf(stepfac, ((P1 - P0) + gvS.x * (Ls.x - Lc.x)) + gvN.x * (Ln.x - Lc.x), Lc.x);
-    o.y = fmaf(stepfac, ((P2 - P1) + gvS.y * (Ls.y - Lc.y)) + gvN.y * (Ln.y - Lc.y), Lc.y);
-    o.z = fmaf(stepfac, ((P3 - P2) + gvS.z * (Ls.z - Lc.z)) + gvN.z * (Ln.z - Lc.z), Lc.z);
-    o.w = fmaf(stepfac, ((P4 - P3) + gvS.w * (Ls.w - Lc.w)) + gvN.w * (Ln.w - Lc.w), Lc.w);
+    o.x = vstep(stepfac, vadd(vadd(vsub(P1, P0), vmul(gvS.x, vsub(Ls.x, Lc.x))), vmul(gvN.x, vsub(Ln.x, Lc.x))), Lc.x);
+    o.y = vstep(stepfac, vadd(vadd(vsub(P2, P1), vmul(gvS.y, vsub(Ls.y, Lc.y))), vmul(gvN.y, vsub(Ln.y, Lc.y))), Lc.y);
+    o.z = vstep(stepfac, vadd(vadd(vsub(P3, P2), vmul(gvS.z, vsub(Ls.z, Lc.z))), vmul(gvN.z, vsub(Ln.z, Lc.z))), Lc.z);
+    o.w = vstep(stepfac, vadd(vadd(vsub(P4, P3), vmul(gvS.w, vsub(Ls.w, Lc.w))), vmul(gvN.w, vsub(Ln.w, Lc.w))), Lc.w);
     return o;
 }
 
@@ -88,31 +110,32 @@ __device__ __forceinline__ float4 fed_row(const float4 Lc, const float4 Ln, cons
 // level exactly like the halo), so the body is branch-free except for the final store and the two
 // reflect-101 injections:  row -1 := row 1 (written when row 1 is produced) and row h := row h-2
 // (written at the iteration that would produce row h) -- for every level and for the g-sum ring.
-template <int NS, int U, bool YEDGE, bool XE>
-__device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const float* __restrict__ L,
-                                         const float* __restrict__ G, float* __restrict__ D, const int p, const int xl,
+template <typename V, int NS, int U, bool YEDGE, bool XE>
+__device__ __forceinline__ void fed_iter(FedState<V, NS>& S, const int t, const V* __restrict__ L,
+                                         const V* __restrict__ G, V* __restrict__ D, const int p, const int xl,
                                          const int x0, const int w, const int h,
-                                         const int ybeg, const int yend, const bool owns, const FedFacs<NS>& fac)
+                                         const int ybeg, const int yend, const bool owns, const FedFacs<V, NS>& fac)
 {
-    constexpr int GS = FedState<NS>::GS;
+    using V4 = typename FedV<V>::V4;
+    constexpr int GS = FedState<V, NS>::GS;
     // ---- level 0: input row t arrives (prefetched); request row t+1 (clamped: rows past the image are never used)
     {
-        constexpr int PD = FedState<NS>::PD;
-        const float4 g = S.Gq[pmod(U, PD)];
+        constexpr int PD = FedState<V, NS>::PD;
+        const V4 g = S.Gq[pmod(U, PD)];
         S.Lw[0][pmod(U, 3)] = S.Lq[pmod(U, PD)];
         // bytes in flight, not issue rate, bound this kernel (one row ahead = 2 KB per wave < latency x bandwidth):
         // keep PD rows of L and g outstanding per wave
         const long nrow = (long)min(t + PD, h - 1) * p + xl;
-        S.Lq[pmod(U, PD)] = *reinterpret_cast<const float4*>(L + nrow);
-        S.Gq[pmod(U, PD)] = *reinterpret_cast<const float4*>(G + nrow);
-        const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
-        GHrow gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
+        S.Lq[pmod(U, PD)] = *reinterpret_cast<const V4*>(L + nrow);
+        S.Gq[pmod(U, PD)] = *reinterpret_cast<const V4*>(G + nrow);
+        const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
+        GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         if (XE) {                                           // only the strips that hold image column 0 or w-1
             gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                // (g+gW) at x == 0 is (g+gE)
             gh.h4 = x0 + 3 == w - 1 ? gh.h3 : gh.h4;        // (g+gE) at x == w-1 is (g+gW)
         }
         S.GH[pmod(U, GS)] = gh;
-        S.GV[pmod(U - 1, GS)] = make_float4(S.gprev.x + g.x, S.gprev.y + g.y, S.gprev.z + g.z, S.gprev.w + g.w);
+        S.GV[pmod(U - 1, GS)] = mk4(vadd(S.gprev.x, g.x), vadd(S.gprev.y, g.y), vadd(S.gprev.z, g.z), vadd(S.gprev.w, g.w));
         S.gprev = g;
         if (YEDGE && t == 1) {                              // abs(y-1) = 1: row -1 := row 1, GV[-1] := GV[0]
             S.Lw[0][pmod(U - 2, 3)] = S.Lw[0][pmod(U, 3)];
@@ -127,73 +150,76 @@ __device__ __forceinline__ void fed_iter(FedState<NS>& S, const int t, const flo
 #pragma unroll
     for (int k = 1; k <= NS; k++) {
         const int rho = t - k;
-        const float4 out = fed_row<XE>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
-                                          S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
-                                          S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
+        const V4 out = fed_row<XE, V, V4>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
+                                           S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
+                                           S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
         if (k < NS) {
             S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
         } else if (rho >= ybeg && rho < yend && owns) {
-            *reinterpret_cast<float4*>(D + (long)rho * p + x0) = out;
+            *reinterpret_cast<V4*>(D + (long)rho * p + x0) = out;
         }
     }
 }
 
 // requires w % 4 == 0 (true for every octave of BASELINE's configs); other widths: k_fed_generic
-template <int NS, bool XE>
-__device__ __forceinline__ void fed_strip(const float* __restrict__ L, const float* __restrict__ G,
-                                          float* __restrict__ D, int w, int h, int p, const FedFacs<NS>& fac,
+template <typename V, int NS, bool XE>
+__device__ __forceinline__ void fed_strip(const V* __restrict__ L, const V* __restrict__ G,
+                                          V* __restrict__ D, int w, int h, int p, const FedFacs<V, NS>& fac,
                                           int x0, int ybeg, int yend, bool owns)
 {
+    using V4 = typename FedV<V>::V4;
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
     const int t0 = max(0, ybeg - NS);                       // first input row; level k is exact from row t0 + k (or 0)
     const int tend = min(yend - 1, h - 1) + NS;             // iteration that emits the strip's last output row
-    FedState<NS> S;
+    FedState<V, NS> S;
+    const V z = 0;
 #pragma unroll
-    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = mk4(z, z, z, z);
 #pragma unroll
-    for (int i = 0; i < FedState<NS>::GS; i++) {
-        S.GH[i] = GHrow{0.f, 0.f, 0.f, 0.f, 0.f};
-        S.GV[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = 0; i < FedState<V, NS>::GS; i++) {
+        S.GH[i] = GHrow<V>{z, z, z, z, z};
+        S.GV[i] = mk4(z, z, z, z);
     }
-    S.gprev = make_float4(0.f, 0.f, 0.f, 0.f);
+    S.gprev = mk4(z, z, z, z);
 #pragma unroll
-    for (int i = 0; i < FedState<NS>::PD; i++) {
+    for (int i = 0; i < FedState<V, NS>::PD; i++) {
         const long row = (long)min(t0 + i, h - 1) * p + xl;
-        S.Lq[i] = *reinterpret_cast<const float4*>(L + row);
-        S.Gq[i] = *reinterpret_cast<const float4*>(G + row);
+        S.Lq[i] = *reinterpret_cast<const V4*>(L + row);
+        S.Gq[i] = *reinterpret_cast<const V4*>(G + row);
     }
     for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 3 / mod 6: static per unrolled body
         // the reflect injections can only fire while some level is at row 1 or row h
         if (tb <= NS || tb + 5 >= h) {
-            fed_iter<NS, 0, true, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 1, true, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 2, true, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 3, true, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 4, true, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 5, true, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 0, true, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 1, true, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 2, true, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 3, true, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 4, true, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 5, true, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         } else {
-            fed_iter<NS, 0, false, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 1, false, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 2, false, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 3, false, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 4, false, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
-            fed_iter<NS, 5, false, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 0, false, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 1, false, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 2, false, XE>(S, tb + 2, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 3, false, XE>(S, tb + 3, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 4, false, XE>(S, tb + 4, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
+            fed_iter<V, NS, 5, false, XE>(S, tb + 5, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
         }
     }
 }
 
-template <int NS>
-__global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src, const float* __restrict__ flow,
-                                                   float* __restrict__ dst, long stride, int w, int h, int p,
-                                                   FedFacs<NS> fac, int ry, int xv, int hx, int nbx, int nby, int nimg)
+// grid: hak_xcd_grid(strips, strip-row groups, images); a block's four waves take four consecutive row segments
+template <typename V, int NS>
+__global__ __launch_bounds__(256) void k_fed_multi(const V* __restrict__ src, const V* __restrict__ flow,
+                                                   V* __restrict__ dst, long stride, int w, int h, int p,
+                                                   FedFacs<V, NS> fac, int ry, int xv, int hx, int nbx, int nby, int nimg)
 {
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
-    const float* L = src + (long)img * stride;
-    const float* G = flow + (long)img * stride;
-    float* D = dst + (long)img * stride;
+    const V* L = src + (long)img * stride;
+    const V* G = flow + (long)img * stride;
+    V* D = dst + (long)img * stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);     // wave-uniform -> row bookkeeping in SGPRs
     const int x0 = bx * xv - hx + 4 * lane;                 // first pixel of this lane (may lie outside the image)
@@ -201,8 +227,8 @@ __global__ __launch_bounds__(256) void k_fed_multi(const float* __restrict__ src
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= hx && 4 * lane < hx + xv && x0 < w && x0 >= 0;
-    if (bx == 0 || (bx + 1) * xv + hx >= w) fed_strip<NS, true>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
-    else fed_strip<NS, false>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
+    if (bx == 0 || (bx + 1) * xv + hx >= w) fed_strip<V, NS, true>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
+    else fed_strip<V, NS, false>(L, G, D, w, h, p, fac, x0, ybeg, yend, owns);
 }
 
 // any width (w % 4 != 0): ONE step per launch with the per-pixel form of the reference expression;
@@ -258,20 +284,23 @@ __global__ __launch_bounds__(256) void k_fed_generic(const float* __restrict__ s
     }
 }
 
-template <int NS>
-static void launch_multi(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
+template <typename V, int NS>
+static void launch_multi(hipStream_t st, const V* src, const V* flow, V* dst, long stride,
                          int w, int h, int p, int nimg, const float* tau)
 {
-    FedFacs<NS> fac;
-    for (int k = 0; k < NS; k++) fac.f[k] = 0.5f * tau[k];          // akazed.cu:2515
-    const int hx = 4;                                               // x halo >= NS, multiple of 4 (float4 alignment)
+    FedFacs<V, NS> fac;
+    for (int k = 0; k < NS; k++) {
+        if constexpr (std::is_same<V, float>::value) fac.f[k] = 0.5f * tau[k];      // akazed.cu:2515
+        else fac.f[k] = (int)(0.5f * tau[k] * 65536 + 0.5f);                        // akazed.cu:4235
+    }
+    const int hx = 4;                                               // x halo >= NS, multiple of 4 (16-byte alignment)
     const int xv = 256 - 2 * hx;
     const int gx = (w + xv - 1) / xv;
     // rows per wave: tall strips amortise the 2*NS warm-up rows; shrink while the grid cannot fill the chip
     int ry = 64;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (h + 4 * ry - 1) / (4 * ry);
-    k_fed_multi<NS><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx, gx, gy, nimg);
+    k_fed_multi<V, NS><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx, gx, gy, nimg);
 }
 
 // launches needed for n steps at width w when at most max_fuse steps are fused per launch
@@ -303,9 +332,22 @@ void hak_launch_fed_group(hipStream_t st, const float* src, const float* flow, f
         return;
     }
     switch (ns) {
-    case 1: launch_multi<1>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
-    case 2: launch_multi<2>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
-    case 3: launch_multi<3>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
-    default: launch_multi<4>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 1: launch_multi<float, 1>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 2: launch_multi<float, 2>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 3: launch_multi<float, 3>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    default: launch_multi<float, 4>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    }
+}
+
+// integer FAST path (fastakaze::hNldStep, akazed.cu:4231-4238): ns fused 16.16 steps src -> dst; requires w % 4 == 0
+// (other widths: the one-step kf_nld_step of kernels_fast.hip)
+void hakf_launch_fed_group(hipStream_t st, const int* src, const int* flow, int* dst, long stride,
+                           int w, int h, int p, int nimg, const float* tau, int ns)
+{
+    switch (ns) {
+    case 1: launch_multi<int, 1>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 2: launch_multi<int, 2>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    case 3: launch_multi<int, 3>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
+    default: launch_multi<int, 4>(st, src, flow, dst, stride, w, h, p, nimg, tau); break;
     }
 }
