@@ -495,8 +495,11 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
                 hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
                 hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
-                hakf_launch_hessian(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-                hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+                if (!hakf_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                                               lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
+                    hakf_launch_hessian(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                    hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+                }
                 continue;
             }
             const int n = lp.nsteps;
@@ -523,8 +526,11 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 done += ns;
                 src = dst;
             }
-            hakf_launch_hessian(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-            hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+            if (!hakf_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                                           lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
+                hakf_launch_hessian(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+            }
         }
     }
     hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts, 1);

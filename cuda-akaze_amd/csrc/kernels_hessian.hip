@@ -19,6 +19,22 @@
 // Same per-pixel expressions and reflect-101 index rule as the reference (akazed.cu:1284-1295,
 // 1326-1330, 1346-1373).
 #include "hak_internal.h"
+#include <type_traits>
+
+// The kernel is shared by both pipelines: V = float (akaze) and V = int (fastakaze 16.16 fixed point,
+// akazed.cu:3339-3403: every weighted sum is followed by >> 16; the determinant is not shifted).
+__device__ __forceinline__ float hs_d(float f1, float f2, float a, float b) { return f1 * a + f2 * b; }
+__device__ __forceinline__ int hs_d(int f1, int f2, int a, int b)
+{
+    return (int)((unsigned)f1 * (unsigned)a + (unsigned)f2 * (unsigned)b) >> 16;
+}
+__device__ __forceinline__ float hs_det(float dxx, float dyy, float dxy) { return dxx * dyy - dxy * dxy; }
+__device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
+{
+    return (int)((unsigned)dxx * (unsigned)dyy - (unsigned)dxy * (unsigned)dxy);
+}
+__device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
+__device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
 
 #define HF_TX 64
 #define HF_NW 4                                  // waves per block (8 measured slower: 4.28 vs 3.55 ms)
@@ -33,11 +49,11 @@ template <int S> struct HessGeo {
     static constexpr int NR = (SH + HF_NW - 1) / HF_NW;                                          // smooth rows per wave
 };
 
-template <int S>
-struct HessPrefetch { float a[HessGeo<S>::NR], b[HessGeo<S>::NR]; };                 // columns lane, 64+lane
+template <typename V, int S>
+struct HessPrefetch { V a[HessGeo<S>::NR], b[HessGeo<S>::NR]; };                 // columns lane, 64+lane
 
-template <int S>
-__device__ __forceinline__ void hess_fetch(HessPrefetch<S>& P, const float* __restrict__ s, int w, int h, int p,
+template <typename V, int S>
+__device__ __forceinline__ void hess_fetch(HessPrefetch<V, S>& P, const V* __restrict__ s, int w, int h, int p,
                                            int x0, int y0, int lane, int wv)
 {
     using G = HessGeo<S>;
@@ -47,15 +63,15 @@ __device__ __forceinline__ void hess_fetch(HessPrefetch<S>& P, const float* __re
     for (int i = 0; i < G::NR; i++) {
         const int r = wv + HF_NW * i;
         if (r < G::SH) {
-            const float* row = s + (long)hak_refl(sy0 + r, h) * p;
+            const V* row = s + (long)hak_refl(sy0 + r, h) * p;
             P.a[i] = row[ca];
             if (lane < G::WS - 64) P.b[i] = row[cb];
         }
     }
 }
 
-template <int S>
-__device__ __forceinline__ void hess_commit(const HessPrefetch<S>& P, float* sm, int lane, int wv)
+template <typename V, int S>
+__device__ __forceinline__ void hess_commit(const HessPrefetch<V, S>& P, V* sm, int lane, int wv)
 {
     using G = HessGeo<S>;
 #pragma unroll
@@ -68,6 +84,7 @@ __device__ __forceinline__ void hess_commit(const HessPrefetch<S>& P, float* sm,
     }
 }
 
+template <typename V>
 struct HakExtremaArgs {
     unsigned long long* maps;       // [nimg][map_stride]
     long map_stride;
@@ -77,14 +94,15 @@ struct HakExtremaArgs {
     int p0;                         // pitch of the full-resolution map
     int octave, layer;
     int psz;                        // (int)borders[octave*ms]     akazed.cu:2572
-    float border, threshold;
+    float border;
+    V threshold;
 };
 
-template <int S, bool INTERIOR>
-__device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ od,
-                                             int w, int h, int p, int x0, int y0, float fac1, float fac2,
-                                             float* __restrict__ sm, float* __restrict__ sx, float* __restrict__ sy, int lane, int wv,
-                                             const HakExtremaArgs& ex, int img)
+template <typename V, int S, bool INTERIOR>
+__device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__ oy, V* __restrict__ od,
+                                             int w, int h, int p, int x0, int y0, V fac1, V fac2,
+                                             V* __restrict__ sm, V* __restrict__ sx, V* __restrict__ sy, int lane, int wv,
+                                             const HakExtremaArgs<V>& ex, int img)
 {
     using G = HessGeo<S>;
     constexpr int SW = G::SW, DW = G::DW, DH = G::DH, EW = G::EW, EH = G::EH, TY = G::TY;
@@ -117,16 +135,16 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             const int r0 = INTERIOR ? r * SW : (hak_refl(y - S, h) - sy0) * SW;
             const int r2 = INTERIOR ? (r + 2 * S) * SW : (hak_refl(y + S, h) - sy0) * SW;
             if (xin) {
-                const float ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
-                const float cl = sm[r1 + c0], cr = sm[r1 + c2];
-                const float ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
-                const float vx = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);       // akazed.cu:1294
-                const float vy = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);       // akazed.cu:1295
+                const V ul = sm[r0 + c0], uc = sm[r0 + c1], ur = sm[r0 + c2];
+                const V cl = sm[r1 + c0], cr = sm[r1 + c2];
+                const V ll = sm[r2 + c0], lc = sm[r2 + c1], lr = sm[r2 + c2];
+                const V vx = hs_d(fac1, fac2, ur + lr - ul - ll, cr - cl);       // akazed.cu:1294
+                const V vy = hs_d(fac1, fac2, lr + ll - ur - ul, lc - uc);       // akazed.cu:1295
                 sx[r * DW + CM + lane] = vx;
                 sy[r * DW + CM + lane] = vy;
                 if (r >= S + HF_E && r < S + HF_E + TY) {
-                    float* rx = ox + (long)y * p + x0;
-                    float* ry = oy + (long)y * p + x0;
+                    V* rx = ox + (long)y * p + x0;
+                    V* ry = oy + (long)y * p + x0;
                     rx[lane] = vx;
                     ry[lane] = vy;
                 }
@@ -146,17 +164,17 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             const int h0 = INTERIOR ? c : hak_refl(xx - S, w) - sx0;
             const int h2 = INTERIOR ? c + 2 * S : hak_refl(xx + S, w) - sx0;
             if (rin) {
-                const float ul = sm[q0 + h0], uc = sm[q0 + h1], ur = sm[q0 + h2];
-                const float cl = sm[q1 + h0], cr = sm[q1 + h2];
-                const float ll = sm[q2 + h0], lc = sm[q2 + h1], lr = sm[q2 + h2];
-                sx[lane * DW + c] = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);
-                sy[lane * DW + c] = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);
+                const V ul = sm[q0 + h0], uc = sm[q0 + h1], ur = sm[q0 + h2];
+                const V cl = sm[q1 + h0], cr = sm[q1 + h2];
+                const V ll = sm[q2 + h0], lc = sm[q2 + h1], lr = sm[q2 + h2];
+                sx[lane * DW + c] = hs_d(fac1, fac2, ur + lr - ul - ll, cr - cl);
+                sy[lane * DW + c] = hs_d(fac1, fac2, lr + ll - ur - ul, lc - uc);
             }
         }
     }
     hak_lds_barrier();                                                // sm is dead from here: the det tile reuses it
     // ---- determinant on the det tile, centre -> HBM
-    float* dt = sm;
+    V* dt = sm;
     {
         const int c1 = lane + HF_E + S;                             // sx column of x
         const int c0 = INTERIOR ? c1 - S : hak_refl(x - S, w) - dx0;
@@ -171,18 +189,18 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             const int r0 = INTERIOR ? r * DW : (hak_refl(y - S, h) - dy0) * DW;
             const int r2 = INTERIOR ? (r + 2 * S) * DW : (hak_refl(y + S, h) - dy0) * DW;
             if (xin) {
-                const float xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
-                const float xcl = sx[r1 + c0], xcr = sx[r1 + c2];
-                const float xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
-                const float yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
-                const float yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
-                const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
-                const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
-                const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
-                const float d = dxx * dyy - dxy * dxy;                                // akazed.cu:1330
+                const V xul = sx[r0 + c0], xuc = sx[r0 + c1], xur = sx[r0 + c2];
+                const V xcl = sx[r1 + c0], xcr = sx[r1 + c2];
+                const V xll = sx[r2 + c0], xlc = sx[r2 + c1], xlr = sx[r2 + c2];
+                const V yul = sy[r0 + c0], yuc = sy[r0 + c1], yur = sy[r0 + c2];
+                const V yll = sy[r2 + c0], ylc = sy[r2 + c1], ylr = sy[r2 + c2];
+                const V dxx = hs_d(fac1, fac2, xur + xlr - xul - xll, xcr - xcl);
+                const V dxy = hs_d(fac1, fac2, xlr + xll - xur - xul, xlc - xuc);
+                const V dyy = hs_d(fac1, fac2, ylr + yll - yur - yul, ylc - yuc);
+                const V d = hs_det(dxx, dyy, dxy);                                // akazed.cu:1330
                 dt[r * EW + HF_E + lane] = d;
                 if (r >= HF_E && r < HF_E + TY) {
-                    float* rd = od + (long)y * p + x0;
+                    V* rd = od + (long)y * p + x0;
                     rd[lane] = d;
                 }
             }
@@ -201,15 +219,15 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             const int h0 = INTERIOR ? c : hak_refl(xx - S, w) - dx0;
             const int h2 = INTERIOR ? c + 2 * S : hak_refl(xx + S, w) - dx0;
             if (rin) {
-                const float xul = sx[q0 + h0], xuc = sx[q0 + h1], xur = sx[q0 + h2];
-                const float xcl = sx[q1 + h0], xcr = sx[q1 + h2];
-                const float xll = sx[q2 + h0], xlc = sx[q2 + h1], xlr = sx[q2 + h2];
-                const float yul = sy[q0 + h0], yuc = sy[q0 + h1], yur = sy[q0 + h2];
-                const float yll = sy[q2 + h0], ylc = sy[q2 + h1], ylr = sy[q2 + h2];
-                const float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
-                const float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
-                const float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
-                dt[lane * EW + c] = dxx * dyy - dxy * dxy;
+                const V xul = sx[q0 + h0], xuc = sx[q0 + h1], xur = sx[q0 + h2];
+                const V xcl = sx[q1 + h0], xcr = sx[q1 + h2];
+                const V xll = sx[q2 + h0], xlc = sx[q2 + h1], xlr = sx[q2 + h2];
+                const V yul = sy[q0 + h0], yuc = sy[q0 + h1], yur = sy[q0 + h2];
+                const V yll = sy[q2 + h0], ylc = sy[q2 + h1], ylr = sy[q2 + h2];
+                const V dxx = hs_d(fac1, fac2, xur + xlr - xul - xll, xcr - xcl);
+                const V dxy = hs_d(fac1, fac2, xlr + xll - xur - xul, xlc - xuc);
+                const V dyy = hs_d(fac1, fac2, ylr + yll - yur - yul, ylc - yuc);
+                dt[lane * EW + c] = hs_det(dxx, dyy, dxy);
             }
         }
     }
@@ -221,8 +239,8 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
         const int y = y0 + rr;
         bool hit = false;
         // threshold first: almost no pixel passes it, so the wave usually skips the neighbourhood test
-        const float* vp = dt + (rr + HF_E) * EW + lane + HF_E;
-        const float v = *vp;
+        const V* vp = dt + (rr + HF_E) * EW + lane + HF_E;
+        const V v = *vp;
         if (__ballot(v > ex.threshold) == 0ull) continue;
         if (v > ex.threshold && xok && y >= ex.psz && (int)(y - ex.border + 0.5f) - 1 >= 0 && (int)(y + ex.border + 0.5f) + 1 < h) {
             hit = v > vp[-EW] && v > vp[EW] && v > vp[-1] && v > vp[1] &&
@@ -235,7 +253,7 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
             base = __builtin_amdgcn_readfirstlane(base);
             if (hit) {
                 const int fx = x << ex.octave, fy = y << ex.octave;
-                const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)ex.layer);
+                const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)ex.layer);
                 atomicMax(&ex.maps[(long)img * ex.map_stride + (long)fy * ex.p0 + fx], key);
                 const long slot = base + __popcll(m & ((1ull << lane) - 1ull));
                 if (slot < ex.cand_cap)
@@ -246,16 +264,16 @@ __device__ __forceinline__ void hessian_tile(float* __restrict__ ox, float* __re
 }
 
 // grid: (x tiles, y tile groups, images); a block walks `tiles_per_block` tiles downwards
-template <int S>
-__global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const float* __restrict__ src, float* __restrict__ lx,
-                                                       float* __restrict__ ly, float* __restrict__ det, long stride,
-                                                       int w, int h, int p, float fac1, float fac2, int tiles_per_block,
-                                                       int ntx, int nby, int nimg, HakExtremaArgs ex)
+template <typename V, int S>
+__global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restrict__ src, V* __restrict__ lx,
+                                                       V* __restrict__ ly, V* __restrict__ det, long stride,
+                                                       int w, int h, int p, V fac1, V fac2, int tiles_per_block,
+                                                       int ntx, int nby, int nimg, HakExtremaArgs<V> ex)
 {
     using G = HessGeo<S>;
-    __shared__ float sm[G::SH * G::SW];
-    __shared__ float sx[G::DH * G::DW];
-    __shared__ float sy[G::DH * G::DW];
+    __shared__ V sm[G::SH * G::SW];
+    __shared__ V sx[G::DH * G::DW];
+    __shared__ V sy[G::DH * G::DW];
     // XCD-aware block order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
     // its own L2.  Tiles that share halos (one image) are therefore given ids that are congruent mod 8, so a
     // whole image is processed on one XCD and the halo re-reads hit that XCD's L2.
@@ -265,10 +283,10 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const float* __res
     if (img >= nimg) return;
     const int t = j - (j / nb) * nb;
     const int bx = t % ntx, by = t / ntx;
-    const float* s = src + (long)img * stride;
-    float* ox = lx + (long)img * stride;
-    float* oy = ly + (long)img * stride;
-    float* od = det + (long)img * stride;
+    const V* s = src + (long)img * stride;
+    V* ox = lx + (long)img * stride;
+    V* oy = ly + (long)img * stride;
+    V* od = det + (long)img * stride;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = bx * HF_TX;
@@ -276,17 +294,17 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const float* __res
     const int ntiles = (h + G::TY - 1) / G::TY;
     const int ty1 = min(ty0 + tiles_per_block, ntiles);
     constexpr int HALO = HF_E + 2 * S;
-    HessPrefetch<S> P;
-    if (ty0 < ty1) hess_fetch<S>(P, s, w, h, p, x0, ty0 * G::TY, lane, wv);
+    HessPrefetch<V, S> P;
+    if (ty0 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, ty0 * G::TY, lane, wv);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * G::TY;
         hak_lds_barrier();                                        // previous tile's readers of sm / sx / sy are done
-        hess_commit<S>(P, sm, lane, wv);
+        hess_commit<V, S>(P, sm, lane, wv);
         hak_lds_barrier();
-        if (ty + 1 < ty1) hess_fetch<S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
+        if (ty + 1 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
-        if (interior) hessian_tile<S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
-        else hessian_tile<S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
+        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
+        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
     }
 }
 
@@ -297,19 +315,35 @@ static void deriv_factors(float& fac1, float& fac2)
     fac2 = wv * fac1;
 }
 
-template <int S>
-static void launch_fused(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
-                         int w, int h, int p, int nimg, const HakExtremaArgs& ex)
+template <typename V, int S>
+static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride,
+                         int w, int h, int p, int nimg, const HakExtremaArgs<V>& ex)
 {
     float f1, f2;
     deriv_factors(f1, f2);
+    V v1, v2;
+    if constexpr (std::is_same<V, float>::value) { v1 = f1; v2 = f2; }
+    else { v1 = (int)(f1 * 65536 + 0.5f); v2 = (int)(f2 * 65536 + 0.5f); }      // akazed.cu:4183-4184
     const int ntx = (w + HF_TX - 1) / HF_TX, nty = (h + HessGeo<S>::TY - 1) / HessGeo<S>::TY;
     // tiles per persistent block: long runs while the grid still covers the chip several times
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
     const long nblocks = 8L * ((nimg + 7) / 8) * ntx * nby;
-    k_hessian_fused<S><<<dim3((unsigned)nblocks), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, f1, f2, tpb, ntx, nby, nimg, ex);
+    k_hessian_fused<V, S><<<dim3((unsigned)nblocks), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex);
+}
+
+template <typename V>
+static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
+{
+    HakExtremaArgs<V> ex{};
+    if (b) {
+        const int layer = octave * L->ms + sub;
+        ex.maps = b->maps; ex.map_stride = b->map_stride; ex.cand = b->cand; ex.cand_cap = b->cand_cap;
+        ex.state = b->state; ex.p0 = L->oct[0].p; ex.octave = octave; ex.layer = layer;
+        ex.psz = (int)htab->borders[octave * L->ms]; ex.border = htab->borders[layer]; ex.threshold = threshold;
+    }
+    return ex;
 }
 
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
@@ -318,21 +352,31 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
-    HakExtremaArgs ex{};
-    if (b) {
-        const int layer = octave * L->ms + sub;
-        ex.maps = b->maps; ex.map_stride = b->map_stride; ex.cand = b->cand; ex.cand_cap = b->cand_cap;
-        ex.state = b->state; ex.p0 = L->oct[0].p; ex.octave = octave; ex.layer = layer;
-        ex.psz = (int)htab->borders[octave * L->ms]; ex.border = htab->borders[layer]; ex.threshold = dthreshold;
-    }
+    const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     switch (step) {
-    case 1: launch_fused<1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 2: launch_fused<2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 3: launch_fused<3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 4: launch_fused<4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 1: launch_fused<float, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 2: launch_fused<float, 2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 3: launch_fused<float, 3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 4: launch_fused<float, 4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
     default: break;
     }
     hak_launch_derivate(st, src, lx, ly, stride, w, h, p, nimg, step);      // dilation > 4: two direct passes
     hak_launch_hessian(st, lx, ly, det, stride, w, h, p, nimg, step);
     return false;
+}
+
+// the integer FAST path's level (fastakaze::hHessianDeterminant + hCalcExtremaMap, akazed.cu:4175-4195, 4260-4285):
+// same kernel on int32 planes.  Returns false for dilation > 4 (caller: kf_derivate / kf_hessian / kf_extrema).
+bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+                               int w, int h, int p, int nimg, int step,
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
+{
+    const HakExtremaArgs<int> ex = extrema_args<int>(b, L, htab, octave, sub, idthreshold);
+    switch (step) {
+    case 1: launch_fused<int, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 2: launch_fused<int, 2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 3: launch_fused<int, 3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 4: launch_fused<int, 4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    default: return false;
+    }
 }
