@@ -307,7 +307,9 @@ def test_fast_path_reference_images(ah, okz, torch, golden, name):
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(noctaves=3, max_scale=3), dict(soffset=1.2), dict(diffusivity=3), dict(upright=True),
-                                dict(descriptor_pattern_size=8)],
+                                dict(descriptor_pattern_size=8), dict(diffusivity=0), dict(diffusivity=2),
+                                dict(derivative_factor=2.5),           # dilation > 4: unfused derivative / extrema kernels
+                                dict(soffset=2.0, derivative_factor=0.6), dict(reordering=False)],
                          ids=lambda k: ",".join(f"{a}={b}" for a, b in k.items()) or "default")
 def test_fast_path_parameter_space(ah, okz, torch, kw):
     u8 = _mg().case_scene(512, 384, 41)

@@ -1,0 +1,212 @@
+"""GPU robustness of the C ABI: error returns instead of faults, degenerate inputs, graph replay with more
+argument sets than cache slots, independent contexts interleaved on separate streams."""
+import ctypes as C
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, assert_points_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def synth():
+    from akaze_hip import synth
+    return synth
+
+
+def _mg():
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    return mg
+
+
+def _detector(ah, w, h, **kw):
+    det = ah.Akazer()
+    det.init((w, h, ah.iAlignUp(w, 128)), **kw)
+    det._make_ctx(w, h)
+    return det
+
+
+def test_bad_arguments_return_errors(ah, torch):
+    w, h = 256, 192
+    p = ah.iAlignUp(w, 128)
+    det = _detector(ah, w, h, max_pts=500, batch=2)
+    img = torch.zeros((2, h, p), dtype=torch.float32, device="cuda")
+    pts = torch.zeros(2 * 500 * 104, dtype=torch.uint8, device="cuda")
+    num = torch.zeros(2, dtype=torch.int32, device="cuda")
+    n = C.c_int(0)
+    lib = ah.lib
+    bad = [
+        lambda: lib.hak_detect_and_compute_batch(det.ctx, None, h * p, p, 2, pts.data_ptr(), num.data_ptr(), 1),
+        lambda: lib.hak_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, p, 3, pts.data_ptr(), num.data_ptr(), 1),
+        lambda: lib.hak_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, w - 1, 2, pts.data_ptr(), num.data_ptr(), 1),
+        lambda: lib.hak_detect_and_compute_batch(None, img.data_ptr(), h * p, p, 2, pts.data_ptr(), num.data_ptr(), 1),
+        lambda: lib.hak_detect_and_compute(det.ctx, img.data_ptr(), p, pts.data_ptr(), 499, C.byref(n), None, 1),
+        lambda: lib.hak_fast_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, p, 0, pts.data_ptr(), num.data_ptr(), 1),
+        lambda: lib.hak_fast_detect_and_compute(det.ctx, None, p, pts.data_ptr(), 500, C.byref(n), None, 1),
+        lambda: lib.hak_match_batch(det.ctx, pts.data_ptr(), None, 1),
+        lambda: lib.hak_match_knn2(None, pts.data_ptr(), 10, pts.data_ptr(), 10, 0, 1, 1, 0, None, None, C.byref(n), None),
+        lambda: lib.hak_match_knn2_batch(det.ctx, pts.data_ptr(), num.data_ptr(), 2, 4, 5, 1, 0, None, num.data_ptr()),
+    ]
+    for i, f in enumerate(bad):
+        assert f() != 0, f"case {i} was accepted"
+        assert lib.hak_last_error(), f"case {i} left no message"
+    # the context is still usable afterwards
+    ah.check(lib.hak_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, p, 2, pts.data_ptr(), num.data_ptr(), 1))
+    ah.check(lib.hak_sync(det.ctx))
+    assert (num.cpu().numpy() == 0).all()
+    cfg = ah.hak_config()
+    lib.hak_default_config(C.byref(cfg))
+    ctx = C.c_void_p()
+    for (cw, ch, field, val) in ((0, 100, None, None), (100, -1, None, None), (79, 200, None, None), (256, 192, "noctaves", 0),
+                                 (256, 192, "max_scale", 0), (256, 192, "noctaves", 99)):
+        c2 = ah.hak_config.from_buffer_copy(cfg)
+        if field:
+            setattr(c2, field, val)
+        assert lib.hak_create(C.byref(c2), cw, ch, C.byref(ctx)) != 0, (cw, ch, field)
+    det.close()
+
+
+@pytest.mark.parametrize("w,h", [(96, 96), (80, 80), (128, 88), (161, 163)])
+def test_degenerate_images_both_paths(ah, okz, torch, synth, w, h):
+    """flat / tiny images: no keypoints, no faults; a small textured one still matches the oracle"""
+    p = ah.iAlignUp(w, 128)
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=300)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, 300, True, True)
+    flat = torch.full((h, p), 0.5, dtype=torch.float32, device="cuda")
+    det.detectAndCompute(flat.data_ptr(), data, (w, h, p), True)
+    assert data.num_pts == 0
+    flat8 = torch.full((h, p), 200, dtype=torch.uint8, device="cuda")
+    det.fastDetectAndCompute(flat8.data_ptr(), data, (w, h, p), True)
+    assert data.num_pts == 0
+    u8 = np.ascontiguousarray(_mg().case_scene(256, 256, 5)[:h, :w])        # the generator needs >= 134 px: crop
+    img = torch.from_numpy(synth.to_float(u8, p)).cuda()
+    det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
+    r = okz.detect_and_compute(synth.to_float(u8, p), w, max_pts=300)
+    assert data.num_pts == len(r.points)
+    if data.num_pts:
+        assert_points_equal(data.h_data[:data.num_pts], r.points)
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    det.fastDetectAndCompute(torch.from_numpy(pad).cuda().data_ptr(), data, (w, h, p), True)
+    rf = okz.fast_detect_and_compute(u8, max_pts=300)
+    assert data.num_pts == len(rf.points)
+    if data.num_pts:
+        assert_points_equal(data.h_data[:data.num_pts], rf.points)
+    ah.freeAkazeData(data)
+    det.close()
+
+
+def test_graph_replay_with_more_argument_sets_than_cache_slots(ah, torch, synth):
+    """six input buffers cycled three times through one context (the graph cache holds four): every call must equal
+    the first result for that buffer, and equal an eager (HAK_GRAPH=0) context's result"""
+    w, h, mp = 480, 360, 1500
+    p = ah.iAlignUp(w, 128)
+    imgs = [torch.from_numpy(synth.to_float(_mg().case_scene(w, h, 100 + i), p)).cuda() for i in range(6)]
+
+    def run(det):
+        data = ah.AkazeData()
+        ah.initAkazeData(data, mp, True, True)
+        outs = [[] for _ in imgs]
+        for rep in range(3):
+            for i, im in enumerate(imgs):
+                det.detectAndCompute(im.data_ptr(), data, (w, h, p), True)
+                outs[i].append(data.h_data[:data.num_pts].copy().tobytes())
+        ah.freeAkazeData(data)
+        return outs
+
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp)
+    graph = run(det)
+    det.close()
+    os.environ["HAK_GRAPH"] = "0"
+    try:
+        det2 = ah.Akazer()
+        det2.init((w, h, p), max_pts=mp)
+        eager = run(det2)
+        det2.close()
+    finally:
+        del os.environ["HAK_GRAPH"]
+    for i in range(len(imgs)):
+        assert len(graph[i][0]) > 104 * 20
+        assert graph[i][0] == graph[i][1] == graph[i][2] == eager[i][0] == eager[i][2]
+    assert len({g[0] for g in graph}) == len(imgs)
+
+
+def test_two_contexts_interleaved_on_their_own_streams(ah, torch, synth):
+    """the bench's pipelining pattern with a parity check: two contexts, batches in flight on both, results equal a
+    context used alone"""
+    w, h, mp, B = 640, 360, 2000, 4
+    p = ah.iAlignUp(w, 128)
+    batches = [np.stack([synth.to_float(_mg().case_scene(w, h, 200 + 10 * k + i), p) for i in range(B)]) for k in range(2)]
+    d_in = [torch.from_numpy(b).cuda() for b in batches]
+
+    def alloc():
+        return (torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda"), torch.zeros(B, dtype=torch.int32, device="cuda"))
+
+    ref = []
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp, batch=B)
+    for k in range(2):
+        pts, num = alloc()
+        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, d_in[k].data_ptr(), h * p, p, B, pts.data_ptr(), num.data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(det.ctx, pts.data_ptr(), num.data_ptr(), B // 2))
+        ah.check(ah.lib.hak_sync(det.ctx))
+        ref.append((pts.cpu().numpy().copy(), num.cpu().numpy().copy()))
+    det.close()
+    dets = []
+    outs = []
+    for k in range(2):
+        d = ah.Akazer()
+        d.init((w, h, p), max_pts=mp, batch=B)
+        dets.append(d)
+        outs.append(alloc())
+    for rep in range(3):
+        for k in range(2):                                  # both enqueued before either is synchronised
+            ah.check(ah.lib.hak_detect_and_compute_batch(dets[k].ctx, d_in[k].data_ptr(), h * p, p, B, outs[k][0].data_ptr(),
+                                                         outs[k][1].data_ptr(), 1))
+            ah.check(ah.lib.hak_match_batch(dets[k].ctx, outs[k][0].data_ptr(), outs[k][1].data_ptr(), B // 2))
+        for k in range(2):
+            ah.check(ah.lib.hak_sync(dets[k].ctx))
+            num = outs[k][1].cpu().numpy()
+            assert np.array_equal(num, ref[k][1]) and num.min() > 20
+            got = outs[k][0].cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+            want = ref[k][0].view(ah.POINT_DTYPE).reshape(B, mp)
+            for i in range(B):
+                assert got[i, :num[i]].tobytes() == want[i, :num[i]].tobytes()
+    for d in dets:
+        d.close()
+
+
+def test_knn2_with_context_scratch_and_repeat(ah, okz, torch, synth):
+    p2 = synth.random_descriptors(900, 3, ah.POINT_DTYPE)
+    p1 = synth.random_descriptors(700, 4, ah.POINT_DTYPE, planted_from=p2, nplanted=300, maxflip=60)
+    want_pts = p1.copy()
+    want = okz.match_knn2(want_pts, p2, (4, 5), True)
+    det = _detector(ah, 256, 192, max_pts=1000, batch=2)
+    d1 = torch.from_numpy(p1.view(np.uint8).reshape(-1).copy()).cuda()
+    d2 = torch.from_numpy(p2.view(np.uint8).reshape(-1).copy()).cuda()
+    d_out = torch.zeros(700 * 32, dtype=torch.uint8, device="cuda")
+    for _ in range(2):
+        h_out = np.zeros(700, ah.MATCH_PAIR_DTYPE)
+        cnt = C.c_int(-1)
+        ah.check(ah.lib.hak_match_knn2(det.ctx, d1.data_ptr(), 700, d2.data_ptr(), 900, 4, 5, 1, 0, None, d_out.data_ptr(),
+                                       C.byref(cnt), h_out.ctypes.data))
+        assert cnt.value == len(want) > 100
+        for f in ah.MATCH_PAIR_DTYPE.names:
+            assert np.array_equal(h_out[:cnt.value][f], want[f]), f
+    det.close()
