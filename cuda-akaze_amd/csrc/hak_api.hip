@@ -512,11 +512,11 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 int* first = (G % 2 == 0) ? Lt : tmp;
                 hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
                 src = first;
-            } else {                                                              // akaze.cpp:664-695
-                hakf_launch_conv_int(st, A + L.lt(o, s - 1), smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
+                hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
+            } else {                                                              // akaze.cpp:664-695: low-pass + flow in one pass
                 src = A + L.lt(o, s - 1);
+                hakf_launch_smooth_flow(st, src, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->itaps1, cfg.diffusivity, c->state, o);
             }
-            hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
             int done = 0;
             for (int g = 0; g < G; g++) {
                 const int ns = fused ? hak_fed_group_size(n, G, g) : 1;

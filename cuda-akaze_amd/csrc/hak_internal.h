@@ -200,6 +200,9 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
                            HakImgState* state, float per, int noct);
 // sigma=1 low-pass + conductivity fused (kernels_smoothflow.hip)
+void hakf_launch_smooth_flow(hipStream_t st, const int* src, int* smooth, int* flow, long stride,
+                             int w, int h, int p, int nimg, const int* itaps, int diffusivity,
+                             const HakImgState* state, int octave);
 void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, float* flow, long stride,
                             int w, int h, int p, int nimg, const float* taps, int diffusivity,
                             const HakImgState* state, int octave, float fixed_ikc);
