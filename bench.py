@@ -96,8 +96,13 @@ def main():
         print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # HAK_BENCH_FORCE_DIST=1 exercises the RCCL code path (barrier / MAX all-reduce / summary all-gather) with one rank too
+    use_dist = world > 1 or os.environ.get("HAK_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import akaze_hip as ah
@@ -162,7 +167,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -172,7 +177,7 @@ def main():
     run_steps(args.steps)
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -230,7 +235,7 @@ def main():
     nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(B)))
     # ---- the trivial result gather: per-rank summary {pairs, keypoints, matches}
     summary = torch.tensor([B, int(counts.sum()), nmatch], dtype=torch.int64, device="cuda")
-    if world > 1:
+    if use_dist:
         allsum = [torch.zeros_like(summary) for _ in range(world)]
         dist.all_gather(allsum, summary)
         summary = torch.stack(allsum).sum(0)
@@ -299,7 +304,7 @@ def main():
         ah.lib.hak_host_free(h_pts_l[k])
         ah.lib.hak_host_free(h_num_l[k])
         dets[k].close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
