@@ -1,0 +1,69 @@
+// fed_common.h -- element traits, DPP wave shifts and the one-row FED update shared by the streaming kernels
+// (kernels_fed.hip: FED steps only; kernels_fedsf.hip: low-pass + conductivity + FED steps in one pass).
+#pragma once
+#include "hak_internal.h"
+#include <type_traits>
+
+// The same streaming kernel serves both pipelines: V = float (akaze) and V = int (fastakaze, 16.16 fixed point,
+// akazed.cu:3448-3470).  Integer arithmetic wraps (unsigned add / mul), so every regrouping used below for the float
+// path (shared pair sums, shared flux products, tE + tW = P[x+1] - P[x]) is exact for the int path as well.
+template <typename V> struct FedV;
+template <> struct FedV<float> { using V4 = float4; };
+template <> struct FedV<int> { using V4 = int4; };
+__device__ __forceinline__ float4 mk4(float a, float b, float c, float d) { return make_float4(a, b, c, d); }
+__device__ __forceinline__ int4 mk4(int a, int b, int c, int d) { return make_int4(a, b, c, d); }
+__device__ __forceinline__ float vadd(float a, float b) { return a + b; }
+__device__ __forceinline__ float vsub(float a, float b) { return a - b; }
+__device__ __forceinline__ float vmul(float a, float b) { return a * b; }
+__device__ __forceinline__ int vadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+__device__ __forceinline__ int vsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+__device__ __forceinline__ int vmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+// L' from the flux sum:  float: fma(0.5*tau, sum, L) (akazed.cu:1263);  int: ((stepfac * (sum >> 16)) >> 16) + L (akazed.cu:3468-3469)
+__device__ __forceinline__ float vstep(float f, float sum, float L) { return fmaf(f, sum, L); }
+__device__ __forceinline__ int vstep(int f, int sum, int L) { return vadd(vmul(f, sum >> 16) >> 16, L); }
+
+template <typename V, int NS>
+struct FedFacs { V f[NS]; };
+
+// bound_ctrl = 1 with a zero `old`: the end lane (no source) reads 0 -- lanes 0 and 63 are strip margin -- and the
+// compiler needs no copy of `v` to seed the destination (an `old = v` shift costs one extra v_mov each)
+__device__ __forceinline__ int wave_shr1(int v)          // lane i <- lane i-1 (lane 0 reads 0)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+}
+__device__ __forceinline__ int wave_shl1(int v)          // lane i <- lane i+1 (lane 63 reads 0)
+{
+    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+}
+__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1(__float_as_int(v))); }
+__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(wave_shl1(__float_as_int(v))); }
+
+constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
+
+// horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 0..4
+template <typename V> struct GHrow { V h0, h1, h2, h3, h4; };
+
+// one output row (4 px per lane) of one level
+template <bool XEDGE, typename V, typename V4>
+__device__ __forceinline__ V4 fed_row(const V4 Lc, const V4 Ln, const V4 Ls, const GHrow<V>& gh,
+                                      const V4 gvS, const V4 gvN, int x0, int w, V stepfac)
+{
+    V Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x);
+    if (XEDGE) {
+        // reflect-101 in x: abs(x-1) = 1 at x == 0; borderAdd(x,1,w) = w-2 at x == w-1 (w % 4 == 0 here,
+        // so x == w-1 is the lane's last component); the matching g-sums were folded into gh already
+        Ll = x0 == 0 ? Lc.y : Ll;
+        Lr = x0 + 3 == w - 1 ? Lc.z : Lr;
+    }
+    // d[j] = L[x0+j] - L[x0+j-1], P[j] = h[j] * d[j]
+    const V d0 = vsub(Lc.x, Ll), d1 = vsub(Lc.y, Lc.x), d2 = vsub(Lc.z, Lc.y), d3 = vsub(Lc.w, Lc.z), d4 = vsub(Lr, Lc.w);
+    const V P0 = vmul(gh.h0, d0), P1 = vmul(gh.h1, d1), P2 = vmul(gh.h2, d2), P3 = vmul(gh.h3, d3), P4 = vmul(gh.h4, d4);
+    V4 o;
+    // ((tE + tW) + tS) + tN ; tE = P[e+1], tW = -P[e]
+    o.x = vstep(stepfac, vadd(vadd(vsub(P1, P0), vmul(gvS.x, vsub(Ls.x, Lc.x))), vmul(gvN.x, vsub(Ln.x, Lc.x))), Lc.x);
+    o.y = vstep(stepfac, vadd(vadd(vsub(P2, P1), vmul(gvS.y, vsub(Ls.y, Lc.y))), vmul(gvN.y, vsub(Ln.y, Lc.y))), Lc.y);
+    o.z = vstep(stepfac, vadd(vadd(vsub(P3, P2), vmul(gvS.z, vsub(Ls.z, Lc.z))), vmul(gvN.z, vsub(Ln.z, Lc.z))), Lc.z);
+    o.w = vstep(stepfac, vadd(vadd(vsub(P4, P3), vmul(gvS.w, vsub(Ls.w, Lc.w))), vmul(gvN.w, vsub(Ln.w, Lc.w))), Lc.w);
+    return o;
+}
+

@@ -168,6 +168,7 @@ struct hak_ctx {
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
+    bool fuse_sf = true;            // low-pass + conductivity fused into the first FED launch of a sublevel (env HAK_FUSE_SF=0 disables)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
 };
@@ -291,6 +292,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     c->cfg = *cfg;
     if (c->cfg.batch < 1) c->cfg.batch = 1;
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
+    if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e) != 0;
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
@@ -425,10 +427,21 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             } else {                                                              // akaze.cpp:393-421
                 fsrc = A + L.lt(o, s - 1);
             }
+            // sublevels > 0: low-pass + conductivity + the first FED group in one streaming pass when the case is covered
+            // (PM_G2, 16-byte rows); the conductivity plane is written only if later groups of the cycle need it
+            bool fused_first = false;
             if (s == 0) {
                 ProfScope ps(c, HAK_PROF_FLOW, st);
                 hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
-            } else {                                                              // akaze.cpp:403-404 in one pass
+            } else if (c->fuse_sf && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 && oc.h >= 8) {
+                const int ns0 = hak_fed_group_size(n, G, 0);
+                float* dst0 = (G % 2 == 1) ? Lt : tmp;
+                ProfScope ps(c, HAK_PROF_FED, st);
+                fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
+                                                lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
+                if (fused_first) c->fed_launches++;
+            }
+            if (s != 0 && !fused_first) {                                         // akaze.cpp:403-404 in one pass
                 ProfScope ps(c, HAK_PROF_LOWPASS, st);
                 hak_launch_smooth_flow(st, fsrc, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
                                        c->state, o, 0.f);
@@ -440,9 +453,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 for (int g = 0; g < G; g++) {
                     const int ns = hak_fed_group_size(n, G, g);
                     float* dst = ((G - g) % 2 == 1) ? Lt : tmp;
-                    ProfScope ps(c, HAK_PROF_FED, st);
-                    hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
-                    c->fed_launches++;
+                    if (!(g == 0 && fused_first)) {
+                        ProfScope ps(c, HAK_PROF_FED, st);
+                        hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
+                        c->fed_launches++;
+                    }
                     done += ns;
                     src = dst;
                 }

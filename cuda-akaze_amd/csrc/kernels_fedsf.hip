@@ -1,0 +1,276 @@
+// kernels_fedsf.hip -- sigma=1 low-pass + PM_G2 conductivity + the first NS FED steps of a sublevel in ONE streaming pass.
+//
+//   hLowPass(Lt(o,s-1) -> smooth, var 1, ksz 5)   akaze.cpp:403, akazed.cu:2336, 204
+//   hFlow(smooth -> flow)                         akaze.cpp:404, akazed.cu:2487, 1068
+//   hNldStep x NS (Lt(o,s-1), flow -> ...)        akaze.cpp:408-420, akazed.cu:2509, 1241
+//
+// The unfused sequence moves 12 B/px in k_smooth_flow (read L, write smooth, write g) and 12 B/px in the first
+// k_fed_multi launch (read L, read g, write L').  Here a wave streams down its 256-px strip exactly like
+// k_fed_multi, but the only input is L: when row t arrives,
+//     row pass  rp(t)      of the separable Gaussian (x neighbours at +-1, +-2 by DPP wave shifts),
+//     smooth    row t-2    = column pass over rp(t-4 .. t)            -> HBM (the Hessian kernel reads it),
+//     g         row t-3    = conductivity of the Scharr gradient of smooth rows t-4, t-3, t-2
+//                            -> HBM only when later FED launches of this cycle still need it,
+//     FED level k          produces row t-3-k from level k-1 (as in kernels_fed.hip, delayed by three rows),
+// so the pass reads 4 B/px and writes 8 (or 12) B/px instead of 24.  Rings (static slots, loop unrolled by 6):
+// L 6 rows, rp 6 rows, smooth 3 rows (+ its two x-neighbour columns), the g-sum rings and per-level windows of
+// the FED kernel.  No LDS, no barriers.
+//
+// Bit-exactness: every stage evaluates the reference expression in the reference order (Gaussian: c*k0, then
+// += k1*(l1+r1), then += k2*(l2+r2), akazed.cu:227-239 / 283-288; Scharr / conductivity akazed.cu:1088-1106).
+// Reflect-101: in x by selects in the lane that holds image column 0 / w-1; in y by writing a row that arrives at
+// 1 (2) also into the slot of row -1 (-2) and by copying rows h-2 (h-3) into the virtual rows h (h+1) -- for the
+// rp ring (the Gaussian is symmetric with commutative tap pairs, so the smooth value computed at a mirrored
+// position IS the smooth value at the reflected index, which is what gFlowNaive reads), for the smooth ring and
+// for the FED rings as before.
+//
+// Float path, PM_G2, w % 4 == 0 only; everything else takes k_smooth_flow + k_fed_multi.
+#include "fed_common.h"
+
+namespace {
+
+struct SfK { float k0, k1, k2; };
+
+template <int NS>
+struct FsState {
+    static constexpr int GS = 6;
+    static constexpr int PD = 3;
+    float4 Lr[6];                       // L rows t-5 .. t                      slot = iteration mod 6
+    float4 Rp[6];                       // row-pass rows t-5 .. t
+    float4 Sm[3];                       // smooth rows a-2 .. a (a = t-2)       slot = iteration mod 3
+    float SmL[3], SmR[3];               // smooth at columns x0-1 and x0+4 of those rows
+    float4 Lw[NS][3];                   // FED level k >= 1 windows ([0] unused: level 0 reads Lr)
+    GHrow<float> GH[GS];
+    float4 GV[GS];
+    float4 gprev;
+    float4 Lq[PD];                      // prefetch ring
+};
+
+template <int NS, int U, bool YEDGE, bool XE, bool WRITE_G>
+__device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float* __restrict__ L, float* __restrict__ SMO,
+                                        float* __restrict__ GO, float* __restrict__ D, const int p, const int xl,
+                                        const int x0, const int w, const int h, const int ybeg, const int yend,
+                                        const bool owns, const FedFacs<float, NS>& fac, const SfK kk, const float ikc)
+{
+    constexpr int GS = FsState<NS>::GS, PD = FsState<NS>::PD;
+    const bool le = x0 == 0, re = x0 + 3 == w - 1;
+    // ---- L row t arrives; request row t + PD (clamped: rows past the image are never used)
+    {
+        const float4 Lc = S.Lq[pmod(U, PD)];
+        S.Lr[pmod(U, 6)] = Lc;
+        S.Lq[pmod(U, PD)] = *reinterpret_cast<const float4*>(L + (long)min(t + PD, h - 1) * p + xl);
+        if (YEDGE && t == 1) S.Lr[pmod(U - 2, 6)] = Lc;                              // FED: row -1 := row 1
+        if (YEDGE && t == h) S.Lr[pmod(U, 6)] = S.Lr[pmod(U - 2, 6)];                // FED: row h := row h-2
+    }
+    // ---- row pass of the Gaussian on row t (akazed.cu:227-239)
+    {
+        const float4 c = S.Lr[pmod(U, 6)];
+        const float sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
+        float4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
+        float4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
+        if (XE) {
+            l1.x = le ? c.y : l1.x;                         // column -1 -> 1
+            l2.x = le ? c.z : l2.x;                         // column -2 -> 2
+            l2.y = le ? c.y : l2.y;                         // column -1 -> 1
+            r1.w = re ? c.z : r1.w;                         // column w   -> w-2
+            r2.z = re ? c.z : r2.z;                         // column w   -> w-2
+            r2.w = re ? c.y : r2.w;                         // column w+1 -> w-3
+        }
+        float4 rp;
+        rp.x = c.x * kk.k0; rp.x += kk.k1 * (l1.x + r1.x); rp.x += kk.k2 * (l2.x + r2.x);
+        rp.y = c.y * kk.k0; rp.y += kk.k1 * (l1.y + r1.y); rp.y += kk.k2 * (l2.y + r2.y);
+        rp.z = c.z * kk.k0; rp.z += kk.k1 * (l1.z + r1.z); rp.z += kk.k2 * (l2.z + r2.z);
+        rp.w = c.w * kk.k0; rp.w += kk.k1 * (l1.w + r1.w); rp.w += kk.k2 * (l2.w + r2.w);
+        S.Rp[pmod(U, 6)] = rp;
+        if (YEDGE) {
+            if (t == 1) S.Rp[pmod(U - 2, 6)] = rp;                                   // row -1 := row 1
+            if (t == 2) S.Rp[pmod(U - 4, 6)] = rp;                                   // row -2 := row 2
+            if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 2, 6)];                     // row h   := row h-2
+            if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 4, 6)];                 // row h+1 := row h-3
+        }
+    }
+    // ---- column pass -> smooth row a = t - 2 (akazed.cu:283-288)
+    {
+        const int a = t - 2;
+        const float4 c = S.Rp[pmod(U - 2, 6)], u1 = S.Rp[pmod(U - 3, 6)], d1 = S.Rp[pmod(U - 1, 6)];
+        const float4 u2 = S.Rp[pmod(U - 4, 6)], d2 = S.Rp[pmod(U, 6)];
+        float4 sm;
+        sm.x = c.x * kk.k0; sm.x += kk.k1 * (u1.x + d1.x); sm.x += kk.k2 * (u2.x + d2.x);
+        sm.y = c.y * kk.k0; sm.y += kk.k1 * (u1.y + d1.y); sm.y += kk.k2 * (u2.y + d2.y);
+        sm.z = c.z * kk.k0; sm.z += kk.k1 * (u1.z + d1.z); sm.z += kk.k2 * (u2.z + d2.z);
+        sm.w = c.w * kk.k0; sm.w += kk.k1 * (u1.w + d1.w); sm.w += kk.k2 * (u2.w + d2.w);
+        if (a >= ybeg && a < yend && owns) *reinterpret_cast<float4*>(SMO + (long)a * p + x0) = sm;
+        float sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
+        if (XE) {
+            sl = le ? sm.y : sl;                            // abs(x-1) = 1
+            sr = re ? sm.z : sr;                            // borderAdd(x,1,w) = w-2
+        }
+        S.Sm[pmod(U, 3)] = sm; S.SmL[pmod(U, 3)] = sl; S.SmR[pmod(U, 3)] = sr;
+        if (YEDGE && a == 1) { S.Sm[pmod(U - 2, 3)] = sm; S.SmL[pmod(U - 2, 3)] = sl; S.SmR[pmod(U - 2, 3)] = sr; }
+        if (YEDGE && a == h) {
+            S.Sm[pmod(U, 3)] = S.Sm[pmod(U - 2, 3)]; S.SmL[pmod(U, 3)] = S.SmL[pmod(U - 2, 3)]; S.SmR[pmod(U, 3)] = S.SmR[pmod(U - 2, 3)];
+        }
+    }
+    // ---- conductivity row b = t - 3 (akazed.cu:1088-1098, PM_G2) and the FED rings' level-0 bookkeeping for that row
+    const int tf = t - 3;                                   // the FED part runs three rows behind the input
+    {
+        const float4 su = S.Sm[pmod(U - 2, 3)], sc = S.Sm[pmod(U - 1, 3)], sd = S.Sm[pmod(U, 3)];
+        const float uL = S.SmL[pmod(U - 2, 3)], uR = S.SmR[pmod(U - 2, 3)];
+        const float cL = S.SmL[pmod(U - 1, 3)], cR = S.SmR[pmod(U - 1, 3)];
+        const float dL = S.SmL[pmod(U, 3)], dR = S.SmR[pmod(U, 3)];
+        float4 g;
+#define FS_G(k, ul, uc, ur, cl, cr, ll, lc, lr)                                             \
+        {                                                                                   \
+            const float dx = 10 * ((cr) - (cl)) + 3 * ((ur) + (lr) - (ul) - (ll));          \
+            const float dy = 10 * ((lc) - (uc)) + 3 * ((ll) + (lr) - (ul) - (ur));          \
+            const float dif2 = ikc * (dx * dx + dy * dy);                                   \
+            g.k = 1.f / (1.f + dif2);                                                       \
+        }
+        FS_G(x, uL, su.x, su.y, cL, sc.y, dL, sd.x, sd.y)
+        FS_G(y, su.x, su.y, su.z, sc.x, sc.z, sd.x, sd.y, sd.z)
+        FS_G(z, su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w)
+        FS_G(w, su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR)
+#undef FS_G
+        if (WRITE_G && tf >= ybeg && tf < yend && owns) *reinterpret_cast<float4*>(GO + (long)tf * p + x0) = g;
+        const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
+        GHrow<float> gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
+        if (XE) {
+            gh.h0 = le ? gh.h1 : gh.h0;                     // (g+gW) at x == 0 is (g+gE)
+            gh.h4 = re ? gh.h3 : gh.h4;                     // (g+gE) at x == w-1 is (g+gW)
+        }
+        S.GH[pmod(U, GS)] = gh;
+        S.GV[pmod(U - 1, GS)] = mk4(S.gprev.x + g.x, S.gprev.y + g.y, S.gprev.z + g.z, S.gprev.w + g.w);
+        S.gprev = g;
+        if (YEDGE && tf == 1) S.GV[pmod(U - 2, GS)] = S.GV[pmod(U - 1, GS)];        // GV[-1] := GV[0]
+        if (YEDGE && tf == h) S.GV[pmod(U - 1, GS)] = S.GV[pmod(U - 2, GS)];        // GV[h-1] := GV[h-2]
+    }
+    // ---- FED levels 1..NS: level k produces row tf-k from level k-1's rows tf-k-1, tf-k, tf-k+1
+#pragma unroll
+    for (int k = 1; k <= NS; k++) {
+        const int rho = tf - k;
+        // level 0 = the L ring (row tf-j lives in slot U-3-j); levels >= 1 = their 3-row windows
+        const float4 Lc = k == 1 ? S.Lr[pmod(U - 3 - 1, 6)] : S.Lw[k - 1][pmod(U - k, 3)];
+        const float4 Ln = k == 1 ? S.Lr[pmod(U - 3 - 2, 6)] : S.Lw[k - 1][pmod(U - k - 1, 3)];
+        const float4 Ls = k == 1 ? S.Lr[pmod(U - 3, 6)] : S.Lw[k - 1][pmod(U - k + 1, 3)];
+        const float4 out = fed_row<XE, float, float4>(Lc, Ln, Ls, S.GH[pmod(U - k, GS)], S.GV[pmod(U - k, GS)],
+                                                      S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
+        if (k < NS) {
+            S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
+            if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
+            if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
+        } else if (rho >= ybeg && rho < yend && owns) {
+            *reinterpret_cast<float4*>(D + (long)rho * p + x0) = out;
+        }
+    }
+}
+
+template <int NS, bool XE, bool WRITE_G>
+__device__ __forceinline__ void fs_strip(const float* __restrict__ L, float* __restrict__ SMO, float* __restrict__ GO,
+                                         float* __restrict__ D, int w, int h, int p, const FedFacs<float, NS>& fac,
+                                         const SfK kk, const float ikc, int x0, int ybeg, int yend, bool owns)
+{
+    const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
+    const int t0 = max(0, ybeg - NS - 4);                   // rp from t0, smooth from t0+2, g from t0+3, level k from t0+3+k
+    const int tend = min(yend - 1, h - 1) + NS + 3;         // iteration that emits the strip's last L' row
+    FsState<NS> S;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < 6; i++) { S.Lr[i] = z4; S.Rp[i] = z4; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { S.Sm[i] = z4; S.SmL[i] = 0.f; S.SmR[i] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = z4;
+#pragma unroll
+    for (int i = 0; i < FsState<NS>::GS; i++) {
+        S.GH[i] = GHrow<float>{0.f, 0.f, 0.f, 0.f, 0.f};
+        S.GV[i] = z4;
+    }
+    S.gprev = z4;
+#pragma unroll
+    for (int i = 0; i < FsState<NS>::PD; i++)
+        S.Lq[i] = *reinterpret_cast<const float4*>(L + (long)min(t0 + i, h - 1) * p + xl);
+    for (int tb = t0; tb <= tend; tb += 6) {
+        // reflect injections fire while some stage is at rows 1..2 (t <= NS + 4) or at the virtual rows past h-1
+        if (tb <= NS + 4 || tb + 5 >= h) {
+            fs_iter<NS, 0, true, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 1, true, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 2, true, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 3, true, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 4, true, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 5, true, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+        } else {
+            fs_iter<NS, 0, false, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 1, false, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 2, false, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 3, false, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 4, false, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<NS, 5, false, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+        }
+    }
+}
+
+constexpr int FS_HX = 8;                                    // x halo: 2 (Gaussian) + 1 (Scharr) + NS (FED) <= 7, multiple of 4
+constexpr int FS_XV = 256 - 2 * FS_HX;
+
+// grid: hak_xcd_grid(strips, strip-row groups, images); a block's four waves take four consecutive row segments
+template <int NS, bool WRITE_G>
+__global__ __launch_bounds__(256) void k_fed_sf(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow,
+                                                float* __restrict__ dst, long stride, int w, int h, int p,
+                                                FedFacs<float, NS> fac, SfK kk, const HakImgState* __restrict__ state, int octave,
+                                                float fixed_ikc, int ry, int nbx, int nby, int nimg)
+{
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    const float* L = src + (long)img * stride;
+    float* SMO = smooth + (long)img * stride;
+    float* GO = flow + (long)img * stride;
+    float* D = dst + (long)img * stride;
+    const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = bx * FS_XV - FS_HX + 4 * lane;           // first pixel of this lane (may lie outside the image)
+    const int ybeg = (by * 4 + wv) * ry;
+    if (ybeg >= h) return;                                  // wave-uniform
+    const int yend = min(ybeg + ry, h);
+    const bool owns = 4 * lane >= FS_HX && 4 * lane < FS_HX + FS_XV && x0 < w && x0 >= 0;
+    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<NS, true, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
+    else fs_strip<NS, false, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
+}
+
+template <int NS>
+void launch_fs(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride, int w, int h, int p,
+               int nimg, const float* taps, const float* tau, const HakImgState* state, int octave, float fixed_ikc, bool write_g)
+{
+    FedFacs<float, NS> fac;
+    for (int k = 0; k < NS; k++) fac.f[k] = 0.5f * tau[k];          // akazed.cu:2515
+    const SfK kk{taps[0], taps[1], taps[2]};
+    const int gx = (w + FS_XV - 1) / FS_XV;
+    // rows per wave: tall segments amortise the NS+4 warm-up rows; shrink while the grid cannot fill the chip
+    int ry = 64;
+    while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    const int gy = (h + 4 * ry - 1) / (4 * ry);
+    if (write_g)
+        k_fed_sf<NS, true><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
+                                                                      fixed_ikc, ry, gx, gy, nimg);
+    else
+        k_fed_sf<NS, false><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
+                                                                       fixed_ikc, ry, gx, gy, nimg);
+}
+
+}   // namespace
+
+// smooth = G1(src); g = PM_G2(smooth) (written to `flow` only when write_g); dst = ns FED steps of src under g.
+// Returns false when the case is not covered (caller: hak_launch_smooth_flow + hak_launch_fed_group).
+bool hak_launch_fed_sf(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride,
+                       int w, int h, int p, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
+                       const HakImgState* state, int octave, float fixed_ikc, bool write_g)
+{
+    if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
+    switch (ns) {
+    case 1: launch_fs<1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
+    case 2: launch_fs<2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
+    case 3: launch_fs<3>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
+    default: launch_fs<4>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
+    }
+    return true;
+}
