@@ -256,7 +256,7 @@ def main():
         ah.check(ah.lib.hak_prof_read(det.ctx, ah.PROF["fed"], C.byref(ms), C.byref(n)))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
         tr = det.traffic(int(counts.mean()))
-        bytes_per_launch = tr.fed_bytes * nimg / tr.fed_launches          # 12 B x px-steps x images / launches
+        bytes_per_launch = tr.fed_bytes * nimg / tr.fed_launches          # algorithmic bytes (hipakaze.h hak_traffic) x images / launches
         avg_s = ms.value * 1e-3 / n.value
         achieved = bytes_per_launch / avg_s / 1e9
         cls = {}
@@ -272,7 +272,8 @@ def main():
             # every FED launch covers the whole batch, so bytes scale with B relative to the batch the passes ran at
             tj = json.load(open(tfile))
             traffic = round(tj["fed_hbm_bytes_per_launch"] * B / float(tj.get("pairs_per_launch_sequence", 16)))
-        roof = {"kernel": "k_fed_multi<NS> (fused FED steps, 12 B/px/step algorithmic)", "bound": "hbm",
+        roof = {"kernel": "k_fed_sf<NS> / k_fed_multi<NS> (FED steps 12 B/px/step; +16 B/px where the sublevel's low-pass and "
+                          "conductivity run inside its first FED launch)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),

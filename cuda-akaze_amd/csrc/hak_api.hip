@@ -856,7 +856,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
 {
     if (!c || !out) return fail("null argument");
     const HakLayout& L = c->L;
-    double pxsteps = 0, all = 0;
+    double pxsteps = 0, all = 0, folded = 0;
     int launches = 0;
     for (int o = 0; o < L.noct; o++) {
         const double N = (double)L.oct[o].w * L.oct[o].h;
@@ -864,6 +864,10 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             pxsteps += N * lp.nsteps;
             launches += lp.nsteps ? hak_fed_groups(lp.nsteps, c->max_fuse, L.oct[o].w) : 0;
+            // sublevels whose low-pass (8 B/px) + conductivity (8 B/px) run inside the first FED launch (k_fed_sf)
+            if (s > 0 && lp.nsteps && c->fuse_sf && c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 &&
+                L.oct[o].h >= 8)
+                folded += 16.0 * N;
             if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue
             else if (s == 0) all += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 8.0 * N + 8.0 * N + 24.0 * N + 4.0 * N;
             else all += 44.0 * N;
@@ -873,7 +877,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
     all += 12.0 * pxsteps;
     all += (872.0 + 5292.0 + 104.0) * npts_hint;
     out->fed_px_steps = pxsteps;
-    out->fed_bytes = 12.0 * pxsteps;
+    out->fed_bytes = 12.0 * pxsteps + folded;
     out->all_stage_bytes = all;
     out->fed_launches = launches;
     return 0;

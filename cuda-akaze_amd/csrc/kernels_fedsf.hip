@@ -246,7 +246,7 @@ void launch_fs(hipStream_t st, const float* src, float* smooth, float* flow, flo
     const SfK kk{taps[0], taps[1], taps[2]};
     const int gx = (w + FS_XV - 1) / FS_XV;
     // rows per wave: tall segments amortise the NS+4 warm-up rows; shrink while the grid cannot fill the chip
-    int ry = 64;
+    int ry = 128;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (h + 4 * ry - 1) / (4 * ry);
     if (write_g)

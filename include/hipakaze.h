@@ -187,7 +187,8 @@ int hak_debug_kcontrast(hak_ctx* ctx, int img, float* kcontrast);
 /* algorithmic-byte accounting of the last detect call on this context */
 typedef struct hak_traffic {
     double fed_px_steps;     /* sum over FED steps of pixels updated, per image */
-    double fed_bytes;        /* 12 B x fed_px_steps */
+    double fed_bytes;        /* 12 B x fed_px_steps, + 16 B/px (low-pass 8 + conductivity 8) for every
+                                sublevel whose low-pass and conductivity run inside its first FED launch (k_fed_sf) */
     double all_stage_bytes;  /* all-stage compulsory bytes per image, keypoint part for npts_hint points */
     int fed_launches;        /* FED kernel launches per batch */
 } hak_traffic;
