@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=32, help="pairs per GPU per step (batch)")
+    ap.add_argument("--pairs", type=int, default=64, help="pairs per GPU per step (batch)")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--octaves", type=int, default=4)
