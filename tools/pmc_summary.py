@@ -17,7 +17,7 @@ def main():
     n = collections.defaultdict(collections.Counter)
     for path in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(path)):
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             if filt not in k:
                 continue
             tot[k][r["Counter_Name"]] += float(r["Counter_Value"])

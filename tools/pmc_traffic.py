@@ -25,7 +25,7 @@ def load(dirname, counter):
         for r in csv.DictReader(open(path)):
             if r["Counter_Name"] != counter:
                 continue
-            k = r["Kernel_Name"].split("(")[0]
+            k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
             tot[k] += float(r["Counter_Value"]) * 1024.0
             n[k] += 1
     return tot, n
@@ -38,7 +38,7 @@ def main():
     rows = []
     for k in sorted(fetch, key=lambda k: -fetch[k]):
         rows.append(dict(kernel=k, dispatches=nf[k], fetch_size_bytes=fetch[k], write_size_bytes=write.get(k, 0.0)))
-    fed = [r for r in rows if "k_fed_multi" in r["kernel"]]
+    fed = [r for r in rows if "k_fed_multi" in r["kernel"] or "k_fed_sf" in r["kernel"]]    # the FED family
     launches = sum(r["dispatches"] for r in fed)
     fed_fetch = sum(r["fetch_size_bytes"] for r in fed)
     fed_write = sum(r["write_size_bytes"] for r in fed)
