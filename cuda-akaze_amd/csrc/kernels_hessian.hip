@@ -19,6 +19,7 @@
 // Same per-pixel expressions and reflect-101 index rule as the reference (akazed.cu:1284-1295,
 // 1326-1330, 1346-1373).
 #include "hak_internal.h"
+#include <cstdlib>
 #include <type_traits>
 
 // The kernel is shared by both pipelines: V = float (akaze) and V = int (fastakaze 16.16 fixed point,
@@ -352,6 +353,14 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
+    // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
+    static const bool use_stream = !(getenv("HAK_HESS_STREAM") && atoi(getenv("HAK_HESS_STREAM")) == 0);
+    if (use_stream) {
+        float f1, f2;
+        deriv_factors(f1, f2);
+        if (hak_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
+            return true;
+    }
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     switch (step) {
     case 1: launch_fused<float, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;

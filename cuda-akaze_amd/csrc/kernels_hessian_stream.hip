@@ -1,0 +1,337 @@
+// kernels_hessian_stream.hip -- derivatives + Hessian determinant + per-level extrema as a register-streaming
+// kernel: no LDS, no barriers (same skeleton as kernels_fed.hip / kernels_fedsf.hip).
+//
+//   hHessianDeterminant/gDerivate/gHessianDeterminant   akazed.cu:2531, 1267, 1299
+//   hCalcExtremaMap/gCalcExtremaMap                     akazed.cu:2563, 1334
+//
+// A wave owns a 256-px-wide strip (one float4 per lane) and streams down the rows of its segment.  For dilation S
+// it keeps three register rings of R = 2S+1 rows -- the smoothed input, Lx and Ly -- and the last three rows of
+// the determinant.  When input row t arrives,
+//     Lx, Ly  of row b = t - S      come from input rows b-S, b, b+S      (the ring's oldest / middle / newest),
+//     det     of row c = t - 2S     comes from Lx / Ly rows c-S, c, c+S,
+//     extrema of row e = t - 2S - 1 come from det rows e-1, e, e+1,
+// so the input is read once (4 B/px) and Lx, Ly, det are written once (12 B/px) with 16-byte accesses.  Horizontal
+// neighbours at distance S are the adjacent lane's components: S DPP wave shifts per direction per row.  The rings
+// rotate statically (row loop unrolled by R); the strip's outer M columns and the 2S+1 warm-up rows above / below a
+// segment are recomputed by the neighbouring wave.
+//
+// Reflect-101 (akazed.cu:1284-1291, 1318-1325): in x the reference reflects the INDEX it reads the plane at, so the
+// lane that holds image column 0 (w-1) replaces the shifted-in values by its own / its neighbour's components; in y
+// a row arriving at 1..S is also written to the ring slot of row -1..-S and the virtual rows h..h+S-1 are copies of
+// rows h-2..h-1-S, for each of the three rings.  Per-pixel expressions and their order are those of the tile kernel
+// (kernels_hessian.hip) and the reference.
+//
+// Requires w % 4 == 0 and 1 <= S <= 4; everything else takes the LDS tile kernel.
+#include "fed_common.h"
+#include <utility>
+
+namespace {
+
+template <int S> struct HsGeo {
+    static constexpr int R = 2 * S + 1;                             // ring rows = unroll factor
+    static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
+    static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
+};
+
+template <int S> struct HsState {
+    float4 A[HsGeo<S>::R], X[HsGeo<S>::R];                          // slot = iteration index mod R
+    float4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
+    float4 Dm, Dc, Dp;                                              // det rows e-1, e, e+1 (rotated by moves)
+    float4 Q0, Q1, Q2;                                              // input rows t, t+1, t+2 in flight
+};
+
+template <int I> __device__ __forceinline__ float hs_c(const float4& r)
+{
+    if constexpr (I == 0) return r.x;
+    else if constexpr (I == 1) return r.y;
+    else if constexpr (I == 2) return r.z;
+    else return r.w;
+}
+// value at column x0 + K - S of the row held as r (columns x0 .. x0+3): the own component, or the left lane's through one
+// DPP shift; `le` (the lane holding image column 0) reads the reflected column S - K instead.  One scalar at a time so
+// that only the values of the component being evaluated are live.
+template <int S, int K, bool XEDGE>
+__device__ __forceinline__ float hs_l(const float4& r, const bool le)
+{
+    float v;
+    if constexpr (K - S >= 0) v = hs_c<K - S>(r);
+    else {
+        v = wave_shr1(hs_c<4 + K - S>(r));
+        if (XEDGE) {
+            if constexpr (S - K <= 3) v = le ? hs_c<S - K>(r) : v;
+            else {
+                // column 4 = the right lane's first component.  The shift must execute with every lane active: inside the
+                // conditional operator it would run under the `le` lane's EXEC mask only and read its neighbour as 0.
+                const float c4 = wave_shl1(r.x);
+                v = le ? c4 : v;
+            }
+        }
+    }
+    return v;
+}
+// value at column x0 + K + S; `re` (the lane holding image column w-1) reads the reflected column 6 - K - S (relative)
+template <int S, int K, bool XEDGE>
+__device__ __forceinline__ float hs_r(const float4& r, const bool re)
+{
+    float v;
+    if constexpr (K + S <= 3) v = hs_c<K + S>(r);
+    else {
+        v = wave_shl1(hs_c<K + S - 4>(r));
+        if (XEDGE) {
+            if constexpr (6 - K - S >= 0) v = re ? hs_c<6 - K - S>(r) : v;
+            else {
+                const float cm1 = wave_shr1(r.w);                   // column -1 = the left lane's last component (all lanes active)
+                v = re ? cm1 : v;
+            }
+        }
+    }
+    return v;
+}
+
+// dilated Scharr pair on one component (akazed.cu:1294-1295)
+#define HS_DX(ul, ur, cl, cr, ll, lr) (fac1 * ((ur) + (lr) - (ul) - (ll)) + fac2 * ((cr) - (cl)))
+#define HS_DY(ul, uc, ur, ll, lc, lr) (fac1 * ((lr) + (ll) - (ur) - (ul)) + fac2 * ((lc) - (uc)))
+
+struct HsArgs {
+    const float* src; float* lx; float* ly; float* det;
+    int w, h, p;
+    float fac1, fac2;
+    // extrema (maps == nullptr: determinant only)
+    unsigned long long* maps; unsigned long long* cand; long cand_cap; HakImgState* st;
+    int p0, octave, layer, psz; float border, threshold;
+};
+
+// candidate emission for one component (rare path: a handful of pixels per segment)
+__device__ __forceinline__ void hs_emit(const bool hit, const float v, const int x, const int e, const HsArgs& a, const int lane)
+{
+    const unsigned long long m = __ballot(hit);
+    if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&a.st->ncand, __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (hit) {
+            const int fx = x << a.octave, fy = e << a.octave;
+            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)a.layer);
+            atomicMax(&a.maps[(long)fy * a.p0 + fx], key);
+            const long slot = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (slot < a.cand_cap) a.cand[slot] = ((unsigned long long)a.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+        }
+    }
+}
+
+template <int S, int U, bool XEDGE, bool YEDGE>
+__device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs& a, const int xl, const int x0,
+                                        const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane)
+{
+    constexpr int R = HsGeo<S>::R;
+    const float fac1 = a.fac1, fac2 = a.fac2;
+    const int w = a.w, h = a.h, p = a.p;
+    const bool le = x0 == 0, re = x0 + 3 == w - 1;
+    // ---- input row t (prefetched three iterations ago); request row t + 3
+    T.A[pmod(U, R)] = T.Q0;
+    T.Q0 = T.Q1; T.Q1 = T.Q2;
+    T.Q2 = *reinterpret_cast<const float4*>(a.src + (long)min(t + 3, h - 1) * p + xl);
+    if (YEDGE) {
+#pragma unroll
+        for (int j = 1; j <= S; j++) {
+            if (t == j) T.A[pmod(U - 2 * j, R)] = T.A[pmod(U, R)];                   // row -j := row j
+            if (t == h - 1 + j) T.A[pmod(U, R)] = T.A[pmod(U - 2 * j, R)];           // row h-1+j := row h-1-j
+        }
+    }
+    // ---- Lx, Ly of row b = t - S
+    float4 vy_row;                                                  // Ly row b (= the determinant's row c+S below)
+    {
+        const int b = t - S;
+        const float4 ru = T.A[pmod(U - 2 * S, R)], rc = T.A[pmod(U - S, R)], rl = T.A[pmod(U, R)];
+        float4 vx, vy;
+#define HS_S1(k, K)                                                                                         \
+        {                                                                                                   \
+            const float ul = hs_l<S, K, XEDGE>(ru, le), ur = hs_r<S, K, XEDGE>(ru, re);                     \
+            const float cl = hs_l<S, K, XEDGE>(rc, le), cr = hs_r<S, K, XEDGE>(rc, re);                     \
+            const float ll = hs_l<S, K, XEDGE>(rl, le), lr = hs_r<S, K, XEDGE>(rl, re);                     \
+            vx.k = HS_DX(ul, ur, cl, cr, ll, lr);                                                           \
+            vy.k = HS_DY(ul, ru.k, ur, ll, rl.k, lr);                                                       \
+        }
+        // scheduling fences keep one component's shifted values live at a time (the scheduler otherwise hoists every
+        // DPP shift of the iteration to the top and needs > 250 VGPRs)
+        HS_S1(x, 0) __builtin_amdgcn_sched_barrier(0); HS_S1(y, 1) __builtin_amdgcn_sched_barrier(0);
+        HS_S1(z, 2) __builtin_amdgcn_sched_barrier(0); HS_S1(w, 3) __builtin_amdgcn_sched_barrier(0);
+#undef HS_S1
+        T.X[pmod(U, R)] = vx;
+        T.Y[pmod(U, R) * 64 + lane] = vy;
+        if (b >= ybeg && b < yend && owns) {
+            *reinterpret_cast<float4*>(a.lx + (long)b * p + x0) = vx;
+            *reinterpret_cast<float4*>(a.ly + (long)b * p + x0) = vy;
+        }
+        if (YEDGE) {
+#pragma unroll
+            for (int j = 1; j <= S; j++) {
+                if (b == j) {
+                    T.X[pmod(U - 2 * j, R)] = T.X[pmod(U, R)];
+                    T.Y[pmod(U - 2 * j, R) * 64 + lane] = vy;
+                }
+                if (b == h - 1 + j) {
+                    T.X[pmod(U, R)] = T.X[pmod(U - 2 * j, R)];
+                    vy = T.Y[pmod(U - 2 * j, R) * 64 + lane];
+                    T.Y[pmod(U, R) * 64 + lane] = vy;
+                }
+            }
+        }
+        vy_row = vy;
+    }
+    // ---- determinant of row c = t - 2S
+    {
+        const int c = t - 2 * S;
+        const float4 xu = T.X[pmod(U - 2 * S, R)], xc = T.X[pmod(U - S, R)], xd = T.X[pmod(U, R)];
+        const float4 yu = T.Y[pmod(U - 2 * S, R) * 64 + lane], yd = vy_row;
+        float4 d;
+#define HS_DET(k, K)                                                                                        \
+        {                                                                                                   \
+            const float xul = hs_l<S, K, XEDGE>(xu, le), xur = hs_r<S, K, XEDGE>(xu, re);                   \
+            const float xcl = hs_l<S, K, XEDGE>(xc, le), xcr = hs_r<S, K, XEDGE>(xc, re);                   \
+            const float xll = hs_l<S, K, XEDGE>(xd, le), xlr = hs_r<S, K, XEDGE>(xd, re);                   \
+            const float yul = hs_l<S, K, XEDGE>(yu, le), yur = hs_r<S, K, XEDGE>(yu, re);                   \
+            const float yll = hs_l<S, K, XEDGE>(yd, le), ylr = hs_r<S, K, XEDGE>(yd, re);                   \
+            const float dxx = HS_DX(xul, xur, xcl, xcr, xll, xlr);                                          \
+            const float dxy = HS_DY(xul, xu.k, xur, xll, xd.k, xlr);                                        \
+            const float dyy = HS_DY(yul, yu.k, yur, yll, yd.k, ylr);                                        \
+            d.k = dxx * dyy - dxy * dxy;                                                                    \
+        }
+        HS_DET(x, 0) __builtin_amdgcn_sched_barrier(0); HS_DET(y, 1) __builtin_amdgcn_sched_barrier(0);
+        HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
+#undef HS_DET
+        T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
+        if (c >= ybeg && c < yend && owns) *reinterpret_cast<float4*>(a.det + (long)c * p + x0) = d;
+    }
+    // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
+    if (a.maps != nullptr) {
+        const int e = t - 2 * S - 1;
+        const float thr = a.threshold;
+        const float4 v = T.Dc;
+        // threshold first: almost no pixel passes it, so the wave almost always skips the neighbourhood test
+        const bool any = owns && (v.x > thr || v.y > thr || v.z > thr || v.w > thr);
+        if (e >= ybeg && e < yend && __ballot(any) != 0ull &&
+            e >= a.psz && (int)(e - a.border + 0.5f) - 1 >= 0 && (int)(e + a.border + 0.5f) + 1 < h) {
+            const float4 up = T.Dm, dn = T.Dp;
+            const float vl = wave_shr1(v.w), vr = wave_shl1(v.x);
+            const float ul = wave_shr1(up.w), ur = wave_shl1(up.x);
+            const float dl = wave_shr1(dn.w), dr = wave_shl1(dn.x);
+            const bool hx = owns && (xok & 1u) && v.x > thr && v.x > up.x && v.x > dn.x && v.x > vl && v.x > v.y &&
+                            v.x > ul && v.x > up.y && v.x > dl && v.x > dn.y;
+            const bool hy = owns && (xok & 2u) && v.y > thr && v.y > up.y && v.y > dn.y && v.y > v.x && v.y > v.z &&
+                            v.y > up.x && v.y > up.z && v.y > dn.x && v.y > dn.z;
+            const bool hz = owns && (xok & 4u) && v.z > thr && v.z > up.z && v.z > dn.z && v.z > v.y && v.z > v.w &&
+                            v.z > up.y && v.z > up.w && v.z > dn.y && v.z > dn.w;
+            const bool hw = owns && (xok & 8u) && v.w > thr && v.w > up.w && v.w > dn.w && v.w > v.z && v.w > vr &&
+                            v.w > up.z && v.w > ur && v.w > dn.z && v.w > dr;
+            if (__ballot(hx || hy || hz || hw) != 0ull) {
+                hs_emit(hx, v.x, x0, e, a, lane);
+                hs_emit(hy, v.y, x0 + 1, e, a, lane);
+                hs_emit(hz, v.z, x0 + 2, e, a, lane);
+                hs_emit(hw, v.w, x0 + 3, e, a, lane);
+            }
+        }
+    }
+}
+
+template <int S, bool XEDGE, bool YEDGE, int... U>
+__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<S>& T, const int tb, const HsArgs& a,
+                                         const int xl, const int x0, const int ybeg, const int yend, const bool owns,
+                                         const unsigned xok, const int lane)
+{
+    (hs_iter<S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane), ...);
+}
+
+template <int S, bool XEDGE>
+__device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const int ybeg, const int yend, const bool owns,
+                                         const int lane, float4* yring)
+{
+    using G = HsGeo<S>;
+    const int h = a.h, w = a.w;
+    const int xl = min(max(x0, 0), a.p - 4);                    // keep every lane's loads inside the plane
+    const int t0 = max(0, ybeg - 1 - 2 * S);                    // first input row
+    const int tend = yend + 2 * S;                              // iteration that tests the segment's last row for extrema
+    // per-component x range of the extrema test (akazed.cu:1351-1356), constant along the strip
+    unsigned xok = 0;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int x = x0 + k;
+        if (x >= a.psz && (int)(x - a.border + 0.5f) - 1 >= 0 && (int)(x + a.border + 0.5f) + 1 < w) xok |= 1u << k;
+    }
+    HsState<S> T;
+    T.Y = yring;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
+    T.Dm = T.Dc = T.Dp = z4;
+    T.Q0 = *reinterpret_cast<const float4*>(a.src + (long)min(t0, h - 1) * a.p + xl);
+    T.Q1 = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + 1, h - 1) * a.p + xl);
+    T.Q2 = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + 2, h - 1) * a.p + xl);
+    for (int tb = t0; tb <= tend; tb += G::R) {
+        // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
+        if (tb <= 2 * S || tb + G::R - 1 >= h)
+            hs_group<S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+        else
+            hs_group<S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+    }
+}
+
+// grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
+template <int S>
+__global__ __launch_bounds__(256) void k_hessian_stream(HsArgs a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
+{
+    using G = HsGeo<S>;
+    __shared__ float4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    a.src += (long)img * stride; a.lx += (long)img * stride; a.ly += (long)img * stride; a.det += (long)img * stride;
+    if (a.maps) { a.maps += (long)img * map_stride; a.cand += (long)img * a.cand_cap; a.st += img; }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ybeg = (by * 4 + wv) * ry;
+    if (ybeg >= a.h) return;                                    // wave-uniform
+    const int yend = min(ybeg + ry, a.h);
+    const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
+    const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
+    // only the strips that contain image column 0 or w-1 pay for the reflect selects
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64);
+    else hs_strip<S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64);
+}
+
+template <int S>
+void launch_stream(hipStream_t st, HsArgs a, long stride, long map_stride, int nimg)
+{
+    using G = HsGeo<S>;
+    const int gx = (a.w + G::XV - 1) / G::XV;
+    // rows per wave: tall segments amortise the 4S+2 warm-up rows; shrink while the grid cannot fill the chip
+    int ry = 128;
+    while (ry > 16 && (long)gx * ((a.h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    const int gy = (a.h + 4 * ry - 1) / (4 * ry);
+    k_hessian_stream<S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
+}
+
+}   // namespace
+
+// returns false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
+bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                               int w, int h, int p, int nimg, int step, float fac1, float fac2,
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+{
+    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
+    HsArgs a{};
+    a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
+    long map_stride = 0;
+    if (b) {
+        const int layer = octave * L->ms + sub;
+        a.maps = b->maps; map_stride = b->map_stride; a.cand = b->cand; a.cand_cap = b->cand_cap; a.st = b->state;
+        a.p0 = L->oct[0].p; a.octave = octave; a.layer = layer;
+        a.psz = (int)htab->borders[octave * L->ms]; a.border = htab->borders[layer]; a.threshold = dthreshold;
+    }
+    switch (step) {
+    case 1: launch_stream<1>(st, a, stride, map_stride, nimg); break;
+    case 2: launch_stream<2>(st, a, stride, map_stride, nimg); break;
+    case 3: launch_stream<3>(st, a, stride, map_stride, nimg); break;
+    default: launch_stream<4>(st, a, stride, map_stride, nimg); break;
+    }
+    return true;
+}
