@@ -67,3 +67,33 @@ __device__ __forceinline__ V4 fed_row(const V4 Lc, const V4 Ln, const V4 Ls, con
     return o;
 }
 
+
+// ---- sigma=1 low-pass taps and the conductivity, per element type (kernels_smoothflow.hip, kernels_fedsf.hip).
+// int: every pass of the separable Gaussian ends in >> 16 (akazed.cu:2922-2985), the gradient energy is formed in wrapping
+// int32 and the conductivity is kept as (int)(g * 65536 + 0.5f) (akazed.cu:3406-3445).
+template <typename V> struct SfTaps { V k0, k1, k2; };
+__device__ __forceinline__ float sf_conv(float c, float a1, float b1, float a2, float b2, const SfTaps<float>& t)
+{
+    float ws = c * t.k0;
+    ws += t.k1 * (a1 + b1);
+    ws += t.k2 * (a2 + b2);
+    return ws;
+}
+__device__ __forceinline__ int sf_conv(int c, int a1, int b1, int a2, int b2, const SfTaps<int>& t)
+{
+    const unsigned ws = (unsigned)c * (unsigned)t.k0 + (unsigned)t.k1 * (unsigned)(a1 + b1) + (unsigned)t.k2 * (unsigned)(a2 + b2);
+    return (int)ws >> 16;
+}
+__device__ __forceinline__ float sf_dif2(float dx, float dy, float ikc) { return ikc * (dx * dx + dy * dy); }
+__device__ __forceinline__ float sf_dif2(int dx, int dy, float ikc)
+{
+    return (float)(int)((unsigned)dx * (unsigned)dx + (unsigned)dy * (unsigned)dy) * ikc;
+}
+__device__ __forceinline__ void sf_store_g(float* o, float g) { *o = g; }
+__device__ __forceinline__ void sf_store_g(int* o, float g) { *o = (int)(g * 65536 + 0.5f); }
+
+__device__ __forceinline__ float sf_g_value(float g) { return g; }
+__device__ __forceinline__ int sf_g_value_int(float g) { return (int)(g * 65536 + 0.5f); }
+template <typename V> __device__ __forceinline__ V sf_g_as(float g);
+template <> __device__ __forceinline__ float sf_g_as<float>(float g) { return g; }
+template <> __device__ __forceinline__ int sf_g_as<int>(float g) { return (int)(g * 65536 + 0.5f); }

@@ -523,19 +523,26 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             const bool fused = (oc.w % 4) == 0;
             const int G = fused ? hak_fed_groups(n, c->max_fuse, oc.w) : n;
             const int* src;
+            bool fused_first = false;
             if (s == 0) {                                                         // akaze.cpp:640-662
                 int* first = (G % 2 == 0) ? Lt : tmp;
                 hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
                 src = first;
                 hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
-            } else {                                                              // akaze.cpp:664-695: low-pass + flow in one pass
+            } else {                                                              // akaze.cpp:664-695
                 src = A + L.lt(o, s - 1);
-                hakf_launch_smooth_flow(st, src, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->itaps1, cfg.diffusivity, c->state, o);
+                // low-pass + conductivity + first FED group in one streaming pass when covered, else low-pass + flow in one tile pass
+                if (fused && c->fuse_sf)
+                    fused_first = hakf_launch_fed_sf(st, src, smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc.w, oc.h, oc.p, nimg, c->itaps1,
+                                                     cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0), c->state, o, G > 1);
+                if (!fused_first)
+                    hakf_launch_smooth_flow(st, src, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->itaps1, cfg.diffusivity, c->state, o);
             }
             int done = 0;
             for (int g = 0; g < G; g++) {
                 const int ns = fused ? hak_fed_group_size(n, G, g) : 1;
                 int* dst = ((G - g) % 2 == 1) ? Lt : tmp;
+                if (g == 0 && fused_first) { done += ns; src = dst; continue; }
                 if (fused) hakf_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
                 else hakf_launch_nld_step(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau[done]);
                 done += ns;

@@ -211,6 +211,9 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
                             const HakImgState* state, int octave, float fixed_ikc);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
+bool hakf_launch_fed_sf(hipStream_t st, const int* src, int* smooth, int* flow, int* dst, long stride,
+                        int w, int h, int p, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
+                        const HakImgState* state, int octave, bool write_g);
 bool hak_launch_fed_sf(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride,
                        int w, int h, int p, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
                        const HakImgState* state, int octave, float fixed_ikc, bool write_g);

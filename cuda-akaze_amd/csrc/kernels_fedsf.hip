@@ -24,50 +24,51 @@
 // position IS the smooth value at the reflected index, which is what gFlowNaive reads), for the smooth ring and
 // for the FED rings as before.
 //
-// Float path, PM_G2, w % 4 == 0 only; everything else takes k_smooth_flow + k_fed_multi.
+// Both element types (float: akaze, int: fastakaze 16.16), PM_G2, w % 4 == 0 only; everything else takes
+// k_smooth_flow + k_fed_multi.
 #include "fed_common.h"
 
 namespace {
 
-struct SfK { float k0, k1, k2; };
-
-template <int NS>
+template <typename V, int NS>
 struct FsState {
+    using V4 = typename FedV<V>::V4;
     static constexpr int GS = 6;
     static constexpr int PD = 3;
-    float4 Lr[6];                       // L rows t-5 .. t                      slot = iteration mod 6
-    float4 Rp[6];                       // row-pass rows t-5 .. t
-    float4 Sm[3];                       // smooth rows a-2 .. a (a = t-2)       slot = iteration mod 3
-    float SmL[3], SmR[3];               // smooth at columns x0-1 and x0+4 of those rows
-    float4 Lw[NS][3];                   // FED level k >= 1 windows ([0] unused: level 0 reads Lr)
-    GHrow<float> GH[GS];
-    float4 GV[GS];
-    float4 gprev;
-    float4 Lq[PD];                      // prefetch ring
+    V4 Lr[6];                           // L rows t-5 .. t                      slot = iteration mod 6
+    V4 Rp[6];                           // row-pass rows t-5 .. t
+    V4 Sm[3];                           // smooth rows a-2 .. a (a = t-2)       slot = iteration mod 3
+    V SmL[3], SmR[3];                   // smooth at columns x0-1 and x0+4 of those rows
+    V4 Lw[NS][3];                       // FED level k >= 1 windows ([0] unused: level 0 reads Lr)
+    GHrow<V> GH[GS];
+    V4 GV[GS];
+    V4 gprev;
+    V4 Lq[PD];                          // prefetch ring
 };
 
-template <int NS, int U, bool YEDGE, bool XE, bool WRITE_G>
-__device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float* __restrict__ L, float* __restrict__ SMO,
-                                        float* __restrict__ GO, float* __restrict__ D, const int p, const int xl,
+template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G>
+__device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V* __restrict__ L, V* __restrict__ SMO,
+                                        V* __restrict__ GO, V* __restrict__ D, const int p, const int xl,
                                         const int x0, const int w, const int h, const int ybeg, const int yend,
-                                        const bool owns, const FedFacs<float, NS>& fac, const SfK kk, const float ikc)
+                                        const bool owns, const FedFacs<V, NS>& fac, const SfTaps<V> kk, const float ikc)
 {
-    constexpr int GS = FsState<NS>::GS, PD = FsState<NS>::PD;
+    using V4 = typename FedV<V>::V4;
+    constexpr int GS = FsState<V, NS>::GS, PD = FsState<V, NS>::PD;
     const bool le = x0 == 0, re = x0 + 3 == w - 1;
     // ---- L row t arrives; request row t + PD (clamped: rows past the image are never used)
     {
-        const float4 Lc = S.Lq[pmod(U, PD)];
+        const V4 Lc = S.Lq[pmod(U, PD)];
         S.Lr[pmod(U, 6)] = Lc;
-        S.Lq[pmod(U, PD)] = *reinterpret_cast<const float4*>(L + (long)min(t + PD, h - 1) * p + xl);
+        S.Lq[pmod(U, PD)] = *reinterpret_cast<const V4*>(L + (long)min(t + PD, h - 1) * p + xl);
         if (YEDGE && t == 1) S.Lr[pmod(U - 2, 6)] = Lc;                              // FED: row -1 := row 1
         if (YEDGE && t == h) S.Lr[pmod(U, 6)] = S.Lr[pmod(U - 2, 6)];                // FED: row h := row h-2
     }
     // ---- row pass of the Gaussian on row t (akazed.cu:227-239)
     {
-        const float4 c = S.Lr[pmod(U, 6)];
-        const float sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
-        float4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
-        float4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
+        const V4 c = S.Lr[pmod(U, 6)];
+        const V sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
+        V4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
+        V4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
         if (XE) {
             l1.x = le ? c.y : l1.x;                         // column -1 -> 1
             l2.x = le ? c.z : l2.x;                         // column -2 -> 2
@@ -76,11 +77,11 @@ __device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float
             r2.z = re ? c.z : r2.z;                         // column w   -> w-2
             r2.w = re ? c.y : r2.w;                         // column w+1 -> w-3
         }
-        float4 rp;
-        rp.x = c.x * kk.k0; rp.x += kk.k1 * (l1.x + r1.x); rp.x += kk.k2 * (l2.x + r2.x);
-        rp.y = c.y * kk.k0; rp.y += kk.k1 * (l1.y + r1.y); rp.y += kk.k2 * (l2.y + r2.y);
-        rp.z = c.z * kk.k0; rp.z += kk.k1 * (l1.z + r1.z); rp.z += kk.k2 * (l2.z + r2.z);
-        rp.w = c.w * kk.k0; rp.w += kk.k1 * (l1.w + r1.w); rp.w += kk.k2 * (l2.w + r2.w);
+        V4 rp;
+        rp.x = sf_conv(c.x, l1.x, r1.x, l2.x, r2.x, kk);
+        rp.y = sf_conv(c.y, l1.y, r1.y, l2.y, r2.y, kk);
+        rp.z = sf_conv(c.z, l1.z, r1.z, l2.z, r2.z, kk);
+        rp.w = sf_conv(c.w, l1.w, r1.w, l2.w, r2.w, kk);
         S.Rp[pmod(U, 6)] = rp;
         if (YEDGE) {
             if (t == 1) S.Rp[pmod(U - 2, 6)] = rp;                                   // row -1 := row 1
@@ -92,15 +93,15 @@ __device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float
     // ---- column pass -> smooth row a = t - 2 (akazed.cu:283-288)
     {
         const int a = t - 2;
-        const float4 c = S.Rp[pmod(U - 2, 6)], u1 = S.Rp[pmod(U - 3, 6)], d1 = S.Rp[pmod(U - 1, 6)];
-        const float4 u2 = S.Rp[pmod(U - 4, 6)], d2 = S.Rp[pmod(U, 6)];
-        float4 sm;
-        sm.x = c.x * kk.k0; sm.x += kk.k1 * (u1.x + d1.x); sm.x += kk.k2 * (u2.x + d2.x);
-        sm.y = c.y * kk.k0; sm.y += kk.k1 * (u1.y + d1.y); sm.y += kk.k2 * (u2.y + d2.y);
-        sm.z = c.z * kk.k0; sm.z += kk.k1 * (u1.z + d1.z); sm.z += kk.k2 * (u2.z + d2.z);
-        sm.w = c.w * kk.k0; sm.w += kk.k1 * (u1.w + d1.w); sm.w += kk.k2 * (u2.w + d2.w);
-        if (a >= ybeg && a < yend && owns) *reinterpret_cast<float4*>(SMO + (long)a * p + x0) = sm;
-        float sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
+        const V4 c = S.Rp[pmod(U - 2, 6)], u1 = S.Rp[pmod(U - 3, 6)], d1 = S.Rp[pmod(U - 1, 6)];
+        const V4 u2 = S.Rp[pmod(U - 4, 6)], d2 = S.Rp[pmod(U, 6)];
+        V4 sm;
+        sm.x = sf_conv(c.x, u1.x, d1.x, u2.x, d2.x, kk);
+        sm.y = sf_conv(c.y, u1.y, d1.y, u2.y, d2.y, kk);
+        sm.z = sf_conv(c.z, u1.z, d1.z, u2.z, d2.z, kk);
+        sm.w = sf_conv(c.w, u1.w, d1.w, u2.w, d2.w, kk);
+        if (a >= ybeg && a < yend && owns) *reinterpret_cast<V4*>(SMO + (long)a * p + x0) = sm;
+        V sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
         if (XE) {
             sl = le ? sm.y : sl;                            // abs(x-1) = 1
             sr = re ? sm.z : sr;                            // borderAdd(x,1,w) = w-2
@@ -114,32 +115,32 @@ __device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float
     // ---- conductivity row b = t - 3 (akazed.cu:1088-1098, PM_G2) and the FED rings' level-0 bookkeeping for that row
     const int tf = t - 3;                                   // the FED part runs three rows behind the input
     {
-        const float4 su = S.Sm[pmod(U - 2, 3)], sc = S.Sm[pmod(U - 1, 3)], sd = S.Sm[pmod(U, 3)];
-        const float uL = S.SmL[pmod(U - 2, 3)], uR = S.SmR[pmod(U - 2, 3)];
-        const float cL = S.SmL[pmod(U - 1, 3)], cR = S.SmR[pmod(U - 1, 3)];
-        const float dL = S.SmL[pmod(U, 3)], dR = S.SmR[pmod(U, 3)];
-        float4 g;
+        const V4 su = S.Sm[pmod(U - 2, 3)], sc = S.Sm[pmod(U - 1, 3)], sd = S.Sm[pmod(U, 3)];
+        const V uL = S.SmL[pmod(U - 2, 3)], uR = S.SmR[pmod(U - 2, 3)];
+        const V cL = S.SmL[pmod(U - 1, 3)], cR = S.SmR[pmod(U - 1, 3)];
+        const V dL = S.SmL[pmod(U, 3)], dR = S.SmR[pmod(U, 3)];
+        V4 g;
 #define FS_G(k, ul, uc, ur, cl, cr, ll, lc, lr)                                             \
         {                                                                                   \
-            const float dx = 10 * ((cr) - (cl)) + 3 * ((ur) + (lr) - (ul) - (ll));          \
-            const float dy = 10 * ((lc) - (uc)) + 3 * ((ll) + (lr) - (ul) - (ur));          \
-            const float dif2 = ikc * (dx * dx + dy * dy);                                   \
-            g.k = 1.f / (1.f + dif2);                                                       \
+            const V dx = 10 * ((cr) - (cl)) + 3 * ((ur) + (lr) - (ul) - (ll));              \
+            const V dy = 10 * ((lc) - (uc)) + 3 * ((ll) + (lr) - (ul) - (ur));              \
+            const float dif2 = sf_dif2(dx, dy, ikc);                                        \
+            g.k = sf_g_as<V>(1.f / (1.f + dif2));                                           \
         }
         FS_G(x, uL, su.x, su.y, cL, sc.y, dL, sd.x, sd.y)
         FS_G(y, su.x, su.y, su.z, sc.x, sc.z, sd.x, sd.y, sd.z)
         FS_G(z, su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w)
         FS_G(w, su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR)
 #undef FS_G
-        if (WRITE_G && tf >= ybeg && tf < yend && owns) *reinterpret_cast<float4*>(GO + (long)tf * p + x0) = g;
-        const float gl = wave_shr1(g.w), gr = wave_shl1(g.x);
-        GHrow<float> gh{gl + g.x, g.x + g.y, g.y + g.z, g.z + g.w, g.w + gr};
+        if (WRITE_G && tf >= ybeg && tf < yend && owns) *reinterpret_cast<V4*>(GO + (long)tf * p + x0) = g;
+        const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
+        GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         if (XE) {
             gh.h0 = le ? gh.h1 : gh.h0;                     // (g+gW) at x == 0 is (g+gE)
             gh.h4 = re ? gh.h3 : gh.h4;                     // (g+gE) at x == w-1 is (g+gW)
         }
         S.GH[pmod(U, GS)] = gh;
-        S.GV[pmod(U - 1, GS)] = mk4(S.gprev.x + g.x, S.gprev.y + g.y, S.gprev.z + g.z, S.gprev.w + g.w);
+        S.GV[pmod(U - 1, GS)] = mk4(vadd(S.gprev.x, g.x), vadd(S.gprev.y, g.y), vadd(S.gprev.z, g.z), vadd(S.gprev.w, g.w));
         S.gprev = g;
         if (YEDGE && tf == 1) S.GV[pmod(U - 2, GS)] = S.GV[pmod(U - 1, GS)];        // GV[-1] := GV[0]
         if (YEDGE && tf == h) S.GV[pmod(U - 1, GS)] = S.GV[pmod(U - 2, GS)];        // GV[h-1] := GV[h-2]
@@ -149,62 +150,64 @@ __device__ __forceinline__ void fs_iter(FsState<NS>& S, const int t, const float
     for (int k = 1; k <= NS; k++) {
         const int rho = tf - k;
         // level 0 = the L ring (row tf-j lives in slot U-3-j); levels >= 1 = their 3-row windows
-        const float4 Lc = k == 1 ? S.Lr[pmod(U - 3 - 1, 6)] : S.Lw[k - 1][pmod(U - k, 3)];
-        const float4 Ln = k == 1 ? S.Lr[pmod(U - 3 - 2, 6)] : S.Lw[k - 1][pmod(U - k - 1, 3)];
-        const float4 Ls = k == 1 ? S.Lr[pmod(U - 3, 6)] : S.Lw[k - 1][pmod(U - k + 1, 3)];
-        const float4 out = fed_row<XE, float, float4>(Lc, Ln, Ls, S.GH[pmod(U - k, GS)], S.GV[pmod(U - k, GS)],
+        const V4 Lc = k == 1 ? S.Lr[pmod(U - 3 - 1, 6)] : S.Lw[k - 1][pmod(U - k, 3)];
+        const V4 Ln = k == 1 ? S.Lr[pmod(U - 3 - 2, 6)] : S.Lw[k - 1][pmod(U - k - 1, 3)];
+        const V4 Ls = k == 1 ? S.Lr[pmod(U - 3, 6)] : S.Lw[k - 1][pmod(U - k + 1, 3)];
+        const V4 out = fed_row<XE, V, V4>(Lc, Ln, Ls, S.GH[pmod(U - k, GS)], S.GV[pmod(U - k, GS)],
                                                       S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
         if (k < NS) {
             S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
         } else if (rho >= ybeg && rho < yend && owns) {
-            *reinterpret_cast<float4*>(D + (long)rho * p + x0) = out;
+            *reinterpret_cast<V4*>(D + (long)rho * p + x0) = out;
         }
     }
 }
 
-template <int NS, bool XE, bool WRITE_G>
-__device__ __forceinline__ void fs_strip(const float* __restrict__ L, float* __restrict__ SMO, float* __restrict__ GO,
-                                         float* __restrict__ D, int w, int h, int p, const FedFacs<float, NS>& fac,
-                                         const SfK kk, const float ikc, int x0, int ybeg, int yend, bool owns)
+template <typename V, int NS, bool XE, bool WRITE_G>
+__device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict__ SMO, V* __restrict__ GO,
+                                         V* __restrict__ D, int w, int h, int p, const FedFacs<V, NS>& fac,
+                                         const SfTaps<V> kk, const float ikc, int x0, int ybeg, int yend, bool owns)
 {
+    using V4 = typename FedV<V>::V4;
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
     const int t0 = max(0, ybeg - NS - 4);                   // rp from t0, smooth from t0+2, g from t0+3, level k from t0+3+k
     const int tend = min(yend - 1, h - 1) + NS + 3;         // iteration that emits the strip's last L' row
-    FsState<NS> S;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    FsState<V, NS> S;
+    const V z = 0;
+    const V4 z4 = mk4(z, z, z, z);
 #pragma unroll
     for (int i = 0; i < 6; i++) { S.Lr[i] = z4; S.Rp[i] = z4; }
 #pragma unroll
-    for (int i = 0; i < 3; i++) { S.Sm[i] = z4; S.SmL[i] = 0.f; S.SmR[i] = 0.f; }
+    for (int i = 0; i < 3; i++) { S.Sm[i] = z4; S.SmL[i] = z; S.SmR[i] = z; }
 #pragma unroll
     for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = z4;
 #pragma unroll
-    for (int i = 0; i < FsState<NS>::GS; i++) {
-        S.GH[i] = GHrow<float>{0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < FsState<V, NS>::GS; i++) {
+        S.GH[i] = GHrow<V>{z, z, z, z, z};
         S.GV[i] = z4;
     }
     S.gprev = z4;
 #pragma unroll
-    for (int i = 0; i < FsState<NS>::PD; i++)
-        S.Lq[i] = *reinterpret_cast<const float4*>(L + (long)min(t0 + i, h - 1) * p + xl);
+    for (int i = 0; i < FsState<V, NS>::PD; i++)
+        S.Lq[i] = *reinterpret_cast<const V4*>(L + (long)min(t0 + i, h - 1) * p + xl);
     for (int tb = t0; tb <= tend; tb += 6) {
         // reflect injections fire while some stage is at rows 1..2 (t <= NS + 4) or at the virtual rows past h-1
         if (tb <= NS + 4 || tb + 5 >= h) {
-            fs_iter<NS, 0, true, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 1, true, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 2, true, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 3, true, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 4, true, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 5, true, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 0, true, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 1, true, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 2, true, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 3, true, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 4, true, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 5, true, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
         } else {
-            fs_iter<NS, 0, false, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 1, false, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 2, false, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 3, false, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 4, false, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<NS, 5, false, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 0, false, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 1, false, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 2, false, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 3, false, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 4, false, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 5, false, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
         }
     }
 }
@@ -213,18 +216,18 @@ constexpr int FS_HX = 8;                                    // x halo: 2 (Gaussi
 constexpr int FS_XV = 256 - 2 * FS_HX;
 
 // grid: hak_xcd_grid(strips, strip-row groups, images); a block's four waves take four consecutive row segments
-template <int NS, bool WRITE_G>
-__global__ __launch_bounds__(256) void k_fed_sf(const float* __restrict__ src, float* __restrict__ smooth, float* __restrict__ flow,
-                                                float* __restrict__ dst, long stride, int w, int h, int p,
-                                                FedFacs<float, NS> fac, SfK kk, const HakImgState* __restrict__ state, int octave,
+template <typename V, int NS, bool WRITE_G>
+__global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __restrict__ smooth, V* __restrict__ flow,
+                                                V* __restrict__ dst, long stride, int w, int h, int p,
+                                                FedFacs<V, NS> fac, SfTaps<V> kk, const HakImgState* __restrict__ state, int octave,
                                                 float fixed_ikc, int ry, int nbx, int nby, int nimg)
 {
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
-    const float* L = src + (long)img * stride;
-    float* SMO = smooth + (long)img * stride;
-    float* GO = flow + (long)img * stride;
-    float* D = dst + (long)img * stride;
+    const V* L = src + (long)img * stride;
+    V* SMO = smooth + (long)img * stride;
+    V* GO = flow + (long)img * stride;
+    V* D = dst + (long)img * stride;
     const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -233,28 +236,45 @@ __global__ __launch_bounds__(256) void k_fed_sf(const float* __restrict__ src, f
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= FS_HX && 4 * lane < FS_HX + FS_XV && x0 < w && x0 >= 0;
-    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<NS, true, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
-    else fs_strip<NS, false, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
+    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<V, NS, true, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
+    else fs_strip<V, NS, false, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
 }
 
-template <int NS>
-void launch_fs(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride, int w, int h, int p,
-               int nimg, const float* taps, const float* tau, const HakImgState* state, int octave, float fixed_ikc, bool write_g)
+template <typename V, int NS>
+void launch_fs(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long stride, int w, int h, int p,
+               int nimg, SfTaps<V> kk, const float* tau, const HakImgState* state, int octave, float fixed_ikc, bool write_g)
 {
-    FedFacs<float, NS> fac;
-    for (int k = 0; k < NS; k++) fac.f[k] = 0.5f * tau[k];          // akazed.cu:2515
-    const SfK kk{taps[0], taps[1], taps[2]};
+    FedFacs<V, NS> fac;
+    for (int k = 0; k < NS; k++) {
+        if constexpr (std::is_same<V, float>::value) fac.f[k] = 0.5f * tau[k];      // akazed.cu:2515
+        else fac.f[k] = (int)(0.5f * tau[k] * 65536 + 0.5f);                        // akazed.cu:4235
+    }
     const int gx = (w + FS_XV - 1) / FS_XV;
     // rows per wave: tall segments amortise the NS+4 warm-up rows; shrink while the grid cannot fill the chip
     int ry = 128;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (h + 4 * ry - 1) / (4 * ry);
     if (write_g)
-        k_fed_sf<NS, true><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
-                                                                      fixed_ikc, ry, gx, gy, nimg);
+        k_fed_sf<V, NS, true><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
+                                                                         fixed_ikc, ry, gx, gy, nimg);
     else
-        k_fed_sf<NS, false><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
-                                                                       fixed_ikc, ry, gx, gy, nimg);
+        k_fed_sf<V, NS, false><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
+                                                                          fixed_ikc, ry, gx, gy, nimg);
+}
+
+template <typename V>
+bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long stride, int w, int h, int p, int nimg,
+                   SfTaps<V> kk, int diffusivity, const float* tau, int ns, const HakImgState* state, int octave, float fixed_ikc,
+                   bool write_g)
+{
+    if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
+    switch (ns) {
+    case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
+    case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
+    case 3: launch_fs<V, 3>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
+    default: launch_fs<V, 4>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
+    }
+    return true;
 }
 
 }   // namespace
@@ -265,12 +285,15 @@ bool hak_launch_fed_sf(hipStream_t st, const float* src, float* smooth, float* f
                        int w, int h, int p, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
                        const HakImgState* state, int octave, float fixed_ikc, bool write_g)
 {
-    if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
-    switch (ns) {
-    case 1: launch_fs<1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
-    case 2: launch_fs<2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
-    case 3: launch_fs<3>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
-    default: launch_fs<4>(st, src, smooth, flow, dst, stride, w, h, p, nimg, taps, tau, state, octave, fixed_ikc, write_g); break;
-    }
-    return true;
+    return launch_fs_any<float>(st, src, smooth, flow, dst, stride, w, h, p, nimg, SfTaps<float>{taps[0], taps[1], taps[2]},
+                                diffusivity, tau, ns, state, octave, fixed_ikc, write_g);
+}
+
+// the integer FAST path's sublevel head (akaze.cpp:664-695): itaps = (int)(tap * 65536 + 0.5f)
+bool hakf_launch_fed_sf(hipStream_t st, const int* src, int* smooth, int* flow, int* dst, long stride,
+                        int w, int h, int p, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
+                        const HakImgState* state, int octave, bool write_g)
+{
+    return launch_fs_any<int>(st, src, smooth, flow, dst, stride, w, h, p, nimg, SfTaps<int>{itaps[0], itaps[1], itaps[2]},
+                              diffusivity, tau, ns, state, octave, 0.f, write_g);
 }

@@ -13,7 +13,7 @@
 // (akazed.cu:237, 286), so the smooth value computed at a mirrored position equals the smooth value
 // at the reflected coordinate bit for bit -- which is exactly what gFlowNaive reads at the border
 // (abs / borderAdd, akazed.cu:1078-1081).
-#include "hak_internal.h"
+#include "fed_common.h"
 
 #define SF_TX 64
 #define SF_TY 32
@@ -25,27 +25,6 @@
 
 // Shared by both pipelines: V = float (akaze) and V = int (fastakaze, 16.16 fixed point: every pass of the separable
 // Gaussian ends in >> 16 (akazed.cu:2922-2985) and the conductivity is stored as (int)(g * 65536 + 0.5f), akazed.cu:3444).
-template <typename V> struct SfTaps { V k0, k1, k2; };
-__device__ __forceinline__ float sf_conv(float c, float a1, float b1, float a2, float b2, const SfTaps<float>& t)
-{
-    float ws = c * t.k0;
-    ws += t.k1 * (a1 + b1);
-    ws += t.k2 * (a2 + b2);
-    return ws;
-}
-__device__ __forceinline__ int sf_conv(int c, int a1, int b1, int a2, int b2, const SfTaps<int>& t)
-{
-    const unsigned ws = (unsigned)c * (unsigned)t.k0 + (unsigned)t.k1 * (unsigned)(a1 + b1) + (unsigned)t.k2 * (unsigned)(a2 + b2);
-    return (int)ws >> 16;
-}
-__device__ __forceinline__ float sf_dif2(float dx, float dy, float ikc) { return ikc * (dx * dx + dy * dy); }
-__device__ __forceinline__ float sf_dif2(int dx, int dy, float ikc)
-{
-    return (float)(int)((unsigned)dx * (unsigned)dx + (unsigned)dy * (unsigned)dy) * ikc;
-}
-__device__ __forceinline__ void sf_store_g(float* o, float g) { *o = g; }
-__device__ __forceinline__ void sf_store_g(int* o, float g) { *o = (int)(g * 65536 + 0.5f); }
-
 template <typename V>
 __device__ __forceinline__ void sf_fetch(V (&pf)[SF_NPF], const V* __restrict__ s, int w, int h, int p,
                                          int x0, int y0, int tid)
