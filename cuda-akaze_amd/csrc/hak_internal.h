@@ -189,6 +189,7 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
                      int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
 // derivate + determinant of one level, with the level's extrema search fused in when b != nullptr
 // (kernels_hessian.hip); returns false when the caller still has to run hak_launch_extrema_level
+extern int hak_hessian_stream_enabled;
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);

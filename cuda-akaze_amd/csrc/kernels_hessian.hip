@@ -347,6 +347,9 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
     return ex;
 }
 
+// process-wide switch, refreshed from HAK_HESS_STREAM by every hak_create (default on)
+int hak_hessian_stream_enabled = 1;
+
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
 // extrema were handled here; false means the caller must run the stand-alone extrema kernel.
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
@@ -354,8 +357,7 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
     // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
-    static const bool use_stream = !(getenv("HAK_HESS_STREAM") && atoi(getenv("HAK_HESS_STREAM")) == 0);
-    if (use_stream) {
+    if (hak_hessian_stream_enabled) {
         float f1, f2;
         deriv_factors(f1, f2);
         if (hak_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))

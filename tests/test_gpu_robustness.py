@@ -210,3 +210,45 @@ def test_knn2_with_context_scratch_and_repeat(ah, okz, torch, synth):
         for f in ah.MATCH_PAIR_DTYPE.names:
             assert np.array_equal(h_out[:cnt.value][f], want[f]), f
     det.close()
+
+
+@pytest.mark.parametrize("env", [{"HAK_FUSE_SF": "0"}, {"HAK_HESS_STREAM": "0"}, {"HAK_FED_MAX_FUSE": "1"}, {"HAK_GRAPH": "0", "HAK_SERIAL": "1"},
+                                 {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_FED_MAX_FUSE": "2"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
+def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
+    """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
+    persistent planes: the fused / streaming kernels and the tile kernels they replace are interchangeable"""
+    w, h, mp = 960, 540, 4000
+    p = ah.iAlignUp(w, 128)
+    img = torch.from_numpy(synth.to_float(synth.scene(w, h, 21), p)).cuda()
+
+    def run():
+        det = ah.Akazer()
+        det.init((w, h, p), max_pts=mp)
+        data = ah.AkazeData()
+        ah.initAkazeData(data, mp, True, True)
+        det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
+        pts = data.h_data[:data.num_pts].copy().tobytes()
+        planes = [det.plane(kind, o, s).tobytes() for o in range(len(det.geometry())) for s in range(4) for kind in (0, 1, 2, 3)]
+        ah.freeAkazeData(data)
+        det.close()
+        return pts, planes
+
+    ref_pts, ref_planes = run()
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        alt_pts, alt_planes = run()
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        det = ah.Akazer()                       # restore the process-wide defaults (hak_create re-reads the environment)
+        det.init((w, h, p), max_pts=mp)
+        det._make_ctx(w, h)
+        det.close()
+    assert len(ref_pts) > 104 * 100
+    assert alt_pts == ref_pts
+    assert alt_planes == ref_planes
