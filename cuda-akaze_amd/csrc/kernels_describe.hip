@@ -47,11 +47,16 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
 {
     __shared__ float acc[ACC_ROWS * ACC_LD];    // [cell*3+ch][thread], one round at a time
     __shared__ float vals[90];
-    __shared__ float sdx[128], sdy[128];
-    __shared__ int sbin[128];
-    __shared__ float resx[42], resy[42];
-    __shared__ float re8x[42], re8y[42];
     __shared__ float s_angle;
+    // the orientation scratch is dead before the first accumulator round starts: it lives inside the table
+    // (12.9 KB per block instead of 15.1 KB = 12 instead of 10 keypoints in flight per CU)
+    float* const sdx = acc;                     // [128]
+    float* const sdy = acc + 128;               // [128]
+    int* const sbin = reinterpret_cast<int*>(acc + 256);    // [128]
+    float* const resx = acc + 384;              // [42]
+    float* const resy = acc + 432;              // [42]
+    float* const re8x = acc + 480;              // [42]
+    float* const re8y = acc + 528;              // [42]
 
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
