@@ -432,3 +432,30 @@ def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth):
         for f, v in got_fields.items():
             assert np.array_equal(v, a[f]), f
     det.close()
+
+
+def test_fast_planes_small(ah, okz, torch):
+    """every persistent int32 plane of every level of the FAST path, bit for bit (localises a failing stage)"""
+    w, h = 320, 240
+    u8 = _mg().case_scene(w, h, 11)
+    p = ah.iAlignUp(w, 128)
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    img = torch.from_numpy(pad).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=5000)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, 5000, True, True)
+    det.fastDetectAndCompute(img.data_ptr(), data, (w, h, p), True)
+    r = okz.fast_detect_and_compute(u8, max_pts=5000, keep_arena=True)
+    assert len(det.geometry()) == r.noct
+    for o in range(r.noct):
+        for s in range(4):
+            for kind, nm in ((0, "Lt"), (2, "Lx"), (3, "Ly"), (1, "det")):
+                a = det.plane(kind, o, s).view(np.int32)
+                b = okz.plane(r, kind, o, s)
+                bad = (a != b).sum()
+                assert bad == 0, f"FAST {nm}({o},{s}): {bad} px differ"
+    assert_points_equal(data.h_data[:data.num_pts], r.points)
+    ah.freeAkazeData(data)
+    det.close()
