@@ -69,19 +69,32 @@ __device__ __forceinline__ int hak_refl(int i, int m)
 // phase boundary of the persistent tile kernels.  Use this between phases that only exchange data
 // through LDS; global results are complete at kernel end as usual.
 // XCD-aware block order.  The hardware deals consecutive workgroup ids round-robin to the 8 XCDs (each has its own
-// L2).  A 1-D grid of hak_xcd_grid() blocks is decoded so that all blocks of one image carry ids congruent mod 8:
-// an image's tiles (which share halos) then run on one XCD.  Returns false for the padding blocks (nimg % 8 != 0).
+// L2).  A 1-D grid of hak_xcd_grid() = nbx * nby * nimg blocks is decoded so that, within every full group of 8
+// images, all blocks of one image carry ids congruent mod 8: an image's tiles (which share halos) then run on one
+// XCD.  The nimg % 8 images left over are laid out plainly (no padding blocks: a single-image call launches exactly
+// its own tiles).  Always returns true (kept as a predicate so callers read `if (!decode) return`).
 __device__ __forceinline__ bool hak_xcd_decode(int nbx, int nby, int nimg, int& bx, int& by, int& img)
 {
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int nb = nbx * nby;
-    const int g = j / nb, t = j - g * nb;
-    img = g * 8 + xcd;
+    const int full = nimg & ~7;                             // images covered by complete groups of 8
+    const int bid = blockIdx.x;
+    int t;
+    if (bid < full * nb) {
+        const int xcd = bid & 7, j = bid >> 3;
+        const int g = j / nb;
+        t = j - g * nb;
+        img = g * 8 + xcd;
+    } else {
+        const int r = bid - full * nb;
+        const int k = r / nb;
+        t = r - k * nb;
+        img = full + k;
+    }
     by = t / nbx;
     bx = t - by * nbx;
     return img < nimg;
 }
-static inline unsigned hak_xcd_grid(int nbx, int nby, int nimg) { return 8u * (unsigned)((nimg + 7) / 8) * (unsigned)nbx * (unsigned)nby; }
+static inline unsigned hak_xcd_grid(int nbx, int nby, int nimg) { return (unsigned)nimg * (unsigned)nbx * (unsigned)nby; }
 
 __device__ __forceinline__ void hak_lds_barrier()
 {

@@ -275,15 +275,8 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
     __shared__ V sm[G::SH * G::SW];
     __shared__ V sx[G::DH * G::DW];
     __shared__ V sy[G::DH * G::DW];
-    // XCD-aware block order: the hardware deals consecutive workgroup ids round-robin to the 8 XCDs, each with
-    // its own L2.  Tiles that share halos (one image) are therefore given ids that are congruent mod 8, so a
-    // whole image is processed on one XCD and the halo re-reads hit that XCD's L2.
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int nb = ntx * nby;
-    const int img = (j / nb) * 8 + xcd;
-    if (img >= nimg) return;
-    const int t = j - (j / nb) * nb;
-    const int bx = t % ntx, by = t / ntx;
+    int bx, by, img;                                              // XCD-aware block order (hak_internal.h)
+    if (!hak_xcd_decode(ntx, nby, nimg, bx, by, img)) return;
     const V* s = src + (long)img * stride;
     V* ox = lx + (long)img * stride;
     V* oy = ly + (long)img * stride;
@@ -330,8 +323,7 @@ static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, lon
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
-    const long nblocks = 8L * ((nimg + 7) / 8) * ntx * nby;
-    k_hessian_fused<V, S><<<dim3((unsigned)nblocks), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex);
+    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex);
 }
 
 template <typename V>
