@@ -168,7 +168,8 @@ struct hak_ctx {
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
-    bool fuse_sf = true;            // low-pass + conductivity fused into the first FED launch of a sublevel (env HAK_FUSE_SF=0 disables)
+    int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
+                                    // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
 };
@@ -292,8 +293,8 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     c->cfg = *cfg;
     if (c->cfg.batch < 1) c->cfg.batch = 1;
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
-    if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e) != 0;
-    { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = !(e && atoi(e) == 0); }
+    if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
+    { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
@@ -434,7 +435,8 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             if (s == 0) {
                 ProfScope ps(c, HAK_PROF_FLOW, st);
                 hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
-            } else if (c->fuse_sf && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 && oc.h >= 8) {
+            } else if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg) && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 &&
+                       oc.h >= 8) {
                 const int ns0 = hak_fed_group_size(n, G, 0);
                 float* dst0 = (G % 2 == 1) ? Lt : tmp;
                 ProfScope ps(c, HAK_PROF_FED, st);
@@ -533,7 +535,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             } else {                                                              // akaze.cpp:664-695
                 src = A + L.lt(o, s - 1);
                 // low-pass + conductivity + first FED group in one streaming pass when covered, else low-pass + flow in one tile pass
-                if (fused && c->fuse_sf)
+                if (fused && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg))
                     fused_first = hakf_launch_fed_sf(st, src, smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc.w, oc.h, oc.p, nimg, c->itaps1,
                                                      cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0), c->state, o, G > 1);
                 if (!fused_first)
@@ -873,7 +875,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
             pxsteps += N * lp.nsteps;
             launches += lp.nsteps ? hak_fed_groups(lp.nsteps, c->max_fuse, L.oct[o].w) : 0;
             // sublevels whose low-pass (8 B/px) + conductivity (8 B/px) run inside the first FED launch (k_fed_sf)
-            if (s > 0 && lp.nsteps && c->fuse_sf && c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 &&
+            if (s > 0 && lp.nsteps && hak_stream_pays(c->fuse_sf, L.oct[o].w, L.oct[o].h, c->cfg.batch) && c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 &&
                 L.oct[o].h >= 8)
                 folded += 16.0 * N;
             if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue

@@ -202,6 +202,16 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
                      int diffusivity, const HakImgState* state, int octave, float fixed_ikc);
 // derivate + determinant of one level, with the level's extrema search fused in when b != nullptr
 // (kernels_hessian.hip); returns false when the caller still has to run hak_launch_extrema_level
+// The register-streaming kernels (k_hessian_stream, k_fed_sf) need a few thousand waves of >= 32 rows to fill the chip;
+// below that (small octaves, single-image calls) the LDS tile kernels are faster.  mode: 0 = never, 1 = by this size
+// rule (default), 2 = always where the kernel applies (tests).  Measured on MI355X: 1080p octave 3 at 128 images and
+// octave 0 at 1 image favour the tile kernels by 20-40 %, everything above ~2000 waves favours streaming by 6-35 %.
+static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
+{
+    if (mode != 1) return mode != 0;
+    const long strips = (w + 239) / 240;
+    return strips * ((h + 31) / 32) * nimg >= 2048;
+}
 extern int hak_hessian_stream_enabled;
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,

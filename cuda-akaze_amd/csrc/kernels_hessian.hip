@@ -339,7 +339,7 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
     return ex;
 }
 
-// process-wide switch, refreshed from HAK_HESS_STREAM by every hak_create (default on)
+// process-wide mode (0 never / 1 by size / 2 always), refreshed from HAK_HESS_STREAM by every hak_create
 int hak_hessian_stream_enabled = 1;
 
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
@@ -349,7 +349,7 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
     // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
-    if (hak_hessian_stream_enabled) {
+    if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
         if (hak_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
