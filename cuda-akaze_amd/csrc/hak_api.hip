@@ -408,7 +408,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             float* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
                 { ProfScope ps(c, HAK_PROF_CONTRAST, st);                          // akaze.cpp:329-332 in two passes over img
-                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->taps1,
+                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, A + L.det(0, 0) /* free until the Hessian of (0,0) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
                                         c->taps_base, c->base_R, c->state, cfg.per, L.noct); }
                 if (c->concurrent) (void)hipEventRecord(c->ev_ready[0], st);       // Lt(0,0) + contrast factors ready
                 { ProfScope ps(c, HAK_PROF_HESSIAN, st);

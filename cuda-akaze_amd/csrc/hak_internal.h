@@ -223,7 +223,7 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
-bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, long stride,
+bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad_scratch, long stride,
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
                            HakImgState* state, float per, int noct);
 // sigma=1 low-pass + conductivity fused (kernels_smoothflow.hip)

@@ -87,7 +87,7 @@ __device__ __forceinline__ void bs_colpass1(const float* rowp, float* sm, const 
 // ---- pass A: Lt(0,0) = G(base) * img, and max |Scharr(G(1) * img)|
 template <int R>
 __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, long img_stride, int sp,
-                                                float* __restrict__ lt, long stride, int w, int h, int p,
+                                                float* __restrict__ lt, float* __restrict__ grad, long stride, int w, int h, int p,
                                                 BsTaps t, HakImgState* state, int tiles_per_block, int nbx, int nby, int nimg)
 {
     constexpr int H = R < 3 ? 3 : R;
@@ -100,6 +100,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
     const float* s = img + (long)im * img_stride;
     float* o = lt + (long)im * stride;
+    float* go = grad ? grad + (long)im * stride : nullptr;
     const int tid = threadIdx.x;
     const int x0 = bx * BS_TX;
     const int ty0 = by * tiles_per_block;
@@ -141,7 +142,11 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
         hak_lds_barrier();
         for (int idx = tid; idx < BS_TY * BS_TX; idx += 256) {
             const int r = idx >> 6, c = idx & 63;
-            if (x0 + c < w && y0 + r < h) tmax = fmaxf(tmax, scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1));
+            if (x0 + c < w && y0 + r < h) {
+                const float g = scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1);
+                tmax = fmaxf(tmax, g);
+                if (go) go[(long)(y0 + r) * p + x0 + c] = g;      // kept for the histogram pass (k_grad_hist_plane)
+            }
         }
     }
     for (int off = 32; off > 0; off >>= 1) tmax = fmaxf(tmax, __shfl_xor(tmax, off));
@@ -203,6 +208,33 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
         if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
 }
 
+// ---- pass B': the same histogram from the gradient plane pass A left behind (4 B/px read, no recomputation)
+__global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict__ grad, long stride, int w, int h, int p,
+                                                         HakImgState* state, int rows_per_block)
+{
+    __shared__ int shist[HAK_NBINS];
+    const int im = blockIdx.y;
+    const float* g0 = grad + (long)im * stride;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HAK_NBINS; i += 256) shist[i] = 0;
+    const float hmax = __uint_as_float(state[im].hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;                         // akazed.cu:2450
+    hak_lds_barrier();
+    const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    for (int y = y0; y < y1; y++) {
+        const float* row = g0 + (long)y * p;
+        for (int x = tid; x < w; x += 256) {
+            // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
+            int hi = (int)((double)row[x] * (double)hfactor);
+            hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
+            atomicAdd(&shist[hi], 1);
+        }
+    }
+    hak_lds_barrier();
+    for (int i = tid; i < HAK_NBINS; i += 256)
+        if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
+}
+
 // host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371)
 // and ikc = 1/(k*k) (akazed.cu:2493), kept on the device
 __global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
@@ -227,7 +259,9 @@ __global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
 }
 
 // img -> Lt(0,0) and the per-image contrast factors.  Returns false when R is not supported here.
-bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, long stride,
+// `grad_scratch` (optional): a free plane of the arena (same stride / pitch as lt) that receives the gradient magnitude so
+// that the histogram pass reads 4 B/px instead of recomputing sigma=1 + Scharr from the image.
+bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad_scratch, long stride,
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
                            HakImgState* state, float per, int noct)
 {
@@ -241,12 +275,18 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     const int nby = (nty + tpb - 1) / tpb;
     const unsigned grid = hak_xcd_grid(ntx, nby, nimg);
     switch (R) {
-    case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
-    case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
-    case 4: k_base_a<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
-    default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    case 4: k_base_a<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
+    default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
     }
-    k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb, ntx, nby, nimg);
+    if (grad_scratch) {
+        int rpb = 8;
+        while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < 2048) rpb >>= 1;
+        k_grad_hist_plane<<<dim3((h + rpb - 1) / rpb, nimg), 256, 0, st>>>(grad_scratch, stride, w, h, p, state, rpb);
+    } else {
+        k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb, ntx, nby, nimg);
+    }
     k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
     return true;
 }
