@@ -172,6 +172,7 @@ struct hak_ctx {
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
+    bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
 };
 
 static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
@@ -318,6 +319,8 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     A((void**)&c->dtab, sizeof(HakTables));
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_num, sizeof(int) * (size_t)B);
     if (e == hipSuccess) e = hipMemcpy(c->dtab, &c->htab, sizeof(HakTables), hipMemcpyHostToDevice);
+    // the key map must be all zero at the start of every call; calls restore that themselves (k_clear_cand_maps)
+    if (e == hipSuccess) e = hipMemset(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * B);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     for (int o = 0; o < L.noct && e == hipSuccess; o++) {
         if (o > 0) e = hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking);
@@ -390,9 +393,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
     c->fed_launches = 0;
 
-    hak_launch_reset_state(st, c->state, nimg);
-    if (hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * nimg, st) != hipSuccess)
-        return fail("memset maps");
+    hak_launch_reset_state(st, c->state, nimg);        // (the key map is all zero here: hak_create / k_clear_cand_maps)
+    if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
+    c->maps_dirty = true;
 
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
@@ -483,6 +486,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
       hak_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    c->maps_dirty = false;
     return 0;
 }
 
@@ -498,9 +502,9 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     const long S = L.arena;
     HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
     const int idthreshold = 65;                                                   // akaze.cpp:559
-    hakf_launch_reset(st, c->state, nimg);
-    if (hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * nimg, st) != hipSuccess)
-        return fail("memset maps");
+    hakf_launch_reset(st, c->state, nimg);              // (the key map is all zero here: hak_create / k_clear_cand_maps)
+    if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
+    c->maps_dirty = true;
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
         int* smooth = A + L.smooth_off[o];
@@ -561,6 +565,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts, 1);
     hakf_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc);
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    c->maps_dirty = false;
     return 0;
 }
 
