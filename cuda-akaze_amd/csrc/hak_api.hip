@@ -802,6 +802,19 @@ extern "C" int hak_download_batch(hak_ctx* c, const hak_point* d_points, const i
                                   hak_point* h_points, int* h_num_pts)
 {
     if (!c || !d_points || !d_num_pts || !h_points || !h_num_pts) return fail("null argument");
+    // pinned (device-visible) destination buffers -- hak_host_alloc -- take one kernel that stores counts and records over PCIe
+    {
+        hipPointerAttribute_t ap{}, an{};
+        const bool pinned = hipPointerGetAttributes(&ap, h_points) == hipSuccess && ap.type == hipMemoryTypeHost &&
+                            hipPointerGetAttributes(&an, h_num_pts) == hipSuccess && an.type == hipMemoryTypeHost;
+        (void)hipGetLastError();                                    // a pageable pointer makes the query fail: not an error here
+        if (pinned) {
+            hak_launch_download(c->stream, d_points, d_num_pts, c->cfg.max_pts, nimg, h_points, h_num_pts);
+            if (hipGetLastError() != hipSuccess) return fail("download launch failed");
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            return 0;
+        }
+    }
     HIP_TRY(hipMemcpyAsync(h_num_pts, d_num_pts, sizeof(int) * (size_t)nimg, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const long mp = c->cfg.max_pts;

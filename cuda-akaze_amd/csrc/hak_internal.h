@@ -258,6 +258,8 @@ void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_str
 // detector tail (kernels_detect.hip)
 void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
                               int s, float dthreshold);
+void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d_num, long max_pts, int nimg, hak_point* h_points,
+                         int* h_num);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
                          hak_point* points, int max_pts, int* num_out, int fast = 0);
 

@@ -247,3 +247,24 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
     k_clear_cand_maps<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, p);
 }
+
+// ---- results -> pinned host memory in one launch (hak_download_batch): every image's valid prefix of point records and
+// its count are stored straight into device-visible host memory over PCIe.  Replaces one D2H copy per image (each a blit
+// kernel + an API call) and the extra host sync the counts needed first.
+__global__ __launch_bounds__(256) void k_download(const hak_point* __restrict__ d_points, const int* __restrict__ d_num, long max_pts,
+                                                  hak_point* h_points, int* h_num)
+{
+    const int img = blockIdx.y;
+    const int n = d_num[img];
+    if (blockIdx.x == 0 && threadIdx.x == 0) h_num[img] = n;
+    const uint2* src = reinterpret_cast<const uint2*>(d_points + (long)img * max_pts);
+    uint2* dst = reinterpret_cast<uint2*>(h_points + (long)img * max_pts);
+    const long total = (long)n * (long)(sizeof(hak_point) / sizeof(uint2));
+    for (long i = blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) dst[i] = src[i];
+}
+
+void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d_num, long max_pts, int nimg, hak_point* h_points,
+                         int* h_num)
+{
+    k_download<<<dim3(8, nimg), 256, 0, st>>>(d_points, d_num, max_pts, h_points, h_num);
+}

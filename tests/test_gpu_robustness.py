@@ -253,3 +253,43 @@ def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
     assert len(ref_pts) > 104 * 100
     assert alt_pts == ref_pts
     assert alt_planes == ref_planes
+
+
+def test_download_batch_pinned_and_pageable(ah, torch, synth):
+    """hak_download_batch: pinned destinations take the one-kernel zero-copy path, pageable ones the per-image copies;
+    both must deliver every image's count and the valid prefix of its records"""
+    w, h, mp, B = 480, 360, 1200, 5
+    p = ah.iAlignUp(w, 128)
+    host = np.stack([synth.to_float(_mg().case_scene(w, h, 300 + i), p) for i in range(B)])
+    host[3] = 0.25                                          # an image without keypoints
+    d_in = torch.from_numpy(host).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp, batch=B)
+    pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+    num = torch.zeros(B, dtype=torch.int32, device="cuda")
+    ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, d_in.data_ptr(), h * p, p, B, pts.data_ptr(), num.data_ptr(), 1))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    want_n = num.cpu().numpy()
+    want = pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    assert want_n[3] == 0 and want_n.max() > 50
+    # pageable numpy buffers
+    hp = np.zeros((B, mp), ah.POINT_DTYPE)
+    hn = np.full(B, -1, np.int32)
+    ah.check(ah.lib.hak_download_batch(det.ctx, pts.data_ptr(), num.data_ptr(), B, hp.ctypes.data, hn.ctypes.data))
+    # pinned buffers from the library's allocator
+    pp, pn = C.c_void_p(), C.c_void_p()
+    ah.check(ah.lib.hak_host_alloc(C.byref(pp), B * mp * 104))
+    ah.check(ah.lib.hak_host_alloc(C.byref(pn), B * 4))
+    C.memset(pp, 0, B * mp * 104)
+    ah.check(ah.lib.hak_download_batch(det.ctx, pts.data_ptr(), num.data_ptr(), B, pp, pn))
+    gn = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_int)), shape=(B,)).copy()
+    gp = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint8)), shape=(B * mp * 104,)).view(ah.POINT_DTYPE).reshape(B, mp).copy()
+    assert np.array_equal(hn, want_n) and np.array_equal(gn, want_n)
+    for i in range(B):
+        n = want_n[i]
+        assert hp[i, :n].tobytes() == want[i, :n].tobytes()
+        assert gp[i, :n].tobytes() == want[i, :n].tobytes()
+        assert not gp[i, n:].view(np.uint8).any()           # nothing beyond the valid prefix is touched
+    ah.lib.hak_host_free(pp)
+    ah.lib.hak_host_free(pn)
+    det.close()
