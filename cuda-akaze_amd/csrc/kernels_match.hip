@@ -10,7 +10,9 @@
 //
 // Mapping: a 256-thread block owns 16 queries x 16 residue classes.  Thread
 // (q, c) keeps query q's 64-byte descriptor in 16 VGPRs and walks class c with
-// 16 x (v_xor, v_bcnt) per train descriptor; classes are merged through LDS.
+// 16 x (v_xor, v_bcnt) per train descriptor; the train descriptors are staged
+// through LDS in tiles of 128 (coalesced, once per block) and read back with
+// broadcast ds_read_b128; classes are merged through LDS.
 #include "hak_internal.h"
 
 #define MQ 16      // queries per block
@@ -25,12 +27,28 @@ __device__ __forceinline__ void load_desc(const hak_point* p, unsigned int d[16]
     d[15] = f[15] & 0xFFu;                      // byte 60 only; bytes 61..63 are struct padding
 }
 
+#define MT 128     // train descriptors staged per LDS tile (8 per residue class)
+
+// 64-byte descriptors of train records [j0, j0 + MT) -> LDS, byte 60 masked (bytes 61..63 are struct padding).
+// Cooperative and coalesced: thread t copies dword (t & 15) of records t >> 4, (t >> 4) + 16, ...
+__device__ __forceinline__ void stage_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (*tile)[16], int tid)
+{
+    const int d = tid & 15;
+    for (int r = tid >> 4; r < MT; r += 16) {
+        const int j = j0 + r;
+        unsigned int v = 0;
+        if (j < n2) v = reinterpret_cast<const unsigned int*>(pts2[j].features)[d];
+        tile[r][d] = d == 15 ? (v & 0xFFu) : v;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_point* pts2_base,
                                                const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                int n1_host, int n2_host, long stride1, long stride2, int count_stride)
 {
     __shared__ int sdist[MC][MQ];
     __shared__ int sidx[MC][MQ];
+    __shared__ unsigned int tile[MT][16];               // 8 KB: every train descriptor is fetched once per block, not once per query group
     const int pair = blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
@@ -41,17 +59,28 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
         const int qi = q0 + q;
         unsigned int qd[16];
         if (qi < n1) load_desc(pts1 + qi, qd);
+        else {
+#pragma unroll
+            for (int k = 0; k < 16; k++) qd[k] = 0;
+        }
         int best = 1 << 30, besti = -1;
-        if (qi < n1)
-            for (int j = c; j < n2; j += MC) {
-                unsigned int td[16];
-                load_desc(pts2 + j, td);
+        for (int j0 = 0; j0 < n2; j0 += MT) {
+            __syncthreads();                                        // previous tile's readers are done
+            stage_train(pts2, j0, n2, tile, threadIdx.x);
+            __syncthreads();
+            const int jn = min(MT, n2 - j0);
+            for (int r = c; r < jn; r += MC) {                      // j = j0 + r keeps the residue class: MT % MC == 0
+                const uint4* t4 = reinterpret_cast<const uint4*>(tile[r]);
                 int dist = 0;
 #pragma unroll
-                for (int k = 0; k < 16; k += 2)
-                    dist += __popcll(((unsigned long long)(qd[k + 1] ^ td[k + 1]) << 32) | (qd[k] ^ td[k]));
-                if (dist < best) { best = dist; besti = j; }       // strict: first minimum of the class
+                for (int k = 0; k < 4; k++) {
+                    const uint4 t = t4[k];                          // 16 lanes read the same 16 bytes: LDS broadcast
+                    dist += __popcll(((unsigned long long)(qd[4 * k + 1] ^ t.y) << 32) | (qd[4 * k] ^ t.x));
+                    dist += __popcll(((unsigned long long)(qd[4 * k + 3] ^ t.w) << 32) | (qd[4 * k + 2] ^ t.z));
+                }
+                if (dist < best) { best = dist; besti = j0 + r; }  // strict: first minimum of the class
             }
+        }
         sdist[c][q] = best;
         sidx[c][q] = besti;
         __syncthreads();
