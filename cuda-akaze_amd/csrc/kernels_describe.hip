@@ -13,12 +13,12 @@
 //
 // The stage is gather-latency-bound (1323 + 218 scattered loads per keypoint), so (a) all gathers
 // of a phase are issued before any is consumed, and (b) the per-thread accumulator table is built
-// in two rounds over a half-size LDS table (2x2 + 3x3 cells, then 4x4 cells), which doubles the
-// number of keypoints a CU works on concurrently.
+// in three rounds over a third-size LDS table (8.2 KB per keypoint), which triples the number of
+// keypoints a CU works on concurrently.
 #include "hak_internal.h"
 
 #define ACC_LD 65           // padded leading dimension of the per-thread accumulator table
-#define ACC_ROWS 48         // rows of one round: 13 cells x 3 (round A) or 16 cells x 3 (round B)
+#define ACC_ROWS 30         // accumulator rows per round (multiple of 3): 87 rows in 3 rounds
 #define MAX_SMP 7           // ceil(21*21 / 64) samples per lane for descriptor_pattern_size 10
 
 // reduce accumulator rows [0, nrows) of the table in the reference's order:
@@ -208,97 +208,57 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 vry[n] = gdx[n] * co + gdy[n] * si;
             }
         }
-        // samples beyond MAX_SMP per lane (descriptor_pattern_size > 10) are handled by the tail loop below
-        // phase 2, round A: 2x2 cells (rows 0..11) and 3x3 cells (rows 12..38)
-        for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
-        hak_lds_barrier();
+        // phase 2: the 87 accumulator rows (2x2 cells: rows 0..11, 3x3: 12..38, 4x4: 39..86; three rows -- value, dx', dy' --
+        // per cell) are built in rounds of ACC_ROWS rows over one small LDS table, so that more keypoints fit on a CU.
+        // Cell bases and ACC_ROWS are multiples of 3: a cell never straddles two rounds.  Samples beyond MAX_SMP per
+        // lane (descriptor_pattern_size > 10) are re-gathered by the tail loop of every round.
+        for (int r0 = 0; r0 < 87; r0 += ACC_ROWS) {
+            for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
+            hak_lds_barrier();
+            auto add = [&](int row, float im, float rx, float ry) {
+                const int rr = row - r0;
+                if (rr >= 0 && rr < ACC_ROWS) {
+                    acc[rr * ACC_LD + lane] += im;
+                    acc[(rr + 1) * ACC_LD + lane] += rx;
+                    acc[(rr + 2) * ACC_LD + lane] += ry;
+                }
+            };
+            auto scatter = [&](int x, int y, float im, float rx, float ry) {
+                const int m = max(x, y);
+                if (m < 2 * size2) add(3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)), im, rx, ry);
+                if (m < 3 * size3) {
+                    const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2));
+                    const int y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+                    add(3 * (4 + y3 * 3 + x3), im, rx, ry);
+                }
+                if (m < 4 * size4) {
+                    const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
+                    const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+                    add(39 + 3 * (y4 * 4 + x4), im, rx, ry);
+                }
+            };
 #pragma unroll
-        for (int n = 0; n < MAX_SMP; n++) {
-            const int x = cx[n], y = cy[n];
-            if (x < 0) continue;
-            const int m = max(x, y);
-            if (m < 2 * size2) {
-                const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1));
-                acc[c * ACC_LD + lane] += vim[n];
-                acc[(c + 1) * ACC_LD + lane] += vrx[n];
-                acc[(c + 2) * ACC_LD + lane] += vry[n];
+            for (int n = 0; n < MAX_SMP; n++)
+                if (cx[n] >= 0) scatter(cx[n], cy[n], vim[n], vrx[n], vry[n]);
+            for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {      // tail: only for pattern sizes > 10
+                const int y = i / winsize, x = i - winsize * y;
+                const float iratio = 1.f / (1 << o);
+                const int scale = (int)(ptsize + 0.5f);
+                float si, co;
+                hak_sincosf(angle, &si, &co);
+                const int l = x - size2, k = y - size2;
+                int xp = (int)(ptx * iratio + scale * (k * co - l * si) + 0.5f);
+                int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
+                xp = min(max(xp, 0), oc.w - 1);
+                yp = min(max(yp, 0), oc.h - 1);
+                const long pos = (long)yp * oc.p + xp;
+                const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+                scatter(x, y, im, -dx * si + dy * co, dx * co + dy * si);
             }
-            if (m < 3 * size3) {
-                const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2));
-                const int y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
-                const int c = 3 * (4 + y3 * 3 + x3);
-                acc[c * ACC_LD + lane] += vim[n];
-                acc[(c + 1) * ACC_LD + lane] += vrx[n];
-                acc[(c + 2) * ACC_LD + lane] += vry[n];
-            }
+            hak_lds_barrier();
+            reduce_rows(acc, vals, min(ACC_ROWS, 87 - r0), r0, lane);
+            hak_lds_barrier();
         }
-        for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {          // tail: only for pattern sizes > 10
-            const int y = i / winsize, x = i - winsize * y, m = max(x, y);
-            const float iratio = 1.f / (1 << o);
-            const int scale = (int)(ptsize + 0.5f);
-            float si, co;
-            hak_sincosf(angle, &si, &co);
-            const int l = x - size2, k = y - size2;
-            int xp = (int)(ptx * iratio + scale * (k * co - l * si) + 0.5f);
-            int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
-            xp = min(max(xp, 0), oc.w - 1);
-            yp = min(max(yp, 0), oc.h - 1);
-            const long pos = (long)yp * oc.p + xp;
-            const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-            const float rx = -dx * si + dy * co, ry = dx * co + dy * si;
-            if (m < 2 * size2) {
-                const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1));
-                acc[c * ACC_LD + lane] += im; acc[(c + 1) * ACC_LD + lane] += rx; acc[(c + 2) * ACC_LD + lane] += ry;
-            }
-            if (m < 3 * size3) {
-                const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
-                const int c = 3 * (4 + y3 * 3 + x3);
-                acc[c * ACC_LD + lane] += im; acc[(c + 1) * ACC_LD + lane] += rx; acc[(c + 2) * ACC_LD + lane] += ry;
-            }
-        }
-        hak_lds_barrier();
-        reduce_rows(acc, vals, 39, 0, lane);
-        hak_lds_barrier();
-        // round B: 4x4 cells (table rows 0..47 <-> accumulator rows 39..86)
-        for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
-        hak_lds_barrier();
-#pragma unroll
-        for (int n = 0; n < MAX_SMP; n++) {
-            const int x = cx[n], y = cy[n];
-            if (x < 0) continue;
-            if (max(x, y) < 4 * size4) {
-                const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
-                const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
-                const int c = 3 * (y4 * 4 + x4);
-                acc[c * ACC_LD + lane] += vim[n];
-                acc[(c + 1) * ACC_LD + lane] += vrx[n];
-                acc[(c + 2) * ACC_LD + lane] += vry[n];
-            }
-        }
-        for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {          // tail: only for pattern sizes > 10
-            const int y = i / winsize, x = i - winsize * y;
-            if (max(x, y) >= 4 * size4) continue;
-            const float iratio = 1.f / (1 << o);
-            const int scale = (int)(ptsize + 0.5f);
-            float si, co;
-            hak_sincosf(angle, &si, &co);
-            const int l = x - size2, k = y - size2;
-            int xp = (int)(ptx * iratio + scale * (k * co - l * si) + 0.5f);
-            int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
-            xp = min(max(xp, 0), oc.w - 1);
-            yp = min(max(yp, 0), oc.h - 1);
-            const long pos = (long)yp * oc.p + xp;
-            const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-            const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
-            const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
-            const int c = 3 * (y4 * 4 + x4);
-            acc[c * ACC_LD + lane] += im;
-            acc[(c + 1) * ACC_LD + lane] += -dx * si + dy * co;
-            acc[(c + 2) * ACC_LD + lane] += dx * co + dy * si;
-        }
-        hak_lds_barrier();
-        reduce_rows(acc, vals, 48, 39, lane);
-        hak_lds_barrier();
         if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
             unsigned int desc_r = 0;
             const int nb = lane == 60 ? 6 : 8;
