@@ -5,8 +5,8 @@
 //   hCalcExtremaMap/gCalcExtremaMap                     akazed.cu:2563, 1334
 //
 // A wave owns a 256-px-wide strip (one float4 per lane) and streams down the rows of its segment.  For dilation S
-// it keeps three register rings of R = 2S+1 rows -- the smoothed input, Lx and Ly -- and the last three rows of
-// the determinant.  When input row t arrives,
+// it keeps rings of the last 2S+1 rows of the smoothed input and of Lx in registers (plus the slots of the rows being
+// loaded), the Ly ring in per-wave LDS, and the last three rows of the determinant.  When input row t arrives,
 //     Lx, Ly  of row b = t - S      come from input rows b-S, b, b+S      (the ring's oldest / middle / newest),
 //     det     of row c = t - 2S     comes from Lx / Ly rows c-S, c, c+S,
 //     extrema of row e = t - 2S - 1 come from det rows e-1, e, e+1,
@@ -28,16 +28,20 @@
 namespace {
 
 template <int S> struct HsGeo {
-    static constexpr int R = 2 * S + 1;                             // ring rows = unroll factor
+    static constexpr int PD = 2;                                    // input rows in flight ahead of the current one
+    static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
     static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
 };
+
+#define HS_CBUF 256
+struct HsCand { unsigned long long* buf; int n; };      // staged candidates: this wave's HS_CBUF LDS entries; n: wave-uniform fill count
 
 template <int S> struct HsState {
     float4 A[HsGeo<S>::R], X[HsGeo<S>::R];                          // slot = iteration index mod R
     float4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
     float4 Dm, Dc, Dp;                                              // det rows e-1, e, e+1 (rotated by moves)
-    float4 Q0, Q1, Q2;                                              // input rows t, t+1, t+2 in flight
+    HsCand cb;                                                      // staged candidates
 };
 
 template <int I> __device__ __forceinline__ float hs_c(const float4& r)
@@ -101,21 +105,40 @@ struct HsArgs {
     int p0, octave, layer, psz; float border, threshold;
 };
 
-// candidate emission for one component (rare path: a handful of pixels per segment)
-__device__ __forceinline__ void hs_emit(const bool hit, const float v, const int x, const int e, const HsArgs& a, const int lane)
+// Candidate emission.  Reserving list slots needs an atomic WITH return, and waiting for it drains every outstanding
+// store and prefetch of the wave (s_waitcnt vmcnt(0)) -- with a candidate in roughly every third row that stalled the
+// stream for a full memory round trip again and again.  Candidates are therefore staged in a 256-entry per-wave LDS
+// buffer and flushed with ONE slot reservation when it runs full (and at the end of the segment); the key-map update is a
+// return-less atomic and stays inline.
+
+__device__ __forceinline__ void hs_flush(HsCand& cb, const HsArgs& a, const int lane)
+{
+    if (cb.n > 0) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&a.st->ncand, cb.n);
+        base = __builtin_amdgcn_readfirstlane(base);
+        for (int i = lane; i < cb.n; i += 64) {
+            const long slot = (long)base + i;
+            if (slot < a.cand_cap) a.cand[slot] = cb.buf[i];
+        }
+        cb.n = 0;
+    }
+}
+
+__device__ __forceinline__ void hs_emit(const bool hit, const float v, const int x, const int e, const HsArgs& a, const int lane,
+                                        HsCand& cb)
 {
     const unsigned long long m = __ballot(hit);
     if (m) {
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&a.st->ncand, __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
+        const int cnt = __popcll(m);
         if (hit) {
             const int fx = x << a.octave, fy = e << a.octave;
             const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)a.layer);
             atomicMax(&a.maps[(long)fy * a.p0 + fx], key);
-            const long slot = base + __popcll(m & ((1ull << lane) - 1ull));
-            if (slot < a.cand_cap) a.cand[slot] = ((unsigned long long)a.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+            cb.buf[cb.n + __popcll(m & ((1ull << lane) - 1ull))] =
+                ((unsigned long long)a.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
         }
+        cb.n += cnt;
     }
 }
 
@@ -127,10 +150,10 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
     const float fac1 = a.fac1, fac2 = a.fac2;
     const int w = a.w, h = a.h, p = a.p;
     const bool le = x0 == 0, re = x0 + 3 == w - 1;
-    // ---- input row t (prefetched three iterations ago); request row t + 3
-    T.A[pmod(U, R)] = T.Q0;
-    T.Q0 = T.Q1; T.Q1 = T.Q2;
-    T.Q2 = *reinterpret_cast<const float4*>(a.src + (long)min(t + 3, h - 1) * p + xl);
+    // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
+    // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
+    // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
+    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const float4*>(a.src + (long)min(t + HsGeo<S>::PD, h - 1) * p + xl);
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -225,10 +248,11 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
             const bool hw = owns && (xok & 8u) && v.w > thr && v.w > up.w && v.w > dn.w && v.w > v.z && v.w > vr &&
                             v.w > up.z && v.w > ur && v.w > dn.z && v.w > dr;
             if (__ballot(hx || hy || hz || hw) != 0ull) {
-                hs_emit(hx, v.x, x0, e, a, lane);
-                hs_emit(hy, v.y, x0 + 1, e, a, lane);
-                hs_emit(hz, v.z, x0 + 2, e, a, lane);
-                hs_emit(hw, v.w, x0 + 3, e, a, lane);
+                if (T.cb.n > HS_CBUF - 128) hs_flush(T.cb, a, lane);    // a row holds at most 128 strict 3x3 maxima per wave
+                hs_emit(hx, v.x, x0, e, a, lane, T.cb);
+                hs_emit(hy, v.y, x0 + 1, e, a, lane, T.cb);
+                hs_emit(hz, v.z, x0 + 2, e, a, lane, T.cb);
+                hs_emit(hw, v.w, x0 + 3, e, a, lane, T.cb);
             }
         }
     }
@@ -244,7 +268,7 @@ __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsSta
 
 template <int S, bool XEDGE>
 __device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const int lane, float4* yring)
+                                         const int lane, float4* yring, unsigned long long* cbuf)
 {
     using G = HsGeo<S>;
     const int h = a.h, w = a.w;
@@ -260,13 +284,14 @@ __device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const in
     }
     HsState<S> T;
     T.Y = yring;
+    T.cb.buf = cbuf;
+    T.cb.n = 0;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
-    T.Q0 = *reinterpret_cast<const float4*>(a.src + (long)min(t0, h - 1) * a.p + xl);
-    T.Q1 = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + 1, h - 1) * a.p + xl);
-    T.Q2 = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + 2, h - 1) * a.p + xl);
+#pragma unroll
+    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + i, h - 1) * a.p + xl);
     for (int tb = t0; tb <= tend; tb += G::R) {
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
         if (tb <= 2 * S || tb + G::R - 1 >= h)
@@ -274,6 +299,7 @@ __device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const in
         else
             hs_group<S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
     }
+    if (a.maps != nullptr) hs_flush(T.cb, a, lane);
 }
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
@@ -282,6 +308,7 @@ __global__ __launch_bounds__(256) void k_hessian_stream(HsArgs a, long stride, l
 {
     using G = HsGeo<S>;
     __shared__ float4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
+    __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
     a.src += (long)img * stride; a.lx += (long)img * stride; a.ly += (long)img * stride; a.det += (long)img * stride;
@@ -294,8 +321,8 @@ __global__ __launch_bounds__(256) void k_hessian_stream(HsArgs a, long stride, l
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64);
-    else hs_strip<S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
+    else hs_strip<S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
 }
 
 template <int S>
