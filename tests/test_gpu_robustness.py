@@ -293,3 +293,56 @@ def test_download_batch_pinned_and_pageable(ah, torch, synth):
     ah.lib.hak_host_free(pp)
     ah.lib.hak_host_free(pn)
     det.close()
+
+
+# widths chosen around the streaming kernels' strip geometry (a wave stores 240 / 232 / 248 columns for dilation <= 3 / 4 / 1,
+# with 8 / 12 / 4 margin columns): exact multiples, one float4 over, last strip narrower than the margin, single strip; heights
+# around the 8..128-row segments and the 2S+1 / NS+4 warm-up rows
+SWEEP = [(240, 131), (244, 96), (248, 203), (252, 117), (232, 88), (236, 129), (480, 135), (484, 97), (472, 160), (720, 81),
+         (964, 92), (1204, 83), (196, 259), (300, 300), (1000, 130)]
+
+
+@pytest.mark.parametrize("w,h", SWEEP, ids=lambda v: str(v))
+def test_strip_geometry_sweep_both_paths(ah, okz, torch, synth, w, h):
+    """float and FAST pipelines vs their oracles on shapes that stress strip / segment boundaries of the streaming kernels"""
+    seed = 7 * w + h
+    big = _mg().case_scene(1280, 320, seed % 97)
+    u8 = np.ascontiguousarray(big[:h, :w]) if h <= 320 else _mg().case_scene(max(w, 134), h, seed % 97)[:, :w].copy()
+    p = ah.iAlignUp(w, 128)
+    noct = 2 + seed % 3
+    kw = dict(noctaves=noct, max_scale=3 + seed % 2, derivative_factor=[1.0, 1.5, 2.0][seed % 3])
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=3000, **kw)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, 3000, True, True)
+    img = torch.from_numpy(synth.to_float(u8, p)).cuda()
+    det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
+    r = okz.detect_and_compute(synth.to_float(u8, p), w, okz.default_params(**kw), max_pts=3000, keep_arena=True)
+
+    def check_planes(ref, as_int):
+        # keypoints stay clear of the image border, so the planes themselves are compared: every pixel of every level
+        assert len(det.geometry()) == ref.noct
+        for o in range(ref.noct):
+            for s in range(kw["max_scale"]):
+                for kind, nm in ((0, "Lt"), (2, "Lx"), (3, "Ly"), (1, "det")):
+                    got = det.plane(kind, o, s)
+                    want = okz.plane(ref, kind, o, s)
+                    got = got.view(np.int32) if as_int else got.view(np.uint32)
+                    want = want if as_int else want.view(np.uint32)
+                    bad = np.argwhere(got != want)
+                    assert len(bad) == 0, f"{'FAST ' if as_int else ''}{nm}({o},{s}): {len(bad)} px differ, first at (y, x) = {tuple(bad[0])}"
+
+    check_planes(r, False)
+    assert data.num_pts == len(r.points), (data.num_pts, len(r.points))
+    if data.num_pts:
+        assert_points_equal(data.h_data[:data.num_pts], r.points)
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    det.fastDetectAndCompute(torch.from_numpy(pad).cuda().data_ptr(), data, (w, h, p), True)
+    rf = okz.fast_detect_and_compute(u8, okz.default_params(**kw), max_pts=3000, keep_arena=True)
+    check_planes(rf, True)
+    assert data.num_pts == len(rf.points), (data.num_pts, len(rf.points))
+    if data.num_pts:
+        assert_points_equal(data.h_data[:data.num_pts], rf.points)
+    ah.freeAkazeData(data)
+    det.close()
