@@ -137,9 +137,10 @@ def test_no_descriptors(ah, okz, torch, synth):
     assert (pts["features"] == 0).all() and (pts["angle"] == 0).all()
 
 
-def test_batch_equals_single(ah, torch, synth):
-    """blockIdx.z batching: B different images in one launch sequence == B single calls"""
-    w, h, B, mp = 400, 300, 5, 2000
+@pytest.mark.parametrize("B", [5, 11, 16])         # below / across / exactly on the XCD groups of 8 images (hak_xcd_decode)
+def test_batch_equals_single(ah, torch, synth, B):
+    """batching: B different images in one launch sequence == B single calls"""
+    w, h, mp = 400, 300, 2000
     p = ah.iAlignUp(w, 128)
     imgs = [_mg().case_scene(w, h, 100 + i) for i in range(B)]
     singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in imgs]
