@@ -514,9 +514,13 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             int* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:589-623
-                hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
-                hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
-                hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
+                // one fused pass + a histogram pass over the gradient plane it leaves in det(0,0) (free until the Hessian below)
+                if (!hakf_launch_base_level(st, d_images, image_stride, pitch, Lt, A + L.det(0, 0), S, oc.w, oc.h, oc.p, nimg, c->itaps1,
+                                            c->itaps_base, c->base_R, c->state, cfg.per, L.noct)) {
+                    hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
+                    hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
+                    hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
+                }
                 if (!hakf_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
                                                lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
                     hakf_launch_hessian(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);

@@ -190,6 +190,129 @@ void hakf_launch_contrast(hipStream_t st, const int* smooth, long stride, int w,
     kf_grad_hist<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
     kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
 }
+// ---- fused octave-0 prologue of the FAST path (akaze.cpp:589-612): one pass over the uint8 image gives Lt(0,0) = the base
+// Gaussian, the maximum Scharr magnitude of the sigma=1 image, and that magnitude as a plane for the histogram pass.  The
+// sigma=1 plane itself is only an intermediate of the contrast factor and is never written.  (Unfused: four kernels,
+// kf_conv<u8,2> + kf_grad_max + kf_grad_hist + kf_conv<u8,R>, each re-reading its input from HBM.)
+#define FB_TX 64
+#define FB_TY 32
+template <int R>
+__global__ __launch_bounds__(256) void kf_base(const unsigned char* __restrict__ img, long img_stride, int sp, int* __restrict__ lt,
+                                               int* __restrict__ grad, long stride, int w, int h, int p, FkTaps t1, FkTaps tb,
+                                               HakImgState* state, int nbx, int nby, int nimg)
+{
+    constexpr int H = R < 3 ? 3 : R;
+    constexpr int RW = FB_TX + 2 * H, RH = FB_TY + 2 * H;         // raw tile
+    constexpr int PW = FB_TX + 2, PH = FB_TY + 6, SH = FB_TY + 2;   // sigma=1 row-pass tile (halo 1 in x, 3 in y), smooth tile (halo 1)
+    __shared__ int raw[RH * (RW + 1)];                              // reused for the sigma=1 smooth tile [SH][PW]
+    __shared__ int rowb[RH * FB_TX];
+    __shared__ int rowp[PH * PW];
+    int bx, by, im;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
+    const unsigned char* s = img + (long)im * img_stride;
+    int* o = lt + (long)im * stride;
+    int* go = grad + (long)im * stride;
+    const int x0 = bx * FB_TX, y0 = by * FB_TY, tid = threadIdx.x;
+    for (int i = tid; i < RH * RW; i += 256) {
+        const int r = i / RW, c = i - r * RW;
+        raw[r * (RW + 1) + c] = (int)s[(long)hak_refl(y0 - H + r, h) * sp + hak_refl(x0 - H + c, w)];
+    }
+    __syncthreads();
+    for (int i = tid; i < RH * FB_TX; i += 256) {                   // base row pass, output columns only
+        const int r = i >> 6, c = i & 63;
+        const int* q = raw + r * (RW + 1) + c + H;
+        int ws = wmul(tb.k[0], q[0]);
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws = wadd(ws, wmul(tb.k[k], q[-k] + q[k]));
+        rowb[i] = ws >> 16;
+    }
+    for (int i = tid; i < PH * PW; i += 256) {                      // sigma=1 row pass: rows y0-3.., columns x0-1..
+        const int r = i / PW, c = i - r * PW;
+        const int* q = raw + (r + H - 3) * (RW + 1) + c + H - 1;
+        rowp[i] = wadd(wadd(wmul(t1.k[0], q[0]), wmul(t1.k[1], q[-1] + q[1])), wmul(t1.k[2], q[-2] + q[2])) >> 16;
+    }
+    __syncthreads();
+    for (int i = tid; i < FB_TY * FB_TX; i += 256) {                // base column pass -> Lt(0,0)
+        const int r = i >> 6, c = i & 63;
+        const int x = x0 + c, y = y0 + r;
+        const int* q = rowb + (r + H) * FB_TX + c;
+        int ws = wmul(tb.k[0], q[0]);
+#pragma unroll
+        for (int k = 1; k <= R; k++) ws = wadd(ws, wmul(tb.k[k], q[-k * FB_TX] + q[k * FB_TX]));
+        if (x < w && y < h) o[(long)y * p + x] = ws >> 16;
+    }
+    int* sm = raw;                                                  // raw is dead: both row passes are done
+    for (int i = tid; i < SH * PW; i += 256) {                      // sigma=1 column pass -> smooth tile (halo 1)
+        const int r = i / PW, c = i - r * PW;
+        const int* q = rowp + (r + 2) * PW + c;
+        sm[i] = wadd(wadd(wmul(t1.k[0], q[0]), wmul(t1.k[1], q[-PW] + q[PW])), wmul(t1.k[2], q[-2 * PW] + q[2 * PW])) >> 16;
+    }
+    __syncthreads();
+    int m = 0;
+    for (int i = tid; i < FB_TY * FB_TX; i += 256) {                // Scharr magnitude (akazed.cu:3208-3232)
+        const int r = i >> 6, c = i & 63;
+        const int x = x0 + c, y = y0 + r;
+        if (x < w && y < h) {
+            const int* q = sm + (r + 1) * PW + c + 1;
+            const int dx = 10 * (q[1] - q[-1]) + 3 * (q[-PW + 1] + q[PW + 1] - q[-PW - 1] - q[PW - 1]);
+            const int dy = 10 * (q[PW] - q[-PW]) + 3 * (q[PW - 1] + q[PW + 1] - q[-PW - 1] - q[-PW + 1]);
+            const int g = fgrad(dx, dy);
+            go[(long)y * p + x] = g;
+            m = max(m, g);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
+    if ((tid & 63) == 0 && m > 1) atomicMax(&state[im].ihmax, m);
+}
+
+// histogram of the gradient plane kf_base left behind (akazed.cu:3299-3330)
+__global__ __launch_bounds__(256) void kf_grad_hist_plane(const int* __restrict__ grad, long stride, int w, int h, int p,
+                                                          HakImgState* state, int rows_per_block)
+{
+    __shared__ int shist[HAK_NBINS];
+    const int im = blockIdx.y;
+    const int* g0 = grad + (long)im * stride;
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) shist[i] = 0;
+    const int hfactor = (int)(HAK_NBINS / (float)state[im].ihmax * 65536 + 0.5f);                // akazed.cu:4133
+    __syncthreads();
+    const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    for (int y = y0; y < y1; y++) {
+        const int* row = g0 + (long)y * p;
+        for (int x = threadIdx.x; x < w; x += 256) {
+            int hi = wmul(row[x], hfactor) >> 16;                                                 // akazed.cu:3319
+            hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : (hi < 0 ? 0 : hi);
+            atomicAdd(&shist[hi], 1);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256)
+        if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
+}
+
+// img (uint8) -> Lt(0,0), contrast factors; `grad_scratch` = a free int32 plane of the arena.  false: R not covered
+// (caller: hakf_launch_conv_u8 x2 + hakf_launch_contrast)
+bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,
+                            int w, int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state,
+                            float per, int noct)
+{
+    if (R < 2 || R > 5) return false;
+    FkTaps t1, tb;
+    for (int i = 0; i < 8; i++) { t1.k[i] = i <= 2 ? itaps1[i] : 0; tb.k[i] = i <= R ? itaps_base[i] : 0; }
+    const int nbx = (w + FB_TX - 1) / FB_TX, nby = (h + FB_TY - 1) / FB_TY;
+    const unsigned grid = hak_xcd_grid(nbx, nby, nimg);
+    switch (R) {
+    case 2: kf_base<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;
+    case 3: kf_base<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;
+    case 4: kf_base<4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;
+    default: kf_base<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;
+    }
+    int rpb = 8;
+    while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < 2048) rpb >>= 1;
+    kf_grad_hist_plane<<<dim3((h + rpb - 1) / rpb, nimg), 256, 0, st>>>(grad_scratch, stride, w, h, p, state, rpb);
+    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    return true;
+}
+
 void hakf_launch_reset(hipStream_t st, HakImgState* state, int nimg) { kf_reset<<<nimg, 256, 0, st>>>(state); }
 
 // ---- akazed.cu:3406 gFlowNaive (conductivity as 16.16 int)
