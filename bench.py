@@ -278,6 +278,10 @@ def main():
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
                 "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls,
+                # end-to-end achieved = all-stage algorithmic bytes per image x images/s of the timed region
+                "end_to_end": {"all_stage_bytes_per_image": round(tr.all_stage_bytes),
+                               "achieved_GBs": round(tr.all_stage_bytes * 2.0 * world * B * args.steps / elapsed / 1e9, 1),
+                               "frac_of_peak": round(tr.all_stage_bytes * 2.0 * world * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
                 "mode": "serial leg (one stream); rocprof counterpart: profiles/*_serial_kernel_stats.csv from `bench.py --serial`"}
 
     cpu = None
