@@ -38,6 +38,7 @@ __device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uin
 __device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
 
 #define HF_TX 64
+#define HF_CBUF 256                               // staged candidates per block
 #define HF_NW 4                                  // waves per block (8 measured slower: 4.28 vs 3.55 ms)
 #define HF_E 1                                   // extra halo so the det tile has its 3x3 neighbourhood
 template <int S> struct HessGeo {
@@ -103,7 +104,7 @@ template <typename V, int S, bool INTERIOR>
 __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__ oy, V* __restrict__ od,
                                              int w, int h, int p, int x0, int y0, V fac1, V fac2,
                                              V* __restrict__ sm, V* __restrict__ sx, V* __restrict__ sy, int lane, int wv,
-                                             const HakExtremaArgs<V>& ex, int img)
+                                             const HakExtremaArgs<V>& ex, int img, unsigned long long* cbuf, int* ccnt)
 {
     using G = HessGeo<S>;
     constexpr int SW = G::SW, DW = G::DW, DH = G::DH, EW = G::EW, EH = G::EH, TY = G::TY;
@@ -249,16 +250,25 @@ __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__
         }
         const unsigned long long m = __ballot(hit);
         if (m) {
+            // list slots: reserving them in the global counter needs an atomic WITH return, and waiting for it drains the
+            // wave's outstanding stores and prefetch loads (s_waitcnt vmcnt(0)).  Candidates are staged in a per-block LDS
+            // buffer (LDS atomic: a short lgkmcnt wait) and flushed by the tile loop; only an overflow goes direct.
             int base = 0;
-            if (lane == 0) base = atomicAdd(&ex.state[img].ncand, __popcll(m));
+            if (lane == 0) base = atomicAdd(ccnt, __popcll(m));
             base = __builtin_amdgcn_readfirstlane(base);
+            const bool direct = base + __popcll(m) > HF_CBUF;                 // wave-uniform
+            if (direct) {
+                if (lane == 0) { atomicSub(ccnt, __popcll(m)); base = atomicAdd(&ex.state[img].ncand, __popcll(m)); }
+                base = __builtin_amdgcn_readfirstlane(base);
+            }
             if (hit) {
                 const int fx = x << ex.octave, fy = y << ex.octave;
                 const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)ex.layer);
                 atomicMax(&ex.maps[(long)img * ex.map_stride + (long)fy * ex.p0 + fx], key);
+                const unsigned long long entry = ((unsigned long long)ex.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
                 const long slot = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (slot < ex.cand_cap)
-                    ex.cand[(long)img * ex.cand_cap + slot] = ((unsigned long long)ex.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+                if (!direct) cbuf[slot] = entry;
+                else if (slot < ex.cand_cap) ex.cand[(long)img * ex.cand_cap + slot] = entry;
             }
         }
     }
@@ -288,17 +298,39 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
     const int ntiles = (h + G::TY - 1) / G::TY;
     const int ty1 = min(ty0 + tiles_per_block, ntiles);
     constexpr int HALO = HF_E + 2 * S;
+    __shared__ unsigned long long cbuf[HF_CBUF];
+    __shared__ int ccnt, cbase;
+    if (threadIdx.x == 0) ccnt = 0;
+    // staged candidates -> the image's list: one global slot reservation for the whole buffer.  Called by all threads
+    // between two barriers that order it against the extrema passes before and after.
+    auto flush = [&]() {
+        const int n = ccnt;                                           // (uniform: read after a barrier)
+        if (n > 0) {
+            if (threadIdx.x == 0) cbase = atomicAdd(&ex.state[img].ncand, n);
+            __syncthreads();
+            const long gb = cbase;
+            for (int i = threadIdx.x; i < n; i += 64 * HF_NW)
+                if (gb + i < ex.cand_cap) ex.cand[(long)img * ex.cand_cap + gb + i] = cbuf[i];
+            __syncthreads();
+            if (threadIdx.x == 0) ccnt = 0;
+        }
+    };
     HessPrefetch<V, S> P;
     if (ty0 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, ty0 * G::TY, lane, wv);
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * G::TY;
         hak_lds_barrier();                                        // previous tile's readers of sm / sx / sy are done
+        if (ex.maps != nullptr && ccnt > HF_CBUF / 2) flush();    // (ccnt is stable here: every wave passed the barrier)
         hess_commit<V, S>(P, sm, lane, wv);
         hak_lds_barrier();
         if (ty + 1 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
-        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
-        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img);
+        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt);
+        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt);
+    }
+    if (ex.maps != nullptr) {
+        __syncthreads();
+        flush();
     }
 }
 
