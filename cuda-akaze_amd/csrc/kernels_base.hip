@@ -221,14 +221,20 @@ __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict
     const float hfactor = HAK_NBINS / hmax;                         // akazed.cu:2450
     hak_lds_barrier();
     const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    auto bin = [&](float g) {
+        // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
+        int hi = (int)((double)g * (double)hfactor);
+        hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
+        atomicAdd(&shist[hi], 1);
+    };
+    const int w4 = w >> 2;                                          // rows are 16-byte aligned (pitch % 64 == 0)
     for (int y = y0; y < y1; y++) {
         const float* row = g0 + (long)y * p;
-        for (int x = tid; x < w; x += 256) {
-            // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
-            int hi = (int)((double)row[x] * (double)hfactor);
-            hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
-            atomicAdd(&shist[hi], 1);
+        for (int x = tid; x < w4; x += 256) {
+            const float4 g = reinterpret_cast<const float4*>(row)[x];
+            bin(g.x); bin(g.y); bin(g.z); bin(g.w);
         }
+        if (tid < (w & 3)) bin(row[4 * w4 + tid]);
     }
     hak_lds_barrier();
     for (int i = tid; i < HAK_NBINS; i += 256)
