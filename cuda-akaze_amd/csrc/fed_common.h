@@ -27,16 +27,25 @@ struct FedFacs { V f[NS]; };
 
 // bound_ctrl = 1 with a zero `old`: the end lane (no source) reads 0 -- lanes 0 and 63 are strip margin -- and the
 // compiler needs no copy of `v` to seed the destination (an `old = v` shift costs one extra v_mov each)
-__device__ __forceinline__ int wave_shr1(int v)          // lane i <- lane i-1 (lane 0 reads 0)
+__device__ __forceinline__ int hak_dpp_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true); }   // lane i <- lane i-1
+__device__ __forceinline__ int hak_dpp_shl1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true); }   // lane i <- lane i+1
+__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(hak_dpp_shr1(__float_as_int(v))); }
+__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(hak_dpp_shl1(__float_as_int(v))); }
+// Integer shifts are made opaque to the optimiser: ROCm 7.2's DPP-combine pass folded `a - shift(b)` into
+// `v_sub_u32_dpp shift(b), a` (operands swapped, no v_subrev) in k_hessian_stream<int>: Lx came out with the sign of its
+// second term flipped in every lane's first column.  The empty asm keeps the shift a plain v_mov_b32_dpp.
+__device__ __forceinline__ int wave_shr1(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true);
+    int r = hak_dpp_shr1(v);
+    asm volatile("" : "+v"(r));
+    return r;
 }
-__device__ __forceinline__ int wave_shl1(int v)          // lane i <- lane i+1 (lane 63 reads 0)
+__device__ __forceinline__ int wave_shl1(int v)
 {
-    return __builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true);
+    int r = hak_dpp_shl1(v);
+    asm volatile("" : "+v"(r));
+    return r;
 }
-__device__ __forceinline__ float wave_shr1(float v) { return __int_as_float(wave_shr1(__float_as_int(v))); }
-__device__ __forceinline__ float wave_shl1(float v) { return __int_as_float(wave_shl1(__float_as_int(v))); }
 
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
 
@@ -97,3 +106,20 @@ __device__ __forceinline__ int sf_g_value_int(float g) { return (int)(g * 65536 
 template <typename V> __device__ __forceinline__ V sf_g_as(float g);
 template <> __device__ __forceinline__ float sf_g_as<float>(float g) { return g; }
 template <> __device__ __forceinline__ int sf_g_as<int>(float g) { return (int)(g * 65536 + 0.5f); }
+
+// ---- dilated Scharr / determinant / key helpers of the Hessian kernels (kernels_hessian.hip, kernels_hessian_stream.hip)
+// Shared by both pipelines: V = float (akaze) and V = int (fastakaze 16.16 fixed point,
+// akazed.cu:3339-3403: every weighted sum is followed by >> 16; the determinant is not shifted).
+__device__ __forceinline__ float hs_d(float f1, float f2, float a, float b) { return f1 * a + f2 * b; }
+__device__ __forceinline__ int hs_d(int f1, int f2, int a, int b)
+{
+    return (int)((unsigned)f1 * (unsigned)a + (unsigned)f2 * (unsigned)b) >> 16;
+}
+__device__ __forceinline__ float hs_det(float dxx, float dyy, float dxy) { return dxx * dyy - dxy * dxy; }
+__device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
+{
+    return (int)((unsigned)dxx * (unsigned)dyy - (unsigned)dxy * (unsigned)dxy);
+}
+__device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
+__device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
+

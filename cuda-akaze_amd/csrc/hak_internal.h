@@ -216,6 +216,9 @@ extern int hak_hessian_stream_enabled;
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
+bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+                                int w, int h, int p, int nimg, int step, int fac1, int fac2,
+                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
 bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
                                int w, int h, int p, int nimg, int step,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);

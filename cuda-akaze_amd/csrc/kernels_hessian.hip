@@ -18,24 +18,9 @@
 //
 // Same per-pixel expressions and reflect-101 index rule as the reference (akazed.cu:1284-1295,
 // 1326-1330, 1346-1373).
-#include "hak_internal.h"
+#include "fed_common.h"
 #include <cstdlib>
 #include <type_traits>
-
-// The kernel is shared by both pipelines: V = float (akaze) and V = int (fastakaze 16.16 fixed point,
-// akazed.cu:3339-3403: every weighted sum is followed by >> 16; the determinant is not shifted).
-__device__ __forceinline__ float hs_d(float f1, float f2, float a, float b) { return f1 * a + f2 * b; }
-__device__ __forceinline__ int hs_d(int f1, int f2, int a, int b)
-{
-    return (int)((unsigned)f1 * (unsigned)a + (unsigned)f2 * (unsigned)b) >> 16;
-}
-__device__ __forceinline__ float hs_det(float dxx, float dyy, float dxy) { return dxx * dyy - dxy * dxy; }
-__device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
-{
-    return (int)((unsigned)dxx * (unsigned)dyy - (unsigned)dxy * (unsigned)dxy);
-}
-__device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
-__device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
 
 #define HF_TX 64
 #define HF_CBUF 256                               // staged candidates per block
@@ -406,6 +391,13 @@ bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* lx, int* ly,
                                int w, int h, int p, int nimg, int step,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
+    if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
+        float f1, f2;
+        deriv_factors(f1, f2);
+        if (hakf_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, (int)(f1 * 65536 + 0.5f), (int)(f2 * 65536 + 0.5f),
+                                       b, L, htab, octave, sub, idthreshold))
+            return true;
+    }
     const HakExtremaArgs<int> ex = extrema_args<int>(b, L, htab, octave, sub, idthreshold);
     switch (step) {
     case 1: launch_fused<int, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;

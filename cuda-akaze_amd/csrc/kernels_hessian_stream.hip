@@ -37,14 +37,15 @@ template <int S> struct HsGeo {
 #define HS_CBUF 256
 struct HsCand { unsigned long long* buf; int n; };      // staged candidates: this wave's HS_CBUF LDS entries; n: wave-uniform fill count
 
-template <int S> struct HsState {
-    float4 A[HsGeo<S>::R], X[HsGeo<S>::R];                          // slot = iteration index mod R
-    float4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
-    float4 Dm, Dc, Dp;                                              // det rows e-1, e, e+1 (rotated by moves)
+template <typename V, int S> struct HsState {
+    using V4 = typename FedV<V>::V4;
+    V4 A[HsGeo<S>::R], X[HsGeo<S>::R];                              // slot = iteration index mod R
+    V4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
+    V4 Dm, Dc, Dp;                                                  // det rows e-1, e, e+1 (rotated by moves)
     HsCand cb;                                                      // staged candidates
 };
 
-template <int I> __device__ __forceinline__ float hs_c(const float4& r)
+template <int I, typename V4> __device__ __forceinline__ auto hs_c(const V4& r)
 {
     if constexpr (I == 0) return r.x;
     else if constexpr (I == 1) return r.y;
@@ -54,10 +55,10 @@ template <int I> __device__ __forceinline__ float hs_c(const float4& r)
 // value at column x0 + K - S of the row held as r (columns x0 .. x0+3): the own component, or the left lane's through one
 // DPP shift; `le` (the lane holding image column 0) reads the reflected column S - K instead.  One scalar at a time so
 // that only the values of the component being evaluated are live.
-template <int S, int K, bool XEDGE>
-__device__ __forceinline__ float hs_l(const float4& r, const bool le)
+template <int S, int K, bool XEDGE, typename V4>
+__device__ __forceinline__ auto hs_l(const V4& r, const bool le)
 {
-    float v;
+    decltype(r.x) v;
     if constexpr (K - S >= 0) v = hs_c<K - S>(r);
     else {
         v = wave_shr1(hs_c<4 + K - S>(r));
@@ -66,7 +67,7 @@ __device__ __forceinline__ float hs_l(const float4& r, const bool le)
             else {
                 // column 4 = the right lane's first component.  The shift must execute with every lane active: inside the
                 // conditional operator it would run under the `le` lane's EXEC mask only and read its neighbour as 0.
-                const float c4 = wave_shl1(r.x);
+                const auto c4 = wave_shl1(r.x);
                 v = le ? c4 : v;
             }
         }
@@ -74,17 +75,17 @@ __device__ __forceinline__ float hs_l(const float4& r, const bool le)
     return v;
 }
 // value at column x0 + K + S; `re` (the lane holding image column w-1) reads the reflected column 6 - K - S (relative)
-template <int S, int K, bool XEDGE>
-__device__ __forceinline__ float hs_r(const float4& r, const bool re)
+template <int S, int K, bool XEDGE, typename V4>
+__device__ __forceinline__ auto hs_r(const V4& r, const bool re)
 {
-    float v;
+    decltype(r.x) v;
     if constexpr (K + S <= 3) v = hs_c<K + S>(r);
     else {
         v = wave_shl1(hs_c<K + S - 4>(r));
         if (XEDGE) {
             if constexpr (6 - K - S >= 0) v = re ? hs_c<6 - K - S>(r) : v;
             else {
-                const float cm1 = wave_shr1(r.w);                   // column -1 = the left lane's last component (all lanes active)
+                const auto cm1 = wave_shr1(r.w);                   // column -1 = the left lane's last component (all lanes active)
                 v = re ? cm1 : v;
             }
         }
@@ -93,16 +94,16 @@ __device__ __forceinline__ float hs_r(const float4& r, const bool re)
 }
 
 // dilated Scharr pair on one component (akazed.cu:1294-1295)
-#define HS_DX(ul, ur, cl, cr, ll, lr) (fac1 * ((ur) + (lr) - (ul) - (ll)) + fac2 * ((cr) - (cl)))
-#define HS_DY(ul, uc, ur, ll, lc, lr) (fac1 * ((lr) + (ll) - (ur) - (ul)) + fac2 * ((lc) - (uc)))
+#define HS_DX(ul, ur, cl, cr, ll, lr) hs_d(fac1, fac2, (ur) + (lr) - (ul) - (ll), (cr) - (cl))
+#define HS_DY(ul, uc, ur, ll, lc, lr) hs_d(fac1, fac2, (lr) + (ll) - (ur) - (ul), (lc) - (uc))
 
-struct HsArgs {
-    const float* src; float* lx; float* ly; float* det;
+template <typename V> struct HsArgs {
+    const V* src; V* lx; V* ly; V* det;
     int w, h, p;
-    float fac1, fac2;
+    V fac1, fac2;
     // extrema (maps == nullptr: determinant only)
     unsigned long long* maps; unsigned long long* cand; long cand_cap; HakImgState* st;
-    int p0, octave, layer, psz; float border, threshold;
+    int p0, octave, layer, psz; float border; V threshold;
 };
 
 // Candidate emission.  Reserving list slots needs an atomic WITH return, and waiting for it drains every outstanding
@@ -111,7 +112,8 @@ struct HsArgs {
 // buffer and flushed with ONE slot reservation when it runs full (and at the end of the segment); the key-map update is a
 // return-less atomic and stays inline.
 
-__device__ __forceinline__ void hs_flush(HsCand& cb, const HsArgs& a, const int lane)
+template <typename V>
+__device__ __forceinline__ void hs_flush(HsCand& cb, const HsArgs<V>& a, const int lane)
 {
     if (cb.n > 0) {
         int base = 0;
@@ -125,7 +127,8 @@ __device__ __forceinline__ void hs_flush(HsCand& cb, const HsArgs& a, const int 
     }
 }
 
-__device__ __forceinline__ void hs_emit(const bool hit, const float v, const int x, const int e, const HsArgs& a, const int lane,
+template <typename V>
+__device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, const int e, const HsArgs<V>& a, const int lane,
                                         HsCand& cb)
 {
     const unsigned long long m = __ballot(hit);
@@ -133,7 +136,7 @@ __device__ __forceinline__ void hs_emit(const bool hit, const float v, const int
         const int cnt = __popcll(m);
         if (hit) {
             const int fx = x << a.octave, fy = e << a.octave;
-            const unsigned long long key = ((unsigned long long)__float_as_uint(v) << 32) | (0xFFFFFFFFu - (unsigned)a.layer);
+            const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)a.layer);
             atomicMax(&a.maps[(long)fy * a.p0 + fx], key);
             cb.buf[cb.n + __popcll(m & ((1ull << lane) - 1ull))] =
                 ((unsigned long long)a.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
@@ -142,18 +145,19 @@ __device__ __forceinline__ void hs_emit(const bool hit, const float v, const int
     }
 }
 
-template <int S, int U, bool XEDGE, bool YEDGE>
-__device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs& a, const int xl, const int x0,
+template <typename V, int S, int U, bool XEDGE, bool YEDGE>
+__device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane)
 {
+    using V4 = typename FedV<V>::V4;
     constexpr int R = HsGeo<S>::R;
-    const float fac1 = a.fac1, fac2 = a.fac2;
+    const V fac1 = a.fac1, fac2 = a.fac2;
     const int w = a.w, h = a.h, p = a.p;
     const bool le = x0 == 0, re = x0 + 3 == w - 1;
     // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
     // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
     // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
-    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const float4*>(a.src + (long)min(t + HsGeo<S>::PD, h - 1) * p + xl);
+    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (long)min(t + HsGeo<S>::PD, h - 1) * p + xl);
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -162,16 +166,16 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
         }
     }
     // ---- Lx, Ly of row b = t - S
-    float4 vy_row;                                                  // Ly row b (= the determinant's row c+S below)
+    V4 vy_row;                                                  // Ly row b (= the determinant's row c+S below)
     {
         const int b = t - S;
-        const float4 ru = T.A[pmod(U - 2 * S, R)], rc = T.A[pmod(U - S, R)], rl = T.A[pmod(U, R)];
-        float4 vx, vy;
+        const V4 ru = T.A[pmod(U - 2 * S, R)], rc = T.A[pmod(U - S, R)], rl = T.A[pmod(U, R)];
+        V4 vx, vy;
 #define HS_S1(k, K)                                                                                         \
         {                                                                                                   \
-            const float ul = hs_l<S, K, XEDGE>(ru, le), ur = hs_r<S, K, XEDGE>(ru, re);                     \
-            const float cl = hs_l<S, K, XEDGE>(rc, le), cr = hs_r<S, K, XEDGE>(rc, re);                     \
-            const float ll = hs_l<S, K, XEDGE>(rl, le), lr = hs_r<S, K, XEDGE>(rl, re);                     \
+            const V ul = hs_l<S, K, XEDGE>(ru, le), ur = hs_r<S, K, XEDGE>(ru, re);                     \
+            const V cl = hs_l<S, K, XEDGE>(rc, le), cr = hs_r<S, K, XEDGE>(rc, re);                     \
+            const V ll = hs_l<S, K, XEDGE>(rl, le), lr = hs_r<S, K, XEDGE>(rl, re);                     \
             vx.k = HS_DX(ul, ur, cl, cr, ll, lr);                                                           \
             vy.k = HS_DY(ul, ru.k, ur, ll, rl.k, lr);                                                       \
         }
@@ -183,8 +187,8 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
         T.X[pmod(U, R)] = vx;
         T.Y[pmod(U, R) * 64 + lane] = vy;
         if (b >= ybeg && b < yend && owns) {
-            *reinterpret_cast<float4*>(a.lx + (long)b * p + x0) = vx;
-            *reinterpret_cast<float4*>(a.ly + (long)b * p + x0) = vy;
+            *reinterpret_cast<V4*>(a.lx + (long)b * p + x0) = vx;
+            *reinterpret_cast<V4*>(a.ly + (long)b * p + x0) = vy;
         }
         if (YEDGE) {
 #pragma unroll
@@ -205,40 +209,40 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
     // ---- determinant of row c = t - 2S
     {
         const int c = t - 2 * S;
-        const float4 xu = T.X[pmod(U - 2 * S, R)], xc = T.X[pmod(U - S, R)], xd = T.X[pmod(U, R)];
-        const float4 yu = T.Y[pmod(U - 2 * S, R) * 64 + lane], yd = vy_row;
-        float4 d;
+        const V4 xu = T.X[pmod(U - 2 * S, R)], xc = T.X[pmod(U - S, R)], xd = T.X[pmod(U, R)];
+        const V4 yu = T.Y[pmod(U - 2 * S, R) * 64 + lane], yd = vy_row;
+        V4 d;
 #define HS_DET(k, K)                                                                                        \
         {                                                                                                   \
-            const float xul = hs_l<S, K, XEDGE>(xu, le), xur = hs_r<S, K, XEDGE>(xu, re);                   \
-            const float xcl = hs_l<S, K, XEDGE>(xc, le), xcr = hs_r<S, K, XEDGE>(xc, re);                   \
-            const float xll = hs_l<S, K, XEDGE>(xd, le), xlr = hs_r<S, K, XEDGE>(xd, re);                   \
-            const float yul = hs_l<S, K, XEDGE>(yu, le), yur = hs_r<S, K, XEDGE>(yu, re);                   \
-            const float yll = hs_l<S, K, XEDGE>(yd, le), ylr = hs_r<S, K, XEDGE>(yd, re);                   \
-            const float dxx = HS_DX(xul, xur, xcl, xcr, xll, xlr);                                          \
-            const float dxy = HS_DY(xul, xu.k, xur, xll, xd.k, xlr);                                        \
-            const float dyy = HS_DY(yul, yu.k, yur, yll, yd.k, ylr);                                        \
-            d.k = dxx * dyy - dxy * dxy;                                                                    \
+            const V xul = hs_l<S, K, XEDGE>(xu, le), xur = hs_r<S, K, XEDGE>(xu, re);                   \
+            const V xcl = hs_l<S, K, XEDGE>(xc, le), xcr = hs_r<S, K, XEDGE>(xc, re);                   \
+            const V xll = hs_l<S, K, XEDGE>(xd, le), xlr = hs_r<S, K, XEDGE>(xd, re);                   \
+            const V yul = hs_l<S, K, XEDGE>(yu, le), yur = hs_r<S, K, XEDGE>(yu, re);                   \
+            const V yll = hs_l<S, K, XEDGE>(yd, le), ylr = hs_r<S, K, XEDGE>(yd, re);                   \
+            const V dxx = HS_DX(xul, xur, xcl, xcr, xll, xlr);                                          \
+            const V dxy = HS_DY(xul, xu.k, xur, xll, xd.k, xlr);                                        \
+            const V dyy = HS_DY(yul, yu.k, yur, yll, yd.k, ylr);                                        \
+            d.k = hs_det(dxx, dyy, dxy);                                                                    \
         }
         HS_DET(x, 0) __builtin_amdgcn_sched_barrier(0); HS_DET(y, 1) __builtin_amdgcn_sched_barrier(0);
         HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_DET
         T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
-        if (c >= ybeg && c < yend && owns) *reinterpret_cast<float4*>(a.det + (long)c * p + x0) = d;
+        if (c >= ybeg && c < yend && owns) *reinterpret_cast<V4*>(a.det + (long)c * p + x0) = d;
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
     if (a.maps != nullptr) {
         const int e = t - 2 * S - 1;
-        const float thr = a.threshold;
-        const float4 v = T.Dc;
+        const V thr = a.threshold;
+        const V4 v = T.Dc;
         // threshold first: almost no pixel passes it, so the wave almost always skips the neighbourhood test
         const bool any = owns && (v.x > thr || v.y > thr || v.z > thr || v.w > thr);
         if (e >= ybeg && e < yend && __ballot(any) != 0ull &&
             e >= a.psz && (int)(e - a.border + 0.5f) - 1 >= 0 && (int)(e + a.border + 0.5f) + 1 < h) {
-            const float4 up = T.Dm, dn = T.Dp;
-            const float vl = wave_shr1(v.w), vr = wave_shl1(v.x);
-            const float ul = wave_shr1(up.w), ur = wave_shl1(up.x);
-            const float dl = wave_shr1(dn.w), dr = wave_shl1(dn.x);
+            const V4 up = T.Dm, dn = T.Dp;
+            const V vl = wave_shr1(v.w), vr = wave_shl1(v.x);
+            const V ul = wave_shr1(up.w), ur = wave_shl1(up.x);
+            const V dl = wave_shr1(dn.w), dr = wave_shl1(dn.x);
             const bool hx = owns && (xok & 1u) && v.x > thr && v.x > up.x && v.x > dn.x && v.x > vl && v.x > v.y &&
                             v.x > ul && v.x > up.y && v.x > dl && v.x > dn.y;
             const bool hy = owns && (xok & 2u) && v.y > thr && v.y > up.y && v.y > dn.y && v.y > v.x && v.y > v.z &&
@@ -258,19 +262,20 @@ __device__ __forceinline__ void hs_iter(HsState<S>& T, const int t, const HsArgs
     }
 }
 
-template <int S, bool XEDGE, bool YEDGE, int... U>
-__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<S>& T, const int tb, const HsArgs& a,
+template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
+__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
                                          const unsigned xok, const int lane)
 {
-    (hs_iter<S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane), ...);
+    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane), ...);
 }
 
-template <int S, bool XEDGE>
-__device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const int lane, float4* yring, unsigned long long* cbuf)
+template <typename V, int S, bool XEDGE>
+__device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
+                                         const int lane, typename FedV<V>::V4* yring, unsigned long long* cbuf)
 {
     using G = HsGeo<S>;
+    using V4 = typename FedV<V>::V4;
     const int h = a.h, w = a.w;
     const int xl = min(max(x0, 0), a.p - 4);                    // keep every lane's loads inside the plane
     const int t0 = max(0, ybeg - 1 - 2 * S);                    // first input row
@@ -282,32 +287,33 @@ __device__ __forceinline__ void hs_strip(const HsArgs& a, const int x0, const in
         const int x = x0 + k;
         if (x >= a.psz && (int)(x - a.border + 0.5f) - 1 >= 0 && (int)(x + a.border + 0.5f) + 1 < w) xok |= 1u << k;
     }
-    HsState<S> T;
+    HsState<V, S> T;
     T.Y = yring;
     T.cb.buf = cbuf;
     T.cb.n = 0;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const V zz = 0;
+    const V4 z4 = mk4(zz, zz, zz, zz);
 #pragma unroll
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
 #pragma unroll
-    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const float4*>(a.src + (long)min(t0 + i, h - 1) * a.p + xl);
+    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const V4*>(a.src + (long)min(t0 + i, h - 1) * a.p + xl);
     for (int tb = t0; tb <= tend; tb += G::R) {
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
         if (tb <= 2 * S || tb + G::R - 1 >= h)
-            hs_group<S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
         else
-            hs_group<S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
     }
     if (a.maps != nullptr) hs_flush(T.cb, a, lane);
 }
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
-template <int S>
-__global__ __launch_bounds__(256) void k_hessian_stream(HsArgs a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
+template <typename V, int S>
+__global__ __launch_bounds__(256) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
 {
     using G = HsGeo<S>;
-    __shared__ float4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
+    __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
@@ -321,12 +327,12 @@ __global__ __launch_bounds__(256) void k_hessian_stream(HsArgs a, long stride, l
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
-    else hs_strip<S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
+    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
 }
 
-template <int S>
-void launch_stream(hipStream_t st, HsArgs a, long stride, long map_stride, int nimg)
+template <typename V, int S>
+void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, int nimg)
 {
     using G = HsGeo<S>;
     const int gx = (a.w + G::XV - 1) / G::XV;
@@ -334,31 +340,46 @@ void launch_stream(hipStream_t st, HsArgs a, long stride, long map_stride, int n
     int ry = 128;
     while (ry > 16 && (long)gx * ((a.h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (a.h + 4 * ry - 1) / (4 * ry);
-    k_hessian_stream<S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
+    k_hessian_stream<V, S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
 }
 
-}   // namespace
 
-// returns false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
-bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
-                               int w, int h, int p, int nimg, int step, float fac1, float fac2,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+template <typename V>
+bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride, int w, int h, int p, int nimg, int step,
+                       V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
 {
     if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
-    HsArgs a{};
+    HsArgs<V> a{};
     a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
     long map_stride = 0;
     if (b) {
         const int layer = octave * L->ms + sub;
         a.maps = b->maps; map_stride = b->map_stride; a.cand = b->cand; a.cand_cap = b->cand_cap; a.st = b->state;
         a.p0 = L->oct[0].p; a.octave = octave; a.layer = layer;
-        a.psz = (int)htab->borders[octave * L->ms]; a.border = htab->borders[layer]; a.threshold = dthreshold;
+        a.psz = (int)htab->borders[octave * L->ms]; a.border = htab->borders[layer]; a.threshold = threshold;
     }
     switch (step) {
-    case 1: launch_stream<1>(st, a, stride, map_stride, nimg); break;
-    case 2: launch_stream<2>(st, a, stride, map_stride, nimg); break;
-    case 3: launch_stream<3>(st, a, stride, map_stride, nimg); break;
-    default: launch_stream<4>(st, a, stride, map_stride, nimg); break;
+    case 1: launch_stream<V, 1>(st, a, stride, map_stride, nimg); break;
+    case 2: launch_stream<V, 2>(st, a, stride, map_stride, nimg); break;
+    case 3: launch_stream<V, 3>(st, a, stride, map_stride, nimg); break;
+    default: launch_stream<V, 4>(st, a, stride, map_stride, nimg); break;
     }
     return true;
+}
+
+}   // namespace
+
+// return false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
+bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+                               int w, int h, int p, int nimg, int step, float fac1, float fac2,
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+{
+    return launch_stream_any<float>(st, src, lx, ly, det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold);
+}
+
+bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+                                int w, int h, int p, int nimg, int step, int fac1, int fac2,
+                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
+{
+    return launch_stream_any<int>(st, src, lx, ly, det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold);
 }
