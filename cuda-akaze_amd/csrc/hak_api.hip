@@ -423,21 +423,33 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             const int n = lp.nsteps;
             const int G = hak_fed_groups(n, c->max_fuse, oc.w);     // launches of this FED cycle
             const float* fsrc;          // input of the first FED launch
+            bool fused_first = false;
             if (s == 0) {                                                         // akaze.cpp:369-392
-                // decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
+                // octave head: decimation + low-pass + conductivity + the first FED group in one streaming pass when covered
+                if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
+                    ProfScope ps(c, HAK_PROF_FED, st);
+                    fused_first = hak_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
+                                                         nimg, c->taps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
+                                                         c->state, o, G > 1);
+                    if (fused_first) c->fed_launches++;
+                }
+                // otherwise decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
                 float* first = (G % 2 == 0) ? Lt : tmp;
-                { ProfScope ps(c, HAK_PROF_DOWN, st);
-                  hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1); }
+                if (!fused_first) {
+                    ProfScope ps(c, HAK_PROF_DOWN, st);
+                    hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1);
+                }
                 fsrc = first;
             } else {                                                              // akaze.cpp:393-421
                 fsrc = A + L.lt(o, s - 1);
             }
             // sublevels > 0: low-pass + conductivity + the first FED group in one streaming pass when the case is covered
             // (PM_G2, 16-byte rows); the conductivity plane is written only if later groups of the cycle need it
-            bool fused_first = false;
             if (s == 0) {
-                ProfScope ps(c, HAK_PROF_FLOW, st);
-                hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
+                if (!fused_first) {
+                    ProfScope ps(c, HAK_PROF_FLOW, st);
+                    hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
+                }
             } else if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg) && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 &&
                        oc.h >= 8) {
                 const int ns0 = hak_fed_group_size(n, G, 0);
@@ -896,10 +908,13 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
             const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
             pxsteps += N * lp.nsteps;
             launches += lp.nsteps ? hak_fed_groups(lp.nsteps, c->max_fuse, L.oct[o].w) : 0;
-            // sublevels whose low-pass (8 B/px) + conductivity (8 B/px) run inside the first FED launch (k_fed_sf)
-            if (s > 0 && lp.nsteps && hak_stream_pays(c->fuse_sf, L.oct[o].w, L.oct[o].h, c->cfg.batch) && c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 &&
-                L.oct[o].h >= 8)
-                folded += 16.0 * N;
+            // sublevels whose low-pass (8 B/px) + conductivity (8 B/px) run inside the first FED launch (k_fed_sf), and octave
+            // heads whose decimation + low-pass (4 N_{o-1} + 8 N_o) + conductivity (8 N_o) do
+            const bool covered = lp.nsteps && hak_stream_pays(c->fuse_sf, L.oct[o].w, L.oct[o].h, c->cfg.batch) &&
+                                 c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 && L.oct[o].h >= 8;
+            if (covered && s > 0) folded += 16.0 * N;
+            if (covered && s == 0 && o > 0 && !(L.oct[o - 1].w & 1) && !(L.oct[o - 1].h & 1))
+                folded += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 16.0 * N;
             if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue
             else if (s == 0) all += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 8.0 * N + 8.0 * N + 24.0 * N + 4.0 * N;
             else all += 44.0 * N;

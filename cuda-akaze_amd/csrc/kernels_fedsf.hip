@@ -46,11 +46,27 @@ struct FsState {
     V4 Lq[PD];                          // prefetch ring
 };
 
-template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G>
+// row `row` of the kernel's input L, columns xl .. xl+3.  DEC = false: L is the plane itself.  DEC = true (octave head,
+// hDownWithSmooth akazed.cu:449-511): L is Lt(o-1,0) and the input is its 2x decimation, L(x, y) = src(2x, 2y); the two
+// 16-byte loads are never copied, the even components are simply the registers the consumers read.
+template <bool DEC, typename V, typename V4>
+__device__ __forceinline__ V4 fs_fetch(const V* __restrict__ L, const int row, const int lp, const int xl, const int sh)
+{
+    if constexpr (!DEC) return *reinterpret_cast<const V4*>(L + (long)row * lp + xl);
+    else {
+        const V* r = L + (long)min(2 * row, sh - 1) * lp + min(2 * xl, lp - 8);
+        const V4 a = *reinterpret_cast<const V4*>(r), b = *reinterpret_cast<const V4*>(r + 4);
+        return mk4(a.x, a.z, b.x, b.z);
+    }
+}
+
+// lp / sh: pitch and row count of the plane L points to (= p, h unless DEC)
+template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G, bool DEC>
 __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V* __restrict__ L, V* __restrict__ SMO,
                                         V* __restrict__ GO, V* __restrict__ D, const int p, const int xl,
                                         const int x0, const int w, const int h, const int ybeg, const int yend,
-                                        const bool owns, const FedFacs<V, NS>& fac, const SfTaps<V> kk, const float ikc)
+                                        const bool owns, const FedFacs<V, NS>& fac, const SfTaps<V> kk, const float ikc,
+                                        const int lp, const int sh)
 {
     using V4 = typename FedV<V>::V4;
     constexpr int GS = FsState<V, NS>::GS, PD = FsState<V, NS>::PD;
@@ -59,7 +75,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
     {
         const V4 Lc = S.Lq[pmod(U, PD)];
         S.Lr[pmod(U, 6)] = Lc;
-        S.Lq[pmod(U, PD)] = *reinterpret_cast<const V4*>(L + (long)min(t + PD, h - 1) * p + xl);
+        S.Lq[pmod(U, PD)] = fs_fetch<DEC, V, V4>(L, min(t + PD, h - 1), lp, xl, sh);
         if (YEDGE && t == 1) S.Lr[pmod(U - 2, 6)] = Lc;                              // FED: row -1 := row 1
         if (YEDGE && t == h) S.Lr[pmod(U, 6)] = S.Lr[pmod(U - 2, 6)];                // FED: row h := row h-2
     }
@@ -73,9 +89,17 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
             l1.x = le ? c.y : l1.x;                         // column -1 -> 1
             l2.x = le ? c.z : l2.x;                         // column -2 -> 2
             l2.y = le ? c.y : l2.y;                         // column -1 -> 1
-            r1.w = re ? c.z : r1.w;                         // column w   -> w-2
-            r2.z = re ? c.z : r2.z;                         // column w   -> w-2
-            r2.w = re ? c.y : r2.w;                         // column w+1 -> w-3
+            if constexpr (!DEC) {
+                r1.w = re ? c.z : r1.w;                     // column w   -> w-2
+                r2.z = re ? c.z : r2.z;                     // column w   -> w-2
+                r2.w = re ? c.y : r2.w;                     // column w+1 -> w-3
+            } else {
+                // octave head: the mirror is taken on the SOURCE extents (akazed.cu:466, 477-494); with an even source
+                // width that is column w -> w-1, w+1 -> w-2 on the decimated lattice
+                r1.w = re ? c.w : r1.w;
+                r2.z = re ? c.w : r2.z;
+                r2.w = re ? c.z : r2.w;
+            }
         }
         V4 rp;
         rp.x = sf_conv(c.x, l1.x, r1.x, l2.x, r2.x, kk);
@@ -86,8 +110,13 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         if (YEDGE) {
             if (t == 1) S.Rp[pmod(U - 2, 6)] = rp;                                   // row -1 := row 1
             if (t == 2) S.Rp[pmod(U - 4, 6)] = rp;                                   // row -2 := row 2
-            if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 2, 6)];                     // row h   := row h-2
-            if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 4, 6)];                 // row h+1 := row h-3
+            if constexpr (!DEC) {
+                if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 2, 6)];                 // row h   := row h-2
+                if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 4, 6)];             // row h+1 := row h-3
+            } else {                                                                 // source-extent mirror, even source height
+                if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 1, 6)];                 // row h   := row h-1
+                if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 3, 6)];             // row h+1 := row h-2
+            }
         }
     }
     // ---- column pass -> smooth row a = t - 2 (akazed.cu:283-288)
@@ -165,10 +194,11 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
     }
 }
 
-template <typename V, int NS, bool XE, bool WRITE_G>
+template <typename V, int NS, bool XE, bool WRITE_G, bool DEC>
 __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict__ SMO, V* __restrict__ GO,
                                          V* __restrict__ D, int w, int h, int p, const FedFacs<V, NS>& fac,
-                                         const SfTaps<V> kk, const float ikc, int x0, int ybeg, int yend, bool owns)
+                                         const SfTaps<V> kk, const float ikc, int x0, int ybeg, int yend, bool owns,
+                                         const int lp, const int sh)
 {
     using V4 = typename FedV<V>::V4;
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
@@ -191,23 +221,23 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
     S.gprev = z4;
 #pragma unroll
     for (int i = 0; i < FsState<V, NS>::PD; i++)
-        S.Lq[i] = *reinterpret_cast<const V4*>(L + (long)min(t0 + i, h - 1) * p + xl);
+        S.Lq[i] = fs_fetch<DEC, V, V4>(L, min(t0 + i, h - 1), lp, xl, sh);
     for (int tb = t0; tb <= tend; tb += 6) {
         // reflect injections fire while some stage is at rows 1..2 (t <= NS + 4) or at the virtual rows past h-1
         if (tb <= NS + 4 || tb + 5 >= h) {
-            fs_iter<V, NS, 0, true, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 1, true, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 2, true, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 3, true, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 4, true, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 5, true, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 0, true, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 1, true, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 2, true, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 3, true, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 4, true, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 5, true, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
         } else {
-            fs_iter<V, NS, 0, false, XE, WRITE_G>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 1, false, XE, WRITE_G>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 2, false, XE, WRITE_G>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 3, false, XE, WRITE_G>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 4, false, XE, WRITE_G>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
-            fs_iter<V, NS, 5, false, XE, WRITE_G>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc);
+            fs_iter<V, NS, 0, false, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 1, false, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 2, false, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 3, false, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 4, false, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 5, false, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
         }
     }
 }
@@ -216,11 +246,11 @@ constexpr int FS_HX = 8;                                    // x halo: 2 (Gaussi
 constexpr int FS_XV = 256 - 2 * FS_HX;
 
 // grid: hak_xcd_grid(strips, strip-row groups, images); a block's four waves take four consecutive row segments
-template <typename V, int NS, bool WRITE_G>
+template <typename V, int NS, bool WRITE_G, bool DEC>
 __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __restrict__ smooth, V* __restrict__ flow,
                                                 V* __restrict__ dst, long stride, int w, int h, int p,
                                                 FedFacs<V, NS> fac, SfTaps<V> kk, const HakImgState* __restrict__ state, int octave,
-                                                float fixed_ikc, int ry, int nbx, int nby, int nimg)
+                                                float fixed_ikc, int ry, int nbx, int nby, int nimg, int lp, int sh)
 {
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
@@ -236,13 +266,15 @@ __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= FS_HX && 4 * lane < FS_HX + FS_XV && x0 < w && x0 >= 0;
-    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<V, NS, true, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
-    else fs_strip<V, NS, false, WRITE_G>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns);
+    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<V, NS, true, WRITE_G, DEC>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
+    else fs_strip<V, NS, false, WRITE_G, DEC>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
 }
 
+// sp > 0: octave head -- `src` is Lt(o-1,0) with pitch sp and sh rows, the kernel's input is its 2x decimation
 template <typename V, int NS>
 void launch_fs(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long stride, int w, int h, int p,
-               int nimg, SfTaps<V> kk, const float* tau, const HakImgState* state, int octave, float fixed_ikc, bool write_g)
+               int nimg, SfTaps<V> kk, const float* tau, const HakImgState* state, int octave, float fixed_ikc, bool write_g,
+               int sp = 0, int sh = 0)
 {
     FedFacs<V, NS> fac;
     for (int k = 0; k < NS; k++) {
@@ -254,25 +286,27 @@ void launch_fs(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long st
     int ry = 128;
     while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (h + 4 * ry - 1) / (4 * ry);
-    if (write_g)
-        k_fed_sf<V, NS, true><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
-                                                                         fixed_ikc, ry, gx, gy, nimg);
-    else
-        k_fed_sf<V, NS, false><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave,
-                                                                          fixed_ikc, ry, gx, gy, nimg);
+    const unsigned grid = hak_xcd_grid(gx, gy, nimg);
+    if (sp > 0) {
+        if (write_g) k_fed_sf<V, NS, true, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
+        else k_fed_sf<V, NS, false, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
+    } else {
+        if (write_g) k_fed_sf<V, NS, true, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+        else k_fed_sf<V, NS, false, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+    }
 }
 
 template <typename V>
 bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long stride, int w, int h, int p, int nimg,
                    SfTaps<V> kk, int diffusivity, const float* tau, int ns, const HakImgState* state, int octave, float fixed_ikc,
-                   bool write_g)
+                   bool write_g, int sp = 0, int sh = 0)
 {
     if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
     switch (ns) {
-    case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
-    case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
-    case 3: launch_fs<V, 3>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
-    default: launch_fs<V, 4>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g); break;
+    case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
+    case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
+    case 3: launch_fs<V, 3>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
+    default: launch_fs<V, 4>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
     }
     return true;
 }
@@ -296,4 +330,17 @@ bool hakf_launch_fed_sf(hipStream_t st, const int* src, int* smooth, int* flow, 
 {
     return launch_fs_any<int>(st, src, smooth, flow, dst, stride, w, h, p, nimg, SfTaps<int>{itaps[0], itaps[1], itaps[2]},
                               diffusivity, tau, ns, state, octave, 0.f, write_g);
+}
+
+// octave head (akaze.cpp:369-392): src = Lt(o-1,0) of the previous octave (so = its geometry); smooth = G1(decimated src) with
+// the source-extent mirror of hDownWithSmooth, g = PM_G2(smooth), dst = ns FED steps of the decimated plane.  The decimated
+// plane itself is never written.  Covered for even source extents only (odd ones mirror onto source pixels that are not on
+// the decimated lattice): otherwise returns false (caller: k_down_smooth + k_flow + k_fed_multi).
+bool hak_launch_fed_sf_head(hipStream_t st, const float* src, HakOct so, float* smooth, float* flow, float* dst, long stride,
+                            HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
+                            const HakImgState* state, int octave, bool write_g)
+{
+    if ((so.w & 1) || (so.h & 1) || so.p < 2 * 8 || dd.w != so.w / 2 || dd.h != so.h / 2) return false;
+    return launch_fs_any<float>(st, src, smooth, flow, dst, stride, dd.w, dd.h, dd.p, nimg, SfTaps<float>{taps[0], taps[1], taps[2]},
+                                diffusivity, tau, ns, state, octave, 0.f, write_g, so.p, so.h);
 }

@@ -188,7 +188,8 @@ int hak_debug_kcontrast(hak_ctx* ctx, int img, float* kcontrast);
 typedef struct hak_traffic {
     double fed_px_steps;     /* sum over FED steps of pixels updated, per image */
     double fed_bytes;        /* 12 B x fed_px_steps, + 16 B/px (low-pass 8 + conductivity 8) for every
-                                sublevel whose low-pass and conductivity run inside its first FED launch (k_fed_sf) */
+                                sublevel whose low-pass and conductivity run inside its first FED launch (k_fed_sf), + the decimation /
+                                low-pass / conductivity bytes of every octave head that does the same */
     double all_stage_bytes;  /* all-stage compulsory bytes per image, keypoint part for npts_hint points */
     int fed_launches;        /* FED kernel launches per batch */
 } hak_traffic;
