@@ -168,6 +168,7 @@ struct hak_ctx {
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
+    int fuse_head = 1;              // octave heads through the decimating k_fed_sf variant (env HAK_FUSE_HEAD=0 disables)
     int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
@@ -295,6 +296,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (c->cfg.batch < 1) c->cfg.batch = 1;
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
     if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
+    if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
     { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
@@ -426,7 +428,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             bool fused_first = false;
             if (s == 0) {                                                         // akaze.cpp:369-392
                 // octave head: decimation + low-pass + conductivity + the first FED group in one streaming pass when covered
-                if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
+                if (c->fuse_head && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
                     ProfScope ps(c, HAK_PROF_FED, st);
                     fused_first = hak_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
                                                          nimg, c->taps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
@@ -549,9 +551,15 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             bool fused_first = false;
             if (s == 0) {                                                         // akaze.cpp:640-662
                 int* first = (G % 2 == 0) ? Lt : tmp;
-                hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
+                if (fused && c->fuse_head && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg))
+                    fused_first = hakf_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
+                                                          nimg, c->itaps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
+                                                          c->state, o, G > 1);
+                if (!fused_first) {
+                    hakf_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->itaps1);
+                    hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
+                }
                 src = first;
-                hakf_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o);
             } else {                                                              // akaze.cpp:664-695
                 src = A + L.lt(o, s - 1);
                 // low-pass + conductivity + first FED group in one streaming pass when covered, else low-pass + flow in one tile pass
@@ -913,7 +921,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
             const bool covered = lp.nsteps && hak_stream_pays(c->fuse_sf, L.oct[o].w, L.oct[o].h, c->cfg.batch) &&
                                  c->cfg.diffusivity == HAK_PM_G2 && (L.oct[o].w & 3) == 0 && L.oct[o].w >= 16 && L.oct[o].h >= 8;
             if (covered && s > 0) folded += 16.0 * N;
-            if (covered && s == 0 && o > 0 && !(L.oct[o - 1].w & 1) && !(L.oct[o - 1].h & 1))
+            if (covered && c->fuse_head && s == 0 && o > 0 && !(L.oct[o - 1].w & 1) && !(L.oct[o - 1].h & 1))
                 folded += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 16.0 * N;
             if (o == 0 && s == 0) all += 56.0 * N;                                // o0 prologue
             else if (s == 0) all += 4.0 * L.oct[o - 1].w * L.oct[o - 1].h + 8.0 * N + 8.0 * N + 24.0 * N + 4.0 * N;

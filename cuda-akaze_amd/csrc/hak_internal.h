@@ -244,6 +244,9 @@ bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_s
 bool hak_launch_fed_sf_head(hipStream_t st, const float* src, HakOct so, float* smooth, float* flow, float* dst, long stride,
                             HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
                             const HakImgState* state, int octave, bool write_g);
+bool hakf_launch_fed_sf_head(hipStream_t st, const int* src, HakOct so, int* smooth, int* flow, int* dst, long stride,
+                             HakOct dd, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
+                             const HakImgState* state, int octave, bool write_g);
 bool hakf_launch_fed_sf(hipStream_t st, const int* src, int* smooth, int* flow, int* dst, long stride,
                         int w, int h, int p, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
                         const HakImgState* state, int octave, bool write_g);

@@ -344,3 +344,13 @@ bool hak_launch_fed_sf_head(hipStream_t st, const float* src, HakOct so, float* 
     return launch_fs_any<float>(st, src, smooth, flow, dst, stride, dd.w, dd.h, dd.p, nimg, SfTaps<float>{taps[0], taps[1], taps[2]},
                                 diffusivity, tau, ns, state, octave, 0.f, write_g, so.p, so.h);
 }
+
+// the FAST path's octave head (fastakaze::gDownWithSmooth akazed.cu:3143-3205 uses the same source-extent mirror)
+bool hakf_launch_fed_sf_head(hipStream_t st, const int* src, HakOct so, int* smooth, int* flow, int* dst, long stride,
+                             HakOct dd, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
+                             const HakImgState* state, int octave, bool write_g)
+{
+    if ((so.w & 1) || (so.h & 1) || so.p < 2 * 8 || dd.w != so.w / 2 || dd.h != so.h / 2) return false;
+    return launch_fs_any<int>(st, src, smooth, flow, dst, stride, dd.w, dd.h, dd.p, nimg, SfTaps<int>{itaps[0], itaps[1], itaps[2]},
+                              diffusivity, tau, ns, state, octave, 0.f, write_g, so.p, so.h);
+}

@@ -214,6 +214,7 @@ def test_knn2_with_context_scratch_and_repeat(ah, okz, torch, synth):
 
 @pytest.mark.parametrize("env", [{"HAK_FUSE_SF": "0"}, {"HAK_HESS_STREAM": "0"}, {"HAK_FED_MAX_FUSE": "1"}, {"HAK_GRAPH": "0", "HAK_SERIAL": "1"},
                                  {"HAK_FUSE_SF": "1", "HAK_HESS_STREAM": "1"},          # the default size rule
+                                 {"HAK_FUSE_HEAD": "0"},
                                  {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_FED_MAX_FUSE": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
