@@ -111,6 +111,7 @@ SYMBOLS = {
     "hak_op_kcontrast": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _ip]),
     "hak_op_flow": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "hak_op_nld_steps": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, _fp, C.c_int]),
+    "hak_op_rcp_check": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     "hak_op_smooth_flow": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "hak_op_hessian": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
 }

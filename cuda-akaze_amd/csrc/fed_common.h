@@ -123,3 +123,15 @@ __device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
 __device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
 __device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
 
+
+// ---- 1 / d for the PM_G2 conductivity g = 1 / (1 + dif2).  hipcc's correctly rounded float division costs ~11 instructions
+// (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup).  For 1 <= d < 2^64 the three-instruction sequence below --
+// v_rcp_f32 plus one Newton step with explicit fmas -- returns the identical bits: checked exhaustively over all 2^29
+// floats of that range on gfx950 (tools/rcp_exhaustive.hip; the library's own copy is re-checked by hak_op_rcp_check in
+// the GPU tests).  Callers must send anything else (NaN, inf, >= 2^64) through the IEEE division.
+__device__ __forceinline__ float hak_rcp_newton(float d)
+{
+    const float y0 = __builtin_amdgcn_rcpf(d);
+    const float e = fmaf(-d, y0, 1.0f);
+    return fmaf(e, y0, y0);
+}

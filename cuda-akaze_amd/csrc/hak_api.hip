@@ -1005,6 +1005,19 @@ extern "C" int hak_op_flow(const float* s, float* d, int w, int h, int p, int di
     return 0;
 }
 
+extern "C" int hak_op_rcp_check(unsigned lo_bits, unsigned hi_bits, unsigned long long* mismatches)
+{
+    if (!mismatches) return fail("null argument");
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(d, 0, sizeof(unsigned long long)));
+    int rc = hak_launch_rcp_check(lo_bits, hi_bits, d);
+    if (!rc && hipDeviceSynchronize() != hipSuccess) rc = fail("rcp check kernel");
+    if (!rc && hipMemcpy(mismatches, d, sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) rc = fail("rcp check download");
+    (void)hipFree(d);
+    return rc;
+}
+
 extern "C" int hak_op_smooth_flow(const float* s, float* sm, float* fl, int w, int h, int p, int diffusivity, float kcontrast)
 {
     float taps[8];

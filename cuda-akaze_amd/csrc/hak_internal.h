@@ -241,6 +241,7 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
 bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,
                             int w, int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state,
                             float per, int noct);
+int hak_launch_rcp_check(unsigned lo, unsigned hi, unsigned long long* d_bad);
 bool hak_launch_fed_sf_head(hipStream_t st, const float* src, HakOct so, float* smooth, float* flow, float* dst, long stride,
                             HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
                             const HakImgState* state, int octave, bool write_g);

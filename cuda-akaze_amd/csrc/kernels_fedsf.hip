@@ -149,18 +149,27 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         const V cL = S.SmL[pmod(U - 1, 3)], cR = S.SmR[pmod(U - 1, 3)];
         const V dL = S.SmL[pmod(U, 3)], dR = S.SmR[pmod(U, 3)];
         V4 g;
+        float4 den;                                         // 1 + dif2 of the four pixels
 #define FS_G(k, ul, uc, ur, cl, cr, ll, lc, lr)                                             \
         {                                                                                   \
             const V dx = 10 * ((cr) - (cl)) + 3 * ((ur) + (lr) - (ul) - (ll));              \
             const V dy = 10 * ((lc) - (uc)) + 3 * ((ll) + (lr) - (ul) - (ur));              \
-            const float dif2 = sf_dif2(dx, dy, ikc);                                        \
-            g.k = sf_g_as<V>(1.f / (1.f + dif2));                                           \
+            den.k = 1.f + sf_dif2(dx, dy, ikc);                                             \
         }
         FS_G(x, uL, su.x, su.y, cL, sc.y, dL, sd.x, sd.y)
         FS_G(y, su.x, su.y, su.z, sc.x, sc.z, sd.x, sd.y, sd.z)
         FS_G(z, su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w)
         FS_G(w, su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR)
 #undef FS_G
+        // g = 1 / den: the 3-instruction reciprocal is bit-identical to the IEEE division on [1, 2^64) (fed_common.h); a wave
+        // with any value outside that range (NaN / inf from a degenerate contrast factor) takes the division for all lanes
+        const bool fast = den.x < 0x1p64f && den.y < 0x1p64f && den.z < 0x1p64f && den.w < 0x1p64f;
+        if (__ballot(!fast) == 0ull) {
+            g = mk4(sf_g_as<V>(hak_rcp_newton(den.x)), sf_g_as<V>(hak_rcp_newton(den.y)), sf_g_as<V>(hak_rcp_newton(den.z)),
+                    sf_g_as<V>(hak_rcp_newton(den.w)));
+        } else {
+            g = mk4(sf_g_as<V>(1.f / den.x), sf_g_as<V>(1.f / den.y), sf_g_as<V>(1.f / den.z), sf_g_as<V>(1.f / den.w));
+        }
         if (WRITE_G && tf >= ybeg && tf < yend && owns) *reinterpret_cast<V4*>(GO + (long)tf * p + x0) = g;
         const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
         GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
@@ -311,7 +320,25 @@ bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, lon
     return true;
 }
 
+__global__ __launch_bounds__(256) void k_rcp_check(unsigned lo, unsigned hi, unsigned long long* bad)
+{
+    unsigned long long n = 0;
+    for (unsigned long long b = lo + blockIdx.x * (unsigned long long)blockDim.x + threadIdx.x; b < hi;
+         b += (unsigned long long)gridDim.x * blockDim.x) {
+        const float d = __uint_as_float((unsigned)b);
+        n += __float_as_uint(hak_rcp_newton(d)) != __float_as_uint(1.0f / d);
+    }
+    if (n) atomicAdd(bad, n);
+}
+
 }   // namespace
+
+// number of floats with bit patterns in [lo, hi) for which hak_rcp_newton(d) differs from the IEEE quotient 1.0f / d
+int hak_launch_rcp_check(unsigned lo, unsigned hi, unsigned long long* d_bad)
+{
+    k_rcp_check<<<4096, 256>>>(lo, hi, d_bad);
+    return hipGetLastError() == hipSuccess ? 0 : 1;
+}
 
 // smooth = G1(src); g = PM_G2(smooth) (written to `flow` only when write_g); dst = ns FED steps of src under g.
 // Returns false when the case is not covered (caller: hak_launch_smooth_flow + hak_launch_fed_group).

@@ -215,6 +215,9 @@ int hak_op_kcontrast(const float* d_smooth, int w, int h, int p, float per, floa
 int hak_op_flow(const float* d_src, float* d_dst, int w, int h, int p, int diffusivity, float kcontrast); /* hFlow 2487 */
 int hak_op_nld_steps(const float* d_src, const float* d_flow, float* d_dst, float* d_tmp,
                      int w, int h, int p, const float* tau, int nsteps);                                  /* hNldStep 2509, n steps */
+/* self-check of the conductivity's fast reciprocal (csrc/fed_common.h hak_rcp_newton): counts the floats with bit patterns
+ * in [lo_bits, hi_bits) whose 3-instruction reciprocal differs from the IEEE quotient 1.0f / d.  Must be 0 on [1, 2^64). */
+int hak_op_rcp_check(unsigned lo_bits, unsigned hi_bits, unsigned long long* mismatches);
 int hak_op_smooth_flow(const float* d_src, float* d_smooth, float* d_flow, int w, int h, int p,
                        int diffusivity, float kcontrast);                                               /* hLowPass(var 1) + hFlow, akaze.cpp:403-404 */
 int hak_op_hessian(const float* d_src, float* d_lx, float* d_ly, float* d_det, int w, int h, int p, int step); /* hHessianDeterminant 2531 */

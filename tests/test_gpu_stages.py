@@ -124,3 +124,13 @@ def test_smooth_flow_fused(ah, okz, torch, w, h, diff):
     ah.check(ah.lib.hak_op_smooth_flow(d_a.data_ptr(), d_sm.data_ptr(), d_g.data_ptr(), w, h, p, diff, 0.41))
     sm = okz.lowpass(a, w, 1.0, 2)
     assert eq(d_sm, sm, w) and eq(d_g, okz.flow(sm, w, diff, 0.41), w)
+
+
+def test_fast_reciprocal_is_the_ieee_quotient(ah):
+    """k_fed_sf computes g = 1 / (1 + dif2) with v_rcp_f32 + one Newton step instead of the 11-instruction IEEE division;
+    that is only legitimate because the two agree on every float of [1, 2^64): checked exhaustively (2^29 values)"""
+    n = C.c_ulonglong(123)
+    ah.check(ah.lib.hak_op_rcp_check(0x3F800000, 0x5F800000, C.byref(n)))
+    assert n.value == 0
+    ah.check(ah.lib.hak_op_rcp_check(0x5F800000, 0x7F800000, C.byref(n)))       # beyond 2^64 the sequence is NOT exact ...
+    assert n.value > 0                                                           # ... which is why the kernel range-checks
