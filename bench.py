@@ -85,6 +85,7 @@ def main():
                     help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path")
     ap.add_argument("--fast", action="store_true",
                     help="also time the integer FAST path (fastDetectAndCompute, uint8 inputs) on the same pairs")
+    ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
     args = ap.parse_args()
@@ -128,7 +129,7 @@ def main():
     stream = torch.cuda.current_stream()
     for k in range(NCTX):
         dk = ah.Akazer()
-        dk.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg)
+        dk.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg, upright=bool(args.upright))
         if k == 0:
             ah.check(ah.lib.hak_set_stream(dk.ctx, C.c_void_p(stream.cuda_stream)))
         if args.serial:

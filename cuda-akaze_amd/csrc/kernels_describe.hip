@@ -50,13 +50,11 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
     __shared__ float s_angle;
     // the orientation scratch is dead before the first accumulator round starts: it lives inside the table
     // (12.9 KB per block instead of 15.1 KB = 12 instead of 10 keypoints in flight per CU)
-    float* const sdx = acc;                     // [128]
-    float* const sdy = acc + 128;               // [128]
-    int* const sbin = reinterpret_cast<int*>(acc + 256);    // [128]
-    float* const resx = acc + 384;              // [42]
-    float* const resy = acc + 432;              // [42]
-    float* const re8x = acc + 480;              // [42]
-    float* const re8y = acc + 528;              // [42]
+    float4* const samp = reinterpret_cast<float4*>(acc);    // [128] {dx, dy, bin (as int bits), -}: one 16-byte broadcast read per sample
+    float* const resx = acc + 512;              // [42]
+    float* const resy = acc + 560;              // [42]
+    float* const re8x = acc + 608;              // [42]
+    float* const re8y = acc + 656;              // [42]
 
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
@@ -120,9 +118,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                     int a = (int)(ang * (21 / HAK_PI_D)) + 21;      // akazed.cu:1702
                     a = a > 41 ? 41 : a;
                     a = a < 0 ? 0 : a;
-                    sdx[slot] = dx;
-                    sdy[slot] = dy;
-                    sbin[slot] = a;
+                    samp[slot] = make_float4(dx, dy, __int_as_float(a), 0.f);
                 }
                 nvalid += __popcll(m);
             }
@@ -131,7 +127,12 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 float rx = 0.f, ry = 0.f;
 #pragma unroll 8
                 for (int n = 0; n < nvalid; n++) {                  // ascending sample order (D7)
-                    if (sbin[n] == lane) { rx += sdx[n]; ry += sdy[n]; }
+                    // unconditional read + select: a branch on the bin made every iteration two dependent LDS round trips
+                    const float4 sv = samp[n];
+                    const bool mine = __float_as_int(sv.z) == lane;
+                    const float nx = rx + sv.x, ny = ry + sv.y;
+                    rx = mine ? nx : rx;
+                    ry = mine ? ny : ry;
                 }
                 resx[lane] = rx;
                 resy[lane] = ry;
