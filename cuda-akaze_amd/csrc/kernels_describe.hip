@@ -41,51 +41,29 @@ __device__ __forceinline__ void reduce_rows(const float* acc, float* vals, int n
     }
 }
 
-__global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base, long stride, HakLayout L,
-                                                 const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
-                                                 hak_point* points, int max_pts, int patsize, int upright, int desc)
+// ---- dominant orientation as its own kernel: it needs ~3 KB of LDS and few registers, so many more keypoints are in flight
+// per CU than inside the descriptor kernel (whose accumulator table and sample registers cap it at 12 per CU); its gather and
+// LDS latency chains then overlap.  Writes pt->angle; k_describe reads it back.
+__global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, long stride, HakLayout L,
+                                               const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
+                                               hak_point* points, int max_pts)
 {
-    __shared__ float acc[ACC_ROWS * ACC_LD];    // [cell*3+ch][thread], one round at a time
-    __shared__ float vals[90];
-    __shared__ float s_angle;
-    // the orientation scratch is dead before the first accumulator round starts: it lives inside the table
-    // (12.9 KB per block instead of 15.1 KB = 12 instead of 10 keypoints in flight per CU)
-    float4* const samp = reinterpret_cast<float4*>(acc);    // [128] {dx, dy, bin (as int bits), -}: one 16-byte broadcast read per sample
-    float* const resx = acc + 512;              // [42]
-    float* const resy = acc + 560;              // [42]
-    float* const re8x = acc + 608;              // [42]
-    float* const re8y = acc + 656;              // [42]
-
+    __shared__ float4 samp[128];                // {dx, dy, bin (as int bits), -}: one 16-byte broadcast read per sample
+    __shared__ float resx[42], resy[42], re8x[42], re8y[42];
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
     const int npts = state[img].num_pts;
     const float* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
-    if (!desc) return;
-
-    const int size2 = patsize;
-    const int size3 = (int)ceilf(2.0f * patsize / 3.0f);            // akazed.cu:2682
-    const int size4 = (int)ceilf(0.5f * patsize);                   // akazed.cu:2683
-    const int winsize = max(3 * size3, 4 * size4);
-    const int nsmp = winsize * winsize;
-
-    // this lane's 8 comparison pairs (akazed.cu:65-159), packed as bytes: one 16-byte load
-    const uint4 cmp = reinterpret_cast<const uint4*>(tab->comp_packed)[lane];
-    const unsigned int cw[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
-
     for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
         const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
         const int layer = pt->octave;
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
-        const float* imd = arena + L.lt(o, s);
         const float* dxd = arena + L.lx(o, s);
         const float* dyd = arena + L.ly(o, s);
-        float angle = 0.f;
-
-        // ------------------------------------------------------ orientation
-        if (!upright) {
+        {
             const int step = (int)(ptsize + 0.5f);
             const int x = (int)(ptx + 0.5f) >> o;
             const int y = (int)(pty + 0.5f) >> o;
@@ -166,11 +144,50 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 r = (absy > absx ? HAK_HPI_F - r : r);
                 r = (xv < 0 ? (float)(HAK_PI_D - r) : r);
                 r = (yv < 0 ? -r : r);
-                s_angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);    // akazed.cu:1734
+                pt->angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);  // akazed.cu:1734
             }
             hak_lds_barrier();
-            angle = s_angle;
         }
+        hak_lds_barrier();                      // the scratch is reused by the next keypoint of this block
+    }
+}
+
+__global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base, long stride, HakLayout L,
+                                                 const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
+                                                 hak_point* points, int max_pts, int patsize, int upright, int desc)
+{
+    __shared__ float acc[ACC_ROWS * ACC_LD];    // [cell*3+ch][thread], one round at a time
+    __shared__ float vals[90];
+
+    const int img = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int npts = state[img].num_pts;
+    const float* arena = base + (long)img * stride;
+    hak_point* pts = points + (long)img * max_pts;
+    if (!desc) return;
+
+    const int size2 = patsize;
+    const int size3 = (int)ceilf(2.0f * patsize / 3.0f);            // akazed.cu:2682
+    const int size4 = (int)ceilf(0.5f * patsize);                   // akazed.cu:2683
+    const int winsize = max(3 * size3, 4 * size4);
+    const int nsmp = winsize * winsize;
+
+    // this lane's 8 comparison pairs (akazed.cu:65-159), packed as bytes: one 16-byte load
+    const uint4 cmp = reinterpret_cast<const uint4*>(tab->comp_packed)[lane];
+    const unsigned int cw[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
+
+    for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
+        hak_point* pt = pts + pi;
+        const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
+        const int layer = pt->octave;
+        const int o = layer / L.ms, s = layer - o * L.ms;
+        const HakOct oc = L.oct[o];
+        const float* imd = arena + L.lt(o, s);
+        const float* dxd = arena + L.lx(o, s);
+        const float* dyd = arena + L.ly(o, s);
+        float angle = 0.f;
+
+        if (!upright) angle = pt->angle;                            // written by k_orient
 
         // ------------------------------------------------------------- MLDB
         // phase 1: positions + all gathers of this lane's samples (i = lane, lane+64, ...)
@@ -281,5 +298,6 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 {
     int gx = max_pts < 4096 ? max_pts : 4096;
     dim3 grid(gx, b.nimg);
+    if (desc && !upright) k_orient<<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts);
     k_describe<<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }
