@@ -13,6 +13,7 @@ kernels whose loads are float4 streams (the FED kernel); WRITE_SIZE is exact for
 """
 import collections
 import csv
+import os
 import glob
 import json
 import sys
@@ -46,12 +47,13 @@ def main():
         note="FETCH_SIZE doubled (gfx950 reports half of a 16 B/lane streaming read); WRITE_SIZE as reported",
         fed_launches=launches,
         fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
-        fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows)
+        fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows,
+        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "64")))
     json.dump(summary, open(out + ".json", "w"), indent=1)
     with open(out + ".csv", "w") as f:
         f.write("kernel,dispatches,FETCH_SIZE_bytes,WRITE_SIZE_bytes\n")
         for r in rows:
-            f.write(f"{r['kernel']},{r['dispatches']},{r['fetch_size_bytes']:.0f},{r['write_size_bytes']:.0f}\n")
+            f.write(f"\"{r['kernel']}\",{r['dispatches']},{r['fetch_size_bytes']:.0f},{r['write_size_bytes']:.0f}\n")
     print(json.dumps({k: v for k, v in summary.items() if k != "per_kernel"}))
 
 
