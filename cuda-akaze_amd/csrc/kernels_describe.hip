@@ -3,6 +3,9 @@
 //
 //   hCalcOrient/gCalcOrient   akazed.cu:2655, 1665 (+ dFastAtan2 173-185)
 //   hDescribe/gDescribe2      akazed.cu:2675, 1869
+//   FAST path (V = int, 16.16 planes): refine akazed.cu:3600, orientation 3649, MLDB 3723 -- the same two kernels,
+//   instantiated on the element type like the other heavy kernels (integer sums are exactly associative, so the
+//   float path's per-lane table + tree is a valid order for them too)
 //
 // Bit-exactness rules taken over from the reference / the parity oracle:
 //   * orientation: the 109 disc samples are summed into the 42 bins in
@@ -16,6 +19,7 @@
 // in three rounds over a third-size LDS table (8.2 KB per keypoint), which triples the number of
 // keypoints a CU works on concurrently.
 #include "hak_internal.h"
+#include <type_traits>
 
 #define ACC_LD 65           // padded leading dimension of the per-thread accumulator table
 #define ACC_ROWS 30         // accumulator rows per round (multiple of 3): 87 rows in 3 rounds
@@ -23,46 +27,95 @@
 
 // reduce accumulator rows [0, nrows) of the table in the reference's order:
 // b_t = a_t + a_{t+32}; tree over t with strides 1,2,4,8,16; lane c owns row c
-__device__ __forceinline__ void reduce_rows(const float* acc, float* vals, int nrows, int out_base, int lane)
+__device__ __forceinline__ float dsc_add(float a, float b) { return a + b; }
+__device__ __forceinline__ int dsc_add(int a, int b) { return (int)((unsigned)a + (unsigned)b); }    // wraps like the reference
+__device__ __forceinline__ int dsc_mul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }
+
+// dFastAtan2, akazed.cu:173-185 (0/0 -> 0)
+__device__ __forceinline__ float dsc_fast_atan2(float yv, float xv)
+{
+    const float absx = fabsf(xv), absy = fabsf(yv);
+    const float mn = absx < absy ? absx : absy, mx = absx < absy ? absy : absx;
+    const float a = mx > 0.f ? mn / mx : 0.f;
+    const float sq = a * a;
+    float r = fmaf(fmaf(fmaf(-0.0464964749f, sq, 0.15931422f), sq, -0.327622764f), sq * a, a);
+    r = (absy > absx ? HAK_HPI_F - r : r);
+    r = (xv < 0 ? (float)(HAK_PI_D - r) : r);
+    r = (yv < 0 ? -r : r);
+    return r;
+}
+
+template <typename V>
+__device__ __forceinline__ void reduce_rows(const V* acc, V* vals, int nrows, int out_base, int lane)
 {
     if (lane < nrows) {
-        const float* a = acc + lane * ACC_LD;
+        const V* a = acc + lane * ACC_LD;
         // the same tree, evaluated 8 leaves at a time to keep the register footprint small:
         // c_k = ((b0+b1)+(b2+b3)) + ((b4+b5)+(b6+b7)) with b_j = a[8k+j] + a[8k+j+32]; result (c0+c1)+(c2+c3)
-        float c[4];
+        V c[4];
 #pragma unroll 1
         for (int k = 0; k < 4; k++) {
-            const float* q = a + 8 * k;
-            const float b0 = q[0] + q[32], b1 = q[1] + q[33], b2 = q[2] + q[34], b3 = q[3] + q[35];
-            const float b4 = q[4] + q[36], b5 = q[5] + q[37], b6 = q[6] + q[38], b7 = q[7] + q[39];
-            c[k] = ((b0 + b1) + (b2 + b3)) + ((b4 + b5) + (b6 + b7));
+            const V* q = a + 8 * k;
+            const V b0 = dsc_add(q[0], q[32]), b1 = dsc_add(q[1], q[33]), b2 = dsc_add(q[2], q[34]), b3 = dsc_add(q[3], q[35]);
+            const V b4 = dsc_add(q[4], q[36]), b5 = dsc_add(q[5], q[37]), b6 = dsc_add(q[6], q[38]), b7 = dsc_add(q[7], q[39]);
+            c[k] = dsc_add(dsc_add(dsc_add(b0, b1), dsc_add(b2, b3)), dsc_add(dsc_add(b4, b5), dsc_add(b6, b7)));
         }
-        vals[out_base + lane] = (c[0] + c[1]) + (c[2] + c[3]);
+        vals[out_base + lane] = dsc_add(dsc_add(c[0], c[1]), dsc_add(c[2], c[3]));
     }
 }
 
 // ---- dominant orientation as its own kernel: it needs ~3 KB of LDS and few registers, so many more keypoints are in flight
 // per CU than inside the descriptor kernel (whose accumulator table and sample registers cap it at 12 per CU); its gather and
-// LDS latency chains then overlap.  Writes pt->angle; k_describe reads it back.
-__global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, long stride, HakLayout L,
+// LDS latency chains then overlap.  Writes pt->angle; k_describe reads it back.  The FAST instantiation first refines the
+// keypoint position on the determinant plane (akazed.cu:3600; the float path refines in k_emit) and is launched for that alone
+// (do_orient = 0) when no orientation is wanted.
+template <typename V>
+__global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long stride, HakLayout L,
                                                const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
-                                               hak_point* points, int max_pts)
+                                               hak_point* points, int max_pts, int do_orient)
 {
+    constexpr bool FAST = std::is_same<V, int>::value;
     __shared__ float4 samp[128];                // {dx, dy, bin (as int bits), -}: one 16-byte broadcast read per sample
     __shared__ float resx[42], resy[42], re8x[42], re8y[42];
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
     const int npts = state[img].num_pts;
-    const float* arena = base + (long)img * stride;
+    const V* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
     for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
-        const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
+        float ptx = pt->x, pty = pt->y;
+        const float ptsize = pt->size;
         const int layer = pt->octave;
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
-        const float* dxd = arena + L.lx(o, s);
-        const float* dyd = arena + L.ly(o, s);
+        const V* dxd = arena + L.lx(o, s);
+        const V* dyd = arena + L.ly(o, s);
+        if constexpr (FAST) {
+            if (lane == 0) {
+                const int* detd = arena + L.det(o, s);
+                const int y = (int)pty >> o, x = (int)ptx >> o, p = oc.p;
+                const long idx = (long)y * p + x;
+                const int v2 = detd[idx] + detd[idx];
+                const int dx = (detd[idx + 1] - detd[idx - 1]) >> 1, dy = (detd[idx + p] - detd[idx - p]) >> 1;
+                const int dxx = detd[idx + 1] + detd[idx - 1] - v2, dyy = detd[idx + p] + detd[idx - p] - v2;
+                const int dxy = (detd[idx + p + 1] + detd[idx - p - 1] - detd[idx - p + 1] - detd[idx + p - 1]) >> 2;
+                const int dd = dsc_add(dsc_mul(dxx, dyy), -dsc_mul(dxy, dxy));
+                const float idd = dd != 0 ? (1.f / dd) : 0.f;
+                const float dst0 = idd * dsc_add(dsc_mul(dxy, dy), -dsc_mul(dyy, dx));
+                const float dst1 = idd * dsc_add(dsc_mul(dxy, dx), -dsc_mul(dxx, dy));
+                if (!(dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f)) {
+                    const int ratio = 1 << o;
+                    pty = ratio * (y + dst1);
+                    ptx = ratio * (x + dst0);
+                    pt->x = ptx;
+                    pt->y = pty;
+                }
+            }
+            ptx = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(ptx)));
+            pty = __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(pty)));
+            if (!do_orient) continue;
+        }
         {
             const int step = (int)(ptsize + 0.5f);
             const int x = (int)(ptx + 0.5f) >> o;
@@ -78,8 +131,8 @@ __global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, l
                 gr2[q] = (tix < 208 && r2 < 36) ? r2 : -1;
                 const int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
                 const long pos = (long)yy * oc.p + xx;
-                gdx[q] = gr2[q] >= 0 ? dxd[pos] : 0.f;
-                gdy[q] = gr2[q] >= 0 ? dyd[pos] : 0.f;
+                gdx[q] = gr2[q] >= 0 ? (float)dxd[pos] : 0.f;
+                gdy[q] = gr2[q] >= 0 ? (float)dyd[pos] : 0.f;
             }
             // valid samples are compacted in ascending thread order through a ballot
             int nvalid = 0;
@@ -92,8 +145,8 @@ __global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, l
                     const float gw = tab->orient_w[gr2[q]];
                     const float dx = gw * gdx[q];
                     const float dy = gw * gdy[q];
-                    const float ang = hak_atan2f(dy, dx);
-                    int a = (int)(ang * (21 / HAK_PI_D)) + 21;      // akazed.cu:1702
+                    const float ang = FAST ? dsc_fast_atan2(dy, dx) : hak_atan2f(dy, dx);   // akazed.cu:3685 / 1702
+                    int a = (int)(ang * (21 / HAK_PI_D)) + 21;
                     a = a > 41 ? 41 : a;
                     a = a < 0 ? 0 : a;
                     samp[slot] = make_float4(dx, dy, __int_as_float(a), 0.f);
@@ -134,16 +187,7 @@ __global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, l
             const unsigned long long mm = __ballot(lane < 42 && rk == rmax);
             const int maxk = rmax > 0.f && mm ? __ffsll((long long)mm) - 1 : 0;
             if (lane == 0) {
-                // dFastAtan2 akazed.cu:173-185
-                float yv = re8y[maxk], xv = re8x[maxk];
-                float absx = fabsf(xv), absy = fabsf(yv);
-                float mn = absx < absy ? absx : absy, mx = absx < absy ? absy : absx;
-                float a = mx > 0.f ? mn / mx : 0.f;
-                float sq = a * a;
-                float r = fmaf(fmaf(fmaf(-0.0464964749f, sq, 0.15931422f), sq, -0.327622764f), sq * a, a);
-                r = (absy > absx ? HAK_HPI_F - r : r);
-                r = (xv < 0 ? (float)(HAK_PI_D - r) : r);
-                r = (yv < 0 ? -r : r);
+                const float r = dsc_fast_atan2(re8y[maxk], re8x[maxk]);
                 pt->angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);  // akazed.cu:1734
             }
             hak_lds_barrier();
@@ -152,17 +196,19 @@ __global__ __launch_bounds__(64) void k_orient(const float* __restrict__ base, l
     }
 }
 
-__global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base, long stride, HakLayout L,
+template <typename V>
+__global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, long stride, HakLayout L,
                                                  const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
                                                  hak_point* points, int max_pts, int patsize, int upright, int desc)
 {
-    __shared__ float acc[ACC_ROWS * ACC_LD];    // [cell*3+ch][thread], one round at a time
-    __shared__ float vals[90];
+    constexpr bool FAST = std::is_same<V, int>::value;
+    __shared__ V acc[ACC_ROWS * ACC_LD];        // [cell*3+ch][thread], one round at a time
+    __shared__ V vals[90];
 
     const int img = blockIdx.y;
     const int lane = threadIdx.x;
     const int npts = state[img].num_pts;
-    const float* arena = base + (long)img * stride;
+    const V* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
     if (!desc) return;
 
@@ -182,16 +228,20 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         const int layer = pt->octave;
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
-        const float* imd = arena + L.lt(o, s);
-        const float* dxd = arena + L.lx(o, s);
-        const float* dyd = arena + L.ly(o, s);
+        const V* imd = arena + L.lt(o, s);
+        const V* dxd = arena + L.lx(o, s);
+        const V* dyd = arena + L.ly(o, s);
         float angle = 0.f;
 
         if (!upright) angle = pt->angle;                            // written by k_orient
 
         // ------------------------------------------------------------- MLDB
         // phase 1: positions + all gathers of this lane's samples (i = lane, lane+64, ...)
-        float vim[MAX_SMP], vrx[MAX_SMP], vry[MAX_SMP];
+        // rotated derivatives: float path -dx*si + dy*co (akazed.cu:1931); FAST path the same in float from the 16.16 integers,
+        // truncated back to int (akazed.cu:3777-3778)
+        auto rot_x = [](V dx, V dy, float si, float co) -> V { return (V)(-dx * si + dy * co); };
+        auto rot_y = [](V dx, V dy, float si, float co) -> V { return (V)(dx * co + dy * si); };
+        V vim[MAX_SMP], vrx[MAX_SMP], vry[MAX_SMP];
         int cx[MAX_SMP], cy[MAX_SMP];           // sample grid coordinates; cx < 0 marks "no sample"
         {
             const float iratio = 1.f / (1 << o);
@@ -200,7 +250,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
             const float yf = pty * iratio;
             float si, co;
             hak_sincosf(angle, &si, &co);
-            float gdx[MAX_SMP], gdy[MAX_SMP];
+            V gdx[MAX_SMP], gdy[MAX_SMP];
 #pragma unroll
             for (int n = 0; n < MAX_SMP; n++) {
                 const int i = lane + 64 * n;
@@ -216,14 +266,14 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
                 const long pos = (long)yp * oc.p + xp;
-                vim[n] = ok ? imd[pos] : 0.f;
-                gdx[n] = ok ? dxd[pos] : 0.f;
-                gdy[n] = ok ? dyd[pos] : 0.f;
+                vim[n] = ok ? imd[pos] : V(0);
+                gdx[n] = ok ? dxd[pos] : V(0);
+                gdy[n] = ok ? dyd[pos] : V(0);
             }
 #pragma unroll
             for (int n = 0; n < MAX_SMP; n++) {
-                vrx[n] = -gdx[n] * si + gdy[n] * co;
-                vry[n] = gdx[n] * co + gdy[n] * si;
+                vrx[n] = rot_x(gdx[n], gdy[n], si, co);
+                vry[n] = rot_y(gdx[n], gdy[n], si, co);
             }
         }
         // phase 2: the 87 accumulator rows (2x2 cells: rows 0..11, 3x3: 12..38, 4x4: 39..86; three rows -- value, dx', dy' --
@@ -231,17 +281,17 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         // Cell bases and ACC_ROWS are multiples of 3: a cell never straddles two rounds.  Samples beyond MAX_SMP per
         // lane (descriptor_pattern_size > 10) are re-gathered by the tail loop of every round.
         for (int r0 = 0; r0 < 87; r0 += ACC_ROWS) {
-            for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = 0.f;
+            for (int i = lane; i < ACC_ROWS * ACC_LD; i += 64) acc[i] = V(0);
             hak_lds_barrier();
-            auto add = [&](int row, float im, float rx, float ry) {
+            auto add = [&](int row, V im, V rx, V ry) {
                 const int rr = row - r0;
                 if (rr >= 0 && rr < ACC_ROWS) {
-                    acc[rr * ACC_LD + lane] += im;
-                    acc[(rr + 1) * ACC_LD + lane] += rx;
-                    acc[(rr + 2) * ACC_LD + lane] += ry;
+                    acc[rr * ACC_LD + lane] = dsc_add(acc[rr * ACC_LD + lane], im);
+                    acc[(rr + 1) * ACC_LD + lane] = dsc_add(acc[(rr + 1) * ACC_LD + lane], rx);
+                    acc[(rr + 2) * ACC_LD + lane] = dsc_add(acc[(rr + 2) * ACC_LD + lane], ry);
                 }
             };
-            auto scatter = [&](int x, int y, float im, float rx, float ry) {
+            auto scatter = [&](int x, int y, V im, V rx, V ry) {
                 const int m = max(x, y);
                 if (m < 2 * size2) add(3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)), im, rx, ry);
                 if (m < 3 * size3) {
@@ -270,8 +320,8 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
                 const long pos = (long)yp * oc.p + xp;
-                const float im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-                scatter(x, y, im, -dx * si + dy * co, dx * co + dy * si);
+                const V im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+                scatter(x, y, im, rot_x(dx, dy, si, co), rot_y(dx, dy, si, co));
             }
             hak_lds_barrier();
             reduce_rows(acc, vals, min(ACC_ROWS, 87 - r0), r0, lane);
@@ -291,6 +341,7 @@ __global__ __launch_bounds__(64) void k_describe(const float* __restrict__ base,
         if (lane == 0) pt->angle = angle;
         hak_lds_barrier();
     }
+    (void)FAST;
 }
 
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
@@ -298,6 +349,17 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 {
     int gx = max_pts < 4096 ? max_pts : 4096;
     dim3 grid(gx, b.nimg);
-    if (desc && !upright) k_orient<<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts);
-    k_describe<<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
+    if (desc && !upright) k_orient<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, 1);
+    if (desc) k_describe<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
+}
+
+// FAST path: k_orient<int> always runs (it carries the sub-pixel refinement of akazed.cu:3600)
+void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
+                          int patsize, int upright, int desc)
+{
+    int gx = max_pts < 4096 ? max_pts : 4096;
+    dim3 grid(gx, b.nimg);
+    const int* base = reinterpret_cast<const int*>(b.base);
+    k_orient<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, desc && !upright);
+    if (desc) k_describe<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }

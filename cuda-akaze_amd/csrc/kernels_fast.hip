@@ -460,151 +460,4 @@ void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, 
                                      tab, octave, s, threshold);
 }
 
-// ---- refine (akazed.cu:3600) + orientation (3649) + MLDB (3723), one wave per keypoint
-__device__ __forceinline__ float fast_atan2(float y, float x)                                     // akazed.cu:173-185 (0/0 -> 0)
-{
-    const float absx = fabsf(x), absy = fabsf(y);
-    const float mn = absx < absy ? absx : absy, mx = absx < absy ? absy : absx;
-    const float a = mx > 0.f ? mn / mx : 0.f;
-    const float s = a * a;
-    float r = fmaf(fmaf(fmaf(-0.0464964749f, s, 0.15931422f), s, -0.327622764f), s * a, a);
-    r = (absy > absx ? HAK_HPI_F - r : r);
-    r = (x < 0 ? (float)(HAK_PI_D - r) : r);
-    r = (y < 0 ? -r : r);
-    return r;
-}
-
-__global__ __launch_bounds__(64) void kf_describe(const int* __restrict__ base, long stride, HakLayout L,
-                                                  const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
-                                                  hak_point* points, int max_pts, int patsize, int upright, int desc)
-{
-    __shared__ int acc[90];
-    __shared__ float sdx[128], sdy[128];
-    __shared__ int sbin[128];
-    __shared__ float resx[42], resy[42], re8x[42], re8y[42];
-    __shared__ float s_angle;
-    const int img = blockIdx.y, lane = threadIdx.x;
-    const int npts = state[img].num_pts;
-    const int* arena = base + (long)img * stride;
-    hak_point* pts = points + (long)img * max_pts;
-    const int size2 = patsize, size3 = (int)ceilf(2.0f * patsize / 3.0f), size4 = (int)ceilf(0.5f * patsize);
-    const int winsize = max(3 * size3, 4 * size4);
-    for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
-        hak_point* pt = pts + pi;
-        const int layer = pt->octave, o = layer / L.ms, s = layer - o * L.ms;
-        const HakOct oc = L.oct[o];
-        const int* imd = arena + L.lt(o, s);
-        const int* detd = arena + L.det(o, s);
-        const int* dxd = arena + L.lx(o, s);
-        const int* dyd = arena + L.ly(o, s);
-        // refine (lane 0), result broadcast through LDS
-        __shared__ float s_xy[2];
-        if (lane == 0) {
-            float px = pt->x, py = pt->y;
-            const int y = (int)py >> o, x = (int)px >> o, p = oc.p;
-            const long idx = (long)y * p + x;
-            const int v2 = detd[idx] + detd[idx];
-            const int dx = (detd[idx + 1] - detd[idx - 1]) >> 1, dy = (detd[idx + p] - detd[idx - p]) >> 1;
-            const int dxx = detd[idx + 1] + detd[idx - 1] - v2, dyy = detd[idx + p] + detd[idx - p] - v2;
-            const int dxy = (detd[idx + p + 1] + detd[idx - p - 1] - detd[idx - p + 1] - detd[idx + p - 1]) >> 2;
-            const int dd = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
-            const float idd = dd != 0 ? (1.f / dd) : 0.f;
-            const float dst0 = idd * wadd(wmul(dxy, dy), -wmul(dyy, dx));
-            const float dst1 = idd * wadd(wmul(dxy, dx), -wmul(dxx, dy));
-            if (!(dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f)) {
-                const int ratio = 1 << o;
-                py = ratio * (y + dst1);
-                px = ratio * (x + dst0);
-                pt->x = px;
-                pt->y = py;
-            }
-            s_xy[0] = px; s_xy[1] = py;
-        }
-        if (lane < 90) acc[lane] = 0;
-        if (lane + 64 < 90) acc[lane + 64] = 0;
-        __syncthreads();
-        const float ptx = s_xy[0], pty = s_xy[1], ptsize = pt->size;
-        float angle = 0.f;
-        if (desc && !upright) {
-            const int step = (int)(ptsize + 0.5f);
-            const int x = (int)(ptx + 0.5f) >> o, y = (int)(pty + 0.5f) >> o;
-            int nvalid = 0;
-            for (int t0 = 0; t0 < 208; t0 += 64) {
-                const int tix = t0 + lane, i = (tix & 15) - 6, j = (tix >> 4) - 6, r2 = i * i + j * j;
-                const bool ok = tix < 208 && r2 < 36;
-                const unsigned long long m = __ballot(ok);
-                if (ok) {
-                    const int slot = nvalid + __popcll(m & ((1ull << lane) - 1ull));
-                    const long pos = (long)min(max(y + step * j, 0), oc.h - 1) * oc.p + min(max(x + step * i, 0), oc.w - 1);
-                    const float gw = tab->orient_w[r2];
-                    const float dx = gw * dxd[pos], dy = gw * dyd[pos];
-                    int a = (int)(fast_atan2(dy, dx) * (21 / HAK_PI_D)) + 21;                     // akazed.cu:3685-3686
-                    a = a > 41 ? 41 : (a < 0 ? 0 : a);
-                    sdx[slot] = dx; sdy[slot] = dy; sbin[slot] = a;
-                }
-                nvalid += __popcll(m);
-            }
-            __syncthreads();
-            if (lane < 42) {
-                float rx = 0.f, ry = 0.f;
-                for (int n = 0; n < nvalid; n++)
-                    if (sbin[n] == lane) { rx += sdx[n]; ry += sdy[n]; }
-                resx[lane] = rx; resy[lane] = ry;
-            }
-            __syncthreads();
-            if (lane < 42) {
-                float ax = resx[lane], ay = resy[lane];
-                for (int k = lane + 1; k < lane + 7; k++) { ax += resx[k < 42 ? k : k - 42]; ay += resy[k < 42 ? k : k - 42]; }
-                re8x[lane] = ax; re8y[lane] = ay;
-            }
-            __syncthreads();
-            if (lane == 0) {
-                float maxr = 0.0f; int maxk = 0;
-                for (int k = 0; k < 42; k++) { const float r = re8x[k] * re8x[k] + re8y[k] * re8y[k]; if (r > maxr) { maxr = r; maxk = k; } }
-                const float r = fast_atan2(re8y[maxk], re8x[maxk]);
-                s_angle = (r < 0.0f ? (float)(r + 2.0f * HAK_PI_D) : r);
-            }
-            __syncthreads();
-            angle = s_angle;
-        }
-        if (desc) {
-            const float iratio = 1.f / (1 << o);
-            const int scale = (int)(ptsize + 0.5f);
-            const float xf = ptx * iratio, yf = pty * iratio;
-            float si, co;
-            hak_sincosf(angle, &si, &co);
-            for (int i = lane; i < winsize * winsize; i += 64) {
-                const int y = i / winsize, x = i - winsize * y, m = max(x, y), l = x - size2, k = y - size2;
-                const int xp = min(max((int)(xf + scale * (k * co - l * si) + 0.5f), 0), oc.w - 1);
-                const int yp = min(max((int)(yf + scale * (k * si + l * co) + 0.5f), 0), oc.h - 1);
-                const long pos = (long)yp * oc.p + xp;
-                const int im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-                const int rx = (int)(-dx * si + dy * co), ry = (int)(dx * co + dy * si);          // akazed.cu:3777-3778
-                if (m < 2 * size2) { const int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry); }
-                if (m < 3 * size3) {
-                    const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
-                    const int c = 3 * (4 + y3 * 3 + x3); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry);
-                }
-                if (m < 4 * size4) {
-                    const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3)), y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
-                    const int c = 3 * (13 + y4 * 4 + x4); atomicAdd(&acc[c], im); atomicAdd(&acc[c + 1], rx); atomicAdd(&acc[c + 2], ry);
-                }
-            }
-            __syncthreads();
-            if (lane < HAK_FLEN) {
-                unsigned int d = 0;
-                const int nb = lane == 60 ? 6 : 8;
-                for (int i = 0; i < nb; ++i) d |= (acc[tab->comp1[lane * 8 + i]] > acc[tab->comp2[lane * 8 + i]] ? 1u : 0u) << i;
-                pt->features[lane] = (unsigned char)d;
-            }
-            if (lane == 0) pt->angle = angle;
-        }
-        __syncthreads();
-    }
-}
-void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
-                          int patsize, int upright, int desc)
-{
-    dim3 grid(max_pts < 4096 ? max_pts : 4096, b.nimg);
-    kf_describe<<<grid, 64, 0, st>>>(reinterpret_cast<const int*>(b.base), b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
-}
+// refine (akazed.cu:3600) + orientation (3649) + MLDB (3723): k_orient<int> / k_describe<int> in kernels_describe.hip
