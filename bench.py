@@ -73,7 +73,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=64, help="pairs per GPU per step (batch)")
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per step (batch); halved until the arenas fit the free HBM")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--octaves", type=int, default=4)
@@ -113,8 +113,13 @@ def main():
     w, h = args.width, args.height
     p = ah.iAlignUp(w, 128)
     B = args.pairs
-    nimg = 2 * B
     max_pts = 10000
+    # arena ~ 19 float planes per octave pyramid + key map + candidate list ~ 31 B/px x 4/3 per image and context
+    # (250 MB at 1080p): 128 pairs x 2 contexts = 127 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
+    free_b = torch.cuda.mem_get_info()[0]
+    while B > 16 and 2 * B * (w * h * 125 + 2 * max_pts * 104) * (1 if args.no_pipeline else max(1, args.pipeline)) > 0.8 * free_b:
+        B //= 2
+    nimg = 2 * B
 
     # ---- synthetic inputs, resident in HBM (2 distinct seeded pairs per rank, cycled over the batch)
     u8_pairs = [synth.pair(w, h, 1 + 2 * rank + i) for i in range(2)]

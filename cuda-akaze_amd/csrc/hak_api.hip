@@ -298,6 +298,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
     if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
     { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
+    { const char* e = getenv("HAK_BASE_STREAM"); hak_base_stream_enabled = e ? atoi(e) : 1; }
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);

@@ -226,6 +226,12 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
+// register-streaming pass A of the octave-0 prologue (kernels_base_stream.hip); false: not covered / does not pay
+extern int hak_base_stream_enabled;
+bool hak_launch_base_stream(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad, long stride, int w, int h,
+                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state);
+bool hakf_launch_base_stream(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad, long stride, int w,
+                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state);
 bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad_scratch, long stride,
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
                            HakImgState* state, float per, int noct);

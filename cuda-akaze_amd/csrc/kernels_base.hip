@@ -280,6 +280,9 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
     const unsigned grid = hak_xcd_grid(ntx, nby, nimg);
+    if (hak_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, taps1, taps_base, R, state)) {
+        // pass A done by the streaming kernel
+    } else
     switch (R) {
     case 2: k_base_a<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
     case 3: k_base_a<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;

@@ -1,0 +1,303 @@
+// kernels_base_stream.hip -- octave-0 prologue, pass A, as a register-streaming kernel (both element types).
+//
+//   hLowPass(img -> Lt(0,0), var soffset^2)       akaze.cpp:325-327 / 589-596, akazed.cu:2336, 204 (gConv2d<R>)
+//   hLowPass(img -> smooth, var 1, ksz 5)         akazed.cu:2336 (gConv2d<2>)
+//   hScharrContrast: max |Scharr(smooth)|         akazed.cu:2410, 644 (float) / 3208 (fastakaze)
+//
+// Same outputs as the LDS tile kernels k_base_a<R> (kernels_base.hip) and kf_base<R> (kernels_fast.hip): Lt(0,0), the
+// gradient magnitude of the sigma=1 image as a plane for the histogram pass, and its maximum.  Here a wave owns a 248-px
+// strip (float4 / 4 bytes per lane) and streams down its row segment like k_fed_sf: when image row t arrives,
+//     row passes of both Gaussians on row t (x neighbours -4..+4 are exactly the two neighbour lanes: 8 DPP shifts),
+//     Lt row t-R     = column pass over the base ring (2R+1 rows),
+//     smooth row t-2 = column pass over the sigma=1 ring (5 rows), kept in a 3-row ring with its two x-neighbour columns,
+//     gradient row t-3 = Scharr magnitude of smooth rows t-4 .. t-2.
+// No LDS, no barriers; 4 B/px read, 8 B/px written.  Reflect-101 is applied to the INPUT, as the tile kernels do
+// (rows: the row index is reflected; columns: the lane just outside the image loads the mirrored pixels), and every
+// stage then indexes plainly.  w % 4 == 0, R <= 4 (a deeper halo than one lane needs the tile kernel).
+#include "fed_common.h"
+
+int hak_base_stream_enabled = 1;        // HAK_BASE_STREAM: 0 never, 1 by the size rule, 2 always where the kernel applies
+
+namespace {
+
+constexpr int BS_HX = 4;                                   // one lane of halo on either side
+constexpr int BS_XV = 256 - 2 * BS_HX;                      // 248 output columns per wave
+constexpr int BS_PD = 3;                                    // rows in flight ahead of the one being consumed
+constexpr int BS_RING = 9;                                  // 2R+1 for R = 4; the loop is unrolled by it
+
+template <typename V> struct BsT;
+template <> struct BsT<float> { using In = float; using Q = float4; using V4 = float4; };
+template <> struct BsT<int> { using In = unsigned char; using Q = unsigned; using V4 = int4; };
+
+template <typename V> struct BsmTaps { SfTaps<V> a; V b[5]; };
+
+// what one lane loads for one row: its aligned 4 pixels, and -- only in the lane just outside the image of an edge
+// strip -- the four mirrored pixels.  Kept raw until the row is consumed so that the prefetch never waits.
+template <typename V> struct BsRaw { typename BsT<V>::Q q; V e0, e1, e2, e3; };
+
+template <typename V, bool XE>
+__device__ __forceinline__ BsRaw<V> bsm_load(const typename BsT<V>::In* __restrict__ s, int row, int sp, int xl, bool edge, int c0, int c1,
+                                             int c2, int c3)
+{
+    using In = typename BsT<V>::In;
+    BsRaw<V> r;
+    const In* q = s + (long)row * sp;
+    r.q = *reinterpret_cast<const typename BsT<V>::Q*>(q + xl);
+    r.e0 = r.e1 = r.e2 = r.e3 = 0;
+    if (XE && edge) { r.e0 = (V)q[c0]; r.e1 = (V)q[c1]; r.e2 = (V)q[c2]; r.e3 = (V)q[c3]; }
+    return r;
+}
+template <bool XE>
+__device__ __forceinline__ float4 bsm_unpack(const BsRaw<float>& r, bool edge)
+{
+    float4 v = r.q;
+    if (XE) { v.x = edge ? r.e0 : v.x; v.y = edge ? r.e1 : v.y; v.z = edge ? r.e2 : v.z; v.w = edge ? r.e3 : v.w; }
+    return v;
+}
+template <bool XE>
+__device__ __forceinline__ int4 bsm_unpack(const BsRaw<int>& r, bool edge)
+{
+    int4 v = make_int4((int)(r.q & 255u), (int)((r.q >> 8) & 255u), (int)((r.q >> 16) & 255u), (int)(r.q >> 24));
+    if (XE) { v.x = edge ? r.e0 : v.x; v.y = edge ? r.e1 : v.y; v.z = edge ? r.e2 : v.z; v.w = edge ? r.e3 : v.w; }
+    return v;
+}
+
+// base Gaussian: c*b0, then += b[k] * (value at -k + value at +k), k = 1..R (akazed.cu:227-239 / 283-288); the integer
+// version ends in >> 16 (akazed.cu:2922-2985)
+template <int R>
+__device__ __forceinline__ float bsm_conv(const float c, const float (&m)[4], const float (&q)[4], const float (&b)[5])
+{
+    float ws = c * b[0];
+#pragma unroll
+    for (int k = 1; k <= R; k++) ws += b[k] * (m[k - 1] + q[k - 1]);
+    return ws;
+}
+template <int R>
+__device__ __forceinline__ int bsm_conv(const int c, const int (&m)[4], const int (&q)[4], const int (&b)[5])
+{
+    unsigned ws = (unsigned)b[0] * (unsigned)c;
+#pragma unroll
+    for (int k = 1; k <= R; k++) ws += (unsigned)b[k] * (unsigned)(m[k - 1] + q[k - 1]);
+    return (int)ws >> 16;
+}
+
+// Scharr magnitude of the sigma=1 image (float: akazed.cu:664-666, un-normalised; int: akazed.cu:3208-3232)
+__device__ __forceinline__ float bsm_mag(float ul, float uc, float ur, float cl, float cr, float ll, float lc, float lr)
+{
+    const float dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
+    const float dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
+    return sqrtf(dx * dx + dy * dy);
+}
+__device__ __forceinline__ int bsm_mag(int ul, int uc, int ur, int cl, int cr, int ll, int lc, int lr)
+{
+    const int dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
+    const int dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
+    return (int)(sqrtf((float)(int)((unsigned)dx * (unsigned)dx + (unsigned)dy * (unsigned)dy)) + 0.5f);
+}
+__device__ __forceinline__ float bsm_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ int bsm_max(int a, int b) { return max(a, b); }
+
+template <typename V>
+struct BsmState {
+    using V4 = typename BsT<V>::V4;
+    V4 Hb[BS_RING];                     // base row pass, rows t-8 .. t          slot = iteration mod 9
+    V4 H1[BS_RING];                     // sigma=1 row pass (5 rows live)
+    V4 Sm[3];                           // smooth rows t-4 .. t-2                slot = iteration mod 3
+    V SmL[3], SmR[3];                   // smooth at columns x0-1 and x0+4 of those rows
+    BsRaw<V> Lq[BS_PD];                 // prefetch ring
+    V tmax;
+};
+
+template <typename V, int R, int U, bool XE>
+__device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT,
+                                         V* __restrict__ GR, const int sp, const int p, const int xl, const int x0, const int h,
+                                         const int ybeg, const int yend, const bool owns, const bool edge, const int c0, const int c1,
+                                         const int c2, const int c3, const BsmTaps<V>& tp)
+{
+    using V4 = typename BsT<V>::V4;
+    // ---- image row t arrives (virtual rows outside the image are their mirror rows); request row t + PD
+    const BsRaw<V> raw = S.Lq[pmod(U, BS_PD)];
+    S.Lq[pmod(U, BS_PD)] = bsm_load<V, XE>(s, hak_refl(min(t + BS_PD, h + 3), h), sp, xl, edge, c0, c1, c2, c3);
+    const V4 c = bsm_unpack<XE>(raw, edge);
+    // ---- both row passes: the window is columns x0-4 .. x0+7
+    {
+        const V win[12] = {wave_shr1(c.x), wave_shr1(c.y), wave_shr1(c.z), wave_shr1(c.w), c.x, c.y, c.z, c.w,
+                           wave_shl1(c.x), wave_shl1(c.y), wave_shl1(c.z), wave_shl1(c.w)};
+        V hb[4], h1[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const V m[4] = {win[3 + j], win[2 + j], win[1 + j], win[j]};
+            const V q[4] = {win[5 + j], win[6 + j], win[7 + j], win[8 + j]};
+            hb[j] = bsm_conv<R>(win[4 + j], m, q, tp.b);
+            h1[j] = sf_conv(win[4 + j], win[3 + j], win[5 + j], win[2 + j], win[6 + j], tp.a);
+        }
+        S.Hb[pmod(U, BS_RING)] = mk4(hb[0], hb[1], hb[2], hb[3]);
+        S.H1[pmod(U, BS_RING)] = mk4(h1[0], h1[1], h1[2], h1[3]);
+    }
+    // ---- base column pass -> Lt row t - R
+    {
+        const int y = t - R;
+        const V4 cc = S.Hb[pmod(U - R, BS_RING)];
+        V4 um[4], dn[4];
+#pragma unroll
+        for (int k = 1; k <= 4; k++) {
+            um[k - 1] = S.Hb[pmod(U - R - (k <= R ? k : 0), BS_RING)];
+            dn[k - 1] = S.Hb[pmod(U - R + (k <= R ? k : 0), BS_RING)];
+        }
+        V4 o;
+        {
+            const V m[4] = {um[0].x, um[1].x, um[2].x, um[3].x}, q[4] = {dn[0].x, dn[1].x, dn[2].x, dn[3].x};
+            o.x = bsm_conv<R>(cc.x, m, q, tp.b);
+        }
+        {
+            const V m[4] = {um[0].y, um[1].y, um[2].y, um[3].y}, q[4] = {dn[0].y, dn[1].y, dn[2].y, dn[3].y};
+            o.y = bsm_conv<R>(cc.y, m, q, tp.b);
+        }
+        {
+            const V m[4] = {um[0].z, um[1].z, um[2].z, um[3].z}, q[4] = {dn[0].z, dn[1].z, dn[2].z, dn[3].z};
+            o.z = bsm_conv<R>(cc.z, m, q, tp.b);
+        }
+        {
+            const V m[4] = {um[0].w, um[1].w, um[2].w, um[3].w}, q[4] = {dn[0].w, dn[1].w, dn[2].w, dn[3].w};
+            o.w = bsm_conv<R>(cc.w, m, q, tp.b);
+        }
+        if (y >= ybeg && y < yend && owns) *reinterpret_cast<V4*>(LT + (long)y * p + x0) = o;
+    }
+    // ---- sigma=1 column pass -> smooth row t - 2 (never written)
+    {
+        const V4 cc = S.H1[pmod(U - 2, BS_RING)], u1 = S.H1[pmod(U - 3, BS_RING)], d1 = S.H1[pmod(U - 1, BS_RING)];
+        const V4 u2 = S.H1[pmod(U - 4, BS_RING)], d2 = S.H1[pmod(U, BS_RING)];
+        V4 sm;
+        sm.x = sf_conv(cc.x, u1.x, d1.x, u2.x, d2.x, tp.a);
+        sm.y = sf_conv(cc.y, u1.y, d1.y, u2.y, d2.y, tp.a);
+        sm.z = sf_conv(cc.z, u1.z, d1.z, u2.z, d2.z, tp.a);
+        sm.w = sf_conv(cc.w, u1.w, d1.w, u2.w, d2.w, tp.a);
+        S.Sm[pmod(U, 3)] = sm;
+        S.SmL[pmod(U, 3)] = wave_shr1(sm.w);
+        S.SmR[pmod(U, 3)] = wave_shl1(sm.x);
+    }
+    // ---- gradient magnitude row t - 3
+    {
+        const int b = t - 3;
+        const V4 su = S.Sm[pmod(U - 2, 3)], sc = S.Sm[pmod(U - 1, 3)], sd = S.Sm[pmod(U, 3)];
+        const V uL = S.SmL[pmod(U - 2, 3)], uR = S.SmR[pmod(U - 2, 3)];
+        const V cL = S.SmL[pmod(U - 1, 3)], cR = S.SmR[pmod(U - 1, 3)];
+        const V dL = S.SmL[pmod(U, 3)], dR = S.SmR[pmod(U, 3)];
+        V4 g;
+        g.x = bsm_mag(uL, su.x, su.y, cL, sc.y, dL, sd.x, sd.y);
+        g.y = bsm_mag(su.x, su.y, su.z, sc.x, sc.z, sd.x, sd.y, sd.z);
+        g.z = bsm_mag(su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w);
+        g.w = bsm_mag(su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR);
+        if (b >= ybeg && b < yend && owns) {
+            *reinterpret_cast<V4*>(GR + (long)b * p + x0) = g;
+            S.tmax = bsm_max(S.tmax, bsm_max(bsm_max(g.x, g.y), bsm_max(g.z, g.w)));
+        }
+    }
+}
+
+template <typename V, int R, bool XE>
+__device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT, V* __restrict__ GR, int sp, int p,
+                                       int w, int h, int x0, int ybeg, int yend, bool owns, const BsmTaps<V>& tp)
+{
+    using V4 = typename BsT<V>::V4;
+    constexpr int RR = R < 3 ? 3 : R;                       // rows of context above and below the segment
+    // aligned 4-pixel load of every lane, kept inside the row; the lane just outside the image loads mirrored pixels instead
+    const int xl = min(max(x0, 0), w - 4);
+    const bool edge = XE && (x0 == -4 || x0 == w);
+    const int c0 = hak_refl(x0, w), c1 = hak_refl(x0 + 1, w), c2 = hak_refl(x0 + 2, w), c3 = hak_refl(x0 + 3, w);
+    const int t0 = ybeg - RR;
+    const int tend = yend - 1 + RR;
+    BsmState<V> S;
+    const V z = 0;
+    const V4 z4 = mk4(z, z, z, z);
+#pragma unroll
+    for (int i = 0; i < BS_RING; i++) { S.Hb[i] = z4; S.H1[i] = z4; }
+#pragma unroll
+    for (int i = 0; i < 3; i++) { S.Sm[i] = z4; S.SmL[i] = z; S.SmR[i] = z; }
+    S.tmax = z;
+#pragma unroll
+    for (int i = 0; i < BS_PD; i++) S.Lq[i] = bsm_load<V, XE>(s, hak_refl(min(t0 + i, h + 3), h), sp, xl, edge, c0, c1, c2, c3);
+    for (int tb = t0; tb <= tend; tb += BS_RING) {
+        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+    }
+    return S.tmax;
+}
+
+// grid: hak_xcd_grid(strips, groups of four row segments, images); a block's four waves take four consecutive segments
+template <typename V, int R>
+__global__ __launch_bounds__(256) void k_base_stream(const typename BsT<V>::In* __restrict__ img, long img_stride, int sp,
+                                                     V* __restrict__ lt, V* __restrict__ grad, long stride, int w, int h, int p,
+                                                     BsmTaps<V> tp, HakImgState* state, int ry, int nbx, int nby, int nimg)
+{
+    int bx, by, im;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
+    const typename BsT<V>::In* s = img + (long)im * img_stride;
+    V* LT = lt + (long)im * stride;
+    V* GR = grad + (long)im * stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = bx * BS_XV - BS_HX + 4 * lane;           // first pixel of this lane (may lie outside the image)
+    const int ybeg = (by * 4 + wv) * ry;
+    if (ybeg >= h) return;                                  // wave-uniform
+    const int yend = min(ybeg + ry, h);
+    const bool owns = lane >= 1 && lane < 63 && x0 < w;
+    V m;
+    if (bx == 0 || (bx + 1) * BS_XV + BS_HX >= w) m = bsm_strip<V, R, true>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp);
+    else m = bsm_strip<V, R, false>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp);
+    for (int off = 32; off > 0; off >>= 1) m = bsm_max(m, __shfl_xor(m, off));
+    if (lane == 0) {
+        if constexpr (std::is_same<V, float>::value) {
+            if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // D2: the intended reduction
+        } else {
+            if (m > 1) atomicMax(&state[im].ihmax, m);
+        }
+    }
+}
+
+template <typename V>
+bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img_stride, int sp, V* lt, V* grad, long stride, int w, int h,
+                        int p, int nimg, const V* taps1, const V* taps_base, int R, HakImgState* state)
+{
+    using In = typename BsT<V>::In;
+    constexpr long LA = 4;                                  // elements per aligned lane load: 4 floats / 4 bytes
+    if (!grad || R < 2 || R > 4 || (w & 3) || w < 16 || h < 16) return false;
+    if ((sp % LA) || (img_stride % LA) || (reinterpret_cast<uintptr_t>(img) % (LA * sizeof(In)))) return false;
+    if (!hak_stream_pays(hak_base_stream_enabled, w, h, nimg)) return false;
+    BsmTaps<V> tp;
+    tp.a = SfTaps<V>{taps1[0], taps1[1], taps1[2]};
+    for (int i = 0; i < 5; i++) tp.b[i] = i <= R ? taps_base[i] : V(0);
+    const int gx = (w + BS_XV - 1) / BS_XV;
+    // rows per wave: ~128-row segments of equal height amortise the 2R warm-up rows; shrink while the grid cannot fill the chip
+    int nseg = (h + 127) / 128;
+    while ((long)gx * nseg * nimg < 4096 && (h + nseg - 1) / nseg > 16) nseg *= 2;
+    const int ry = (h + nseg - 1) / nseg;
+    const int gy = ((h + ry - 1) / ry + 3) / 4;
+    const unsigned grid = hak_xcd_grid(gx, gy, nimg);
+    switch (R) {
+    case 2: k_base_stream<V, 2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    case 3: k_base_stream<V, 3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    default: k_base_stream<V, 4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    }
+    return true;
+}
+
+} // namespace
+
+bool hak_launch_base_stream(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad, long stride, int w, int h,
+                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state)
+{
+    return launch_base_stream<float>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, taps1, taps_base, R, state);
+}
+bool hakf_launch_base_stream(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad, long stride, int w,
+                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state)
+{
+    return launch_base_stream<int>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, itaps1, itaps_base, R, state);
+}

@@ -300,6 +300,9 @@ bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_s
     for (int i = 0; i < 8; i++) { t1.k[i] = i <= 2 ? itaps1[i] : 0; tb.k[i] = i <= R ? itaps_base[i] : 0; }
     const int nbx = (w + FB_TX - 1) / FB_TX, nby = (h + FB_TY - 1) / FB_TY;
     const unsigned grid = hak_xcd_grid(nbx, nby, nimg);
+    if (hakf_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, itaps1, itaps_base, R, state)) {
+        // pass A done by the streaming kernel
+    } else
     switch (R) {
     case 2: kf_base<2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;
     case 3: kf_base<3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t1, tb, state, nbx, nby, nimg); break;

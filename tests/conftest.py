@@ -12,11 +12,12 @@ for sub in ("cuda-akaze_amd", "oracle", ""):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
-# The library picks the register-streaming kernels (k_hessian_stream, k_fed_sf) only when a launch is large enough to fill
+# The library picks the register-streaming kernels (k_hessian_stream, k_fed_sf, k_base_stream) only when a launch is large enough to fill
 # the chip; the parity tests run small images and batches, so they force those kernels on wherever they apply (mode 2).  The
 # tile kernels and the size rule itself are covered by test_kernel_alternatives_are_bit_identical and by the odd-size cases.
 os.environ.setdefault("HAK_HESS_STREAM", "2")
 os.environ.setdefault("HAK_FUSE_SF", "2")
+os.environ.setdefault("HAK_BASE_STREAM", "2")
 
 
 def pytest_configure(config):

@@ -214,15 +214,19 @@ def test_knn2_with_context_scratch_and_repeat(ah, okz, torch, synth):
 
 @pytest.mark.parametrize("env", [{"HAK_FUSE_SF": "0"}, {"HAK_HESS_STREAM": "0"}, {"HAK_FED_MAX_FUSE": "1"}, {"HAK_GRAPH": "0", "HAK_SERIAL": "1"},
                                  {"HAK_FUSE_SF": "1", "HAK_HESS_STREAM": "1"},          # the default size rule
-                                 {"HAK_FUSE_HEAD": "0"},
-                                 {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_FED_MAX_FUSE": "2"}],
+                                 {"HAK_FUSE_HEAD": "0"}, {"HAK_BASE_STREAM": "0"}, {"HAK_BASE_STREAM": "1"},
+                                 {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0", "HAK_FED_MAX_FUSE": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
     """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
     persistent planes: the fused / streaming kernels and the tile kernels they replace are interchangeable"""
     w, h, mp = 960, 540, 4000
     p = ah.iAlignUp(w, 128)
-    img = torch.from_numpy(synth.to_float(synth.scene(w, h, 21), p)).cuda()
+    u8 = synth.scene(w, h, 21)
+    img = torch.from_numpy(synth.to_float(u8, p)).cuda()
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    img8 = torch.from_numpy(pad).cuda()
 
     def run():
         det = ah.Akazer()
@@ -232,6 +236,10 @@ def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
         det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
         pts = data.h_data[:data.num_pts].copy().tobytes()
         planes = [det.plane(kind, o, s).tobytes() for o in range(len(det.geometry())) for s in range(4) for kind in (0, 1, 2, 3)]
+        det.fastDetectAndCompute(img8.data_ptr(), data, (w, h, p), True)          # the integer path shares the knobs
+        assert data.num_pts > 100
+        pts += data.h_data[:data.num_pts].copy().tobytes()
+        planes += [det.plane(kind, o, s).tobytes() for o in range(len(det.geometry())) for s in range(4) for kind in (0, 1, 2, 3)]
         ah.freeAkazeData(data)
         det.close()
         return pts, planes

@@ -48,7 +48,7 @@ def main():
         fed_launches=launches,
         fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
         fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows,
-        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "64")))
+        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "128")))
     json.dump(summary, open(out + ".json", "w"), indent=1)
     with open(out + ".csv", "w") as f:
         f.write("kernel,dispatches,FETCH_SIZE_bytes,WRITE_SIZE_bytes\n")
