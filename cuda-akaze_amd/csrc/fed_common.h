@@ -47,6 +47,21 @@ __device__ __forceinline__ int wave_shl1(int v)
     return r;
 }
 
+// 16-byte store with the `nt` bit: planes that are written once and next read sparsely or much later should not displace
+// the streams other kernels are reading from L2 / Infinity Cache (measured: Hessian -3 %, +3 % end to end)
+typedef float hak_v4f __attribute__((ext_vector_type(4)));
+typedef int hak_v4i __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void hak_store_nt(float4* p, const float4 v)
+{
+    const hak_v4f t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<hak_v4f*>(p));
+}
+__device__ __forceinline__ void hak_store_nt(int4* p, const int4 v)
+{
+    const hak_v4i t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<hak_v4i*>(p));
+}
+
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
 
 // horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 0..4

@@ -161,7 +161,7 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
             const V m[4] = {um[0].w, um[1].w, um[2].w, um[3].w}, q[4] = {dn[0].w, dn[1].w, dn[2].w, dn[3].w};
             o.w = bsm_conv<R>(cc.w, m, q, tp.b);
         }
-        if (y >= ybeg && y < yend && owns) *reinterpret_cast<V4*>(LT + (long)y * p + x0) = o;
+        if (y >= ybeg && y < yend && owns) hak_store_nt(reinterpret_cast<V4*>(LT + (long)y * p + x0), o);
     }
     // ---- sigma=1 column pass -> smooth row t - 2 (never written)
     {
@@ -189,7 +189,7 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
         g.z = bsm_mag(su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w);
         g.w = bsm_mag(su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR);
         if (b >= ybeg && b < yend && owns) {
-            *reinterpret_cast<V4*>(GR + (long)b * p + x0) = g;
+            hak_store_nt(reinterpret_cast<V4*>(GR + (long)b * p + x0), g);
             S.tmax = bsm_max(S.tmax, bsm_max(bsm_max(g.x, g.y), bsm_max(g.z, g.w)));
         }
     }

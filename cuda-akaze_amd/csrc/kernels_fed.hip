@@ -94,7 +94,7 @@ __device__ __forceinline__ void fed_iter(FedState<V, NS>& S, const int t, const 
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
         } else if (rho >= ybeg && rho < yend && owns) {
-            *reinterpret_cast<V4*>(D + (long)rho * p + x0) = out;
+            hak_store_nt(reinterpret_cast<V4*>(D + (long)rho * p + x0), out);
         }
     }
 }

@@ -129,7 +129,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         sm.y = sf_conv(c.y, u1.y, d1.y, u2.y, d2.y, kk);
         sm.z = sf_conv(c.z, u1.z, d1.z, u2.z, d2.z, kk);
         sm.w = sf_conv(c.w, u1.w, d1.w, u2.w, d2.w, kk);
-        if (a >= ybeg && a < yend && owns) *reinterpret_cast<V4*>(SMO + (long)a * p + x0) = sm;
+        if (a >= ybeg && a < yend && owns) hak_store_nt(reinterpret_cast<V4*>(SMO + (long)a * p + x0), sm);
         V sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
         if (XE) {
             sl = le ? sm.y : sl;                            // abs(x-1) = 1
@@ -170,7 +170,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         } else {
             g = mk4(sf_g_as<V>(1.f / den.x), sf_g_as<V>(1.f / den.y), sf_g_as<V>(1.f / den.z), sf_g_as<V>(1.f / den.w));
         }
-        if (WRITE_G && tf >= ybeg && tf < yend && owns) *reinterpret_cast<V4*>(GO + (long)tf * p + x0) = g;
+        if (WRITE_G && tf >= ybeg && tf < yend && owns) hak_store_nt(reinterpret_cast<V4*>(GO + (long)tf * p + x0), g);
         const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
         GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         if (XE) {
@@ -198,7 +198,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
         } else if (rho >= ybeg && rho < yend && owns) {
-            *reinterpret_cast<V4*>(D + (long)rho * p + x0) = out;
+            hak_store_nt(reinterpret_cast<V4*>(D + (long)rho * p + x0), out);
         }
     }
 }

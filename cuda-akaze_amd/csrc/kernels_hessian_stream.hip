@@ -10,7 +10,8 @@
 //     Lx, Ly  of row b = t - S      come from input rows b-S, b, b+S      (the ring's oldest / middle / newest),
 //     det     of row c = t - 2S     comes from Lx / Ly rows c-S, c, c+S,
 //     extrema of row e = t - 2S - 1 come from det rows e-1, e, e+1,
-// so the input is read once (4 B/px) and Lx, Ly, det are written once (12 B/px) with 16-byte accesses.  Horizontal
+// so the input is read once (4 B/px) and Lx, Ly, det are written once (12 B/px) with 16-byte accesses (non-temporal
+// stores: the three planes are next touched sparsely, by the NMS and the descriptor stage).  Horizontal
 // neighbours at distance S are the adjacent lane's components: S DPP wave shifts per direction per row.  The rings
 // rotate statically (row loop unrolled by R); the strip's outer M columns and the 2S+1 warm-up rows above / below a
 // segment are recomputed by the neighbouring wave.
@@ -187,8 +188,8 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         T.X[pmod(U, R)] = vx;
         T.Y[pmod(U, R) * 64 + lane] = vy;
         if (b >= ybeg && b < yend && owns) {
-            *reinterpret_cast<V4*>(a.lx + (long)b * p + x0) = vx;
-            *reinterpret_cast<V4*>(a.ly + (long)b * p + x0) = vy;
+            hak_store_nt(reinterpret_cast<V4*>(a.lx + (long)b * p + x0), vx);
+            hak_store_nt(reinterpret_cast<V4*>(a.ly + (long)b * p + x0), vy);
         }
         if (YEDGE) {
 #pragma unroll
@@ -228,7 +229,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_DET
         T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
-        if (c >= ybeg && c < yend && owns) *reinterpret_cast<V4*>(a.det + (long)c * p + x0) = d;
+        if (c >= ybeg && c < yend && owns) hak_store_nt(reinterpret_cast<V4*>(a.det + (long)c * p + x0), d);
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
     if (a.maps != nullptr) {
