@@ -94,12 +94,16 @@ __device__ __forceinline__ auto hs_r(const V4& r, const bool re)
     return v;
 }
 
+__device__ __forceinline__ float hs_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+__device__ __forceinline__ int hs_max3(int a, int b, int c) { return max(max(a, b), c); }
+
 // dilated Scharr pair on one component (akazed.cu:1294-1295)
 #define HS_DX(ul, ur, cl, cr, ll, lr) hs_d(fac1, fac2, (ur) + (lr) - (ul) - (ll), (cr) - (cl))
 #define HS_DY(ul, uc, ur, ll, lc, lr) hs_d(fac1, fac2, (lr) + (ll) - (ur) - (ul), (lc) - (uc))
 
 template <typename V> struct HsArgs {
     const V* src; V* lx; V* ly; V* det;
+    V* obase; unsigned off_lx, off_ly, off_det;     // lx / ly / det as byte offsets from the lowest of the three (buffer stores)
     int w, h, p;
     V fac1, fac2;
     // extrema (maps == nullptr: determinant only)
@@ -148,7 +152,8 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
 
 template <typename V, int S, int U, bool XEDGE, bool YEDGE>
 __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
-                                        const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane)
+                                        const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
+                                        const __amdgpu_buffer_rsrc_t orsrc, const unsigned ovoff)
 {
     using V4 = typename FedV<V>::V4;
     constexpr int R = HsGeo<S>::R;
@@ -158,7 +163,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
     // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
     // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
     // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
-    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (long)min(t + HsGeo<S>::PD, h - 1) * p + xl);
+    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S>::PD, h - 1) * p + xl));
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -187,9 +192,11 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
 #undef HS_S1
         T.X[pmod(U, R)] = vx;
         T.Y[pmod(U, R) * 64 + lane] = vy;
-        if (b >= ybeg && b < yend && owns) {
-            hak_store_nt(reinterpret_cast<V4*>(a.lx + (long)b * p + x0), vx);
-            hak_store_nt(reinterpret_cast<V4*>(a.ly + (long)b * p + x0), vy);
+        {
+            // unconditional buffer stores; rows outside the segment and margin lanes carry the out-of-range bit
+            const unsigned voff = ovoff + (b >= ybeg && b < yend ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB);
+            hak_buf_store_nt(orsrc, voff, a.off_lx, vx);
+            hak_buf_store_nt(orsrc, voff, a.off_ly, vy);
         }
         if (YEDGE) {
 #pragma unroll
@@ -229,7 +236,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_DET
         T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
-        if (c >= ybeg && c < yend && owns) hak_store_nt(reinterpret_cast<V4*>(a.det + (long)c * p + x0), d);
+        hak_buf_store_nt(orsrc, ovoff + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), a.off_det, d);
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
     if (a.maps != nullptr) {
@@ -244,14 +251,17 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
             const V vl = wave_shr1(v.w), vr = wave_shl1(v.x);
             const V ul = wave_shr1(up.w), ur = wave_shl1(up.x);
             const V dl = wave_shr1(dn.w), dr = wave_shl1(dn.x);
-            const bool hx = owns && (xok & 1u) && v.x > thr && v.x > up.x && v.x > dn.x && v.x > vl && v.x > v.y &&
-                            v.x > ul && v.x > up.y && v.x > dl && v.x > dn.y;
-            const bool hy = owns && (xok & 2u) && v.y > thr && v.y > up.y && v.y > dn.y && v.y > v.x && v.y > v.z &&
-                            v.y > up.x && v.y > up.z && v.y > dn.x && v.y > dn.z;
-            const bool hz = owns && (xok & 4u) && v.z > thr && v.z > up.z && v.z > dn.z && v.z > v.y && v.z > v.w &&
-                            v.z > up.y && v.z > up.w && v.z > dn.y && v.z > dn.w;
-            const bool hw = owns && (xok & 8u) && v.w > thr && v.w > up.w && v.w > dn.w && v.w > v.z && v.w > vr &&
-                            v.w > up.z && v.w > ur && v.w > dn.z && v.w > dr;
+            // strict maximum over the threshold and the 8 neighbours: v > max(all nine) -- four v_max3 and one compare per
+            // pixel instead of nine compares and their scalar mask chain (ordered compares: a NaN neighbour can only appear
+            // for non-finite input images)
+            const V mx = hs_max3(hs_max3(thr, up.x, dn.x), hs_max3(vl, v.y, ul), hs_max3(up.y, dl, dn.y));
+            const V my = hs_max3(hs_max3(thr, up.y, dn.y), hs_max3(v.x, v.z, up.x), hs_max3(up.z, dn.x, dn.z));
+            const V mz = hs_max3(hs_max3(thr, up.z, dn.z), hs_max3(v.y, v.w, up.y), hs_max3(up.w, dn.y, dn.w));
+            const V mw = hs_max3(hs_max3(thr, up.w, dn.w), hs_max3(v.z, vr, up.z), hs_max3(ur, dn.z, dr));
+            const bool hx = owns && (xok & 1u) && v.x > mx;
+            const bool hy = owns && (xok & 2u) && v.y > my;
+            const bool hz = owns && (xok & 4u) && v.z > mz;
+            const bool hw = owns && (xok & 8u) && v.w > mw;
             if (__ballot(hx || hy || hz || hw) != 0ull) {
                 if (T.cb.n > HS_CBUF - 128) hs_flush(T.cb, a, lane);    // a row holds at most 128 strict 3x3 maxima per wave
                 hs_emit(hx, v.x, x0, e, a, lane, T.cb);
@@ -266,9 +276,9 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
 template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
 __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const unsigned xok, const int lane)
+                                         const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned ovoff)
 {
-    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane), ...);
+    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff), ...);
 }
 
 template <typename V, int S, bool XEDGE>
@@ -288,6 +298,8 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
         const int x = x0 + k;
         if (x >= a.psz && (int)(x - a.border + 0.5f) - 1 >= 0 && (int)(x + a.border + 0.5f) + 1 < w) xok |= 1u << k;
     }
+    const __amdgpu_buffer_rsrc_t orsrc = hak_buf_rsrc(a.obase);
+    const unsigned ovoff = owns ? (unsigned)x0 * (unsigned)sizeof(V) : HAK_BUF_OOB;
     HsState<V, S> T;
     T.Y = yring;
     T.cb.buf = cbuf;
@@ -298,13 +310,13 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
 #pragma unroll
-    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const V4*>(a.src + (long)min(t0 + i, h - 1) * a.p + xl);
+    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl));
     for (int tb = t0; tb <= tend; tb += G::R) {
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
         if (tb <= 2 * S || tb + G::R - 1 >= h)
-            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
         else
-            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane);
+            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
     }
     if (a.maps != nullptr) hs_flush(T.cb, a, lane);
 }
@@ -318,7 +330,7 @@ __global__ __launch_bounds__(256) void k_hessian_stream(HsArgs<V> a, long stride
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
-    a.src += (long)img * stride; a.lx += (long)img * stride; a.ly += (long)img * stride; a.det += (long)img * stride;
+    a.src += (long)img * stride; a.obase += (long)img * stride;
     if (a.maps) { a.maps += (long)img * map_stride; a.cand += (long)img * a.cand_cap; a.st += img; }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -349,8 +361,12 @@ template <typename V>
 bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride, int w, int h, int p, int nimg, int step,
                        V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
 {
-    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
+    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2 || (long)h * p * (long)sizeof(V) >= (long)HAK_BUF_OOB) return false;
     HsArgs<V> a{};
+    V* lo = lx < ly ? lx : ly;
+    lo = det < lo ? det : lo;
+    if ((lx - lo) >= (1L << 28) || (ly - lo) >= (1L << 28) || (det - lo) >= (1L << 28)) return false;   // soffset is 32-bit bytes
+    a.obase = lo; a.off_lx = (unsigned)((lx - lo) * sizeof(V)); a.off_ly = (unsigned)((ly - lo) * sizeof(V)); a.off_det = (unsigned)((det - lo) * sizeof(V));
     a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
     long map_stride = 0;
     if (b) {
