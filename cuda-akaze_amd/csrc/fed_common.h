@@ -68,24 +68,28 @@ __device__ __forceinline__ void hak_store_nt(int4* p, const int4 v)
 // kernels exposed the full store latency once per row.  A raw buffer store drops lanes whose offset is out of range in
 // hardware, so the predicate moves into the offset (HAK_BUF_OOB) and the instruction is unconditional and countable.
 typedef unsigned hak_v4u __attribute__((ext_vector_type(4)));
-// out-of-range marker = num_records of every resource made below.  Offsets are SUMS of a lane part and a wave-uniform row
-// part, either of which may carry the marker: valid sums stay below 2^30 (callers check the plane size), one marker gives
-// [2^30, 2^31), two give 2^31 -- all out of range, none wraps.
+// out-of-range marker = num_records of every resource made below.  Offsets are SUMS of a lane part (column + plane offset)
+// and a wave-uniform row part, either of which may carry the marker: valid sums stay below 2^30 (launchers check plane
+// offset + plane size), one marker gives [2^30, 2^31), two give 2^31 -- all out of range, none wraps.
 constexpr unsigned HAK_BUF_OOB = 0x40000000u;
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t hak_buf_rsrc(void* base)
 {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, HAK_BUF_OOB, 0x00020000);     // raw buffer, gfx9 dword-3 format bits
 }
-// byte offsets: voff per lane (>= HAK_BUF_OOB = lane writes nothing), soff wave-uniform.  aux 2 = nt (see hak_store_nt)
-__device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const float4 v)
+// voff: byte offset per lane (>= HAK_BUF_OOB = the lane writes nothing).  aux 2 = nt (see hak_store_nt).
+// The scalar offset field is deliberately the constant 0: with an SGPR there, LLVM's hazard recognizer assumes that a
+// following VALU write of the 128-bit store data needs no wait state (GCNHazardRecognizer::createsVALUHazard), but on
+// gfx950 the next instruction did overwrite the data of the last four lanes of each 16-lane pass before the store had
+// read them (lanes 12-15 / 28-31 / ... of one row wrong, only in some code shapes).  Plane offsets therefore go into voff.
+__device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, const float4 v)
 {
     const hak_v4u d = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, 0, 2);
 }
-__device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const int4 v)
+__device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, const int4 v)
 {
     const hak_v4u d = {(unsigned)v.x, (unsigned)v.y, (unsigned)v.z, (unsigned)v.w};
-    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, soff, 2);
+    __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, 0, 2);
 }
 
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }

@@ -97,6 +97,9 @@ __device__ __forceinline__ int bsm_mag(int ul, int uc, int ur, int cl, int cr, i
 __device__ __forceinline__ float bsm_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ int bsm_max(int a, int b) { return max(a, b); }
 
+// Lt and the gradient plane as one raw buffer (lower pointer) + byte offsets: unconditional, countable stores (fed_common.h)
+struct BsmOut { __amdgpu_buffer_rsrc_t r; unsigned lt, gr; };    // per-lane byte offsets (column + plane) or HAK_BUF_OOB
+
 template <typename V>
 struct BsmState {
     using V4 = typename BsT<V>::V4;
@@ -112,7 +115,7 @@ template <typename V, int R, int U, bool XE>
 __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT,
                                          V* __restrict__ GR, const int sp, const int p, const int xl, const int x0, const int h,
                                          const int ybeg, const int yend, const bool owns, const bool edge, const int c0, const int c1,
-                                         const int c2, const int c3, const BsmTaps<V>& tp)
+                                         const int c2, const int c3, const BsmTaps<V>& tp, const BsmOut& O)
 {
     using V4 = typename BsT<V>::V4;
     // ---- image row t arrives (virtual rows outside the image are their mirror rows); request row t + PD
@@ -161,7 +164,7 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
             const V m[4] = {um[0].w, um[1].w, um[2].w, um[3].w}, q[4] = {dn[0].w, dn[1].w, dn[2].w, dn[3].w};
             o.w = bsm_conv<R>(cc.w, m, q, tp.b);
         }
-        if (y >= ybeg && y < yend && owns) hak_store_nt(reinterpret_cast<V4*>(LT + (long)y * p + x0), o);
+        hak_buf_store_nt(O.r, O.lt + (y >= ybeg && y < yend ? (unsigned)(y * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), o);
     }
     // ---- sigma=1 column pass -> smooth row t - 2 (never written)
     {
@@ -188,10 +191,9 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
         g.y = bsm_mag(su.x, su.y, su.z, sc.x, sc.z, sd.x, sd.y, sd.z);
         g.z = bsm_mag(su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w);
         g.w = bsm_mag(su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR);
-        if (b >= ybeg && b < yend && owns) {
-            hak_store_nt(reinterpret_cast<V4*>(GR + (long)b * p + x0), g);
-            S.tmax = bsm_max(S.tmax, bsm_max(bsm_max(g.x, g.y), bsm_max(g.z, g.w)));
-        }
+        const bool inr = b >= ybeg && b < yend;
+        hak_buf_store_nt(O.r, O.gr + (inr ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
+        if (inr && owns) S.tmax = bsm_max(S.tmax, bsm_max(bsm_max(g.x, g.y), bsm_max(g.z, g.w)));
     }
 }
 
@@ -205,6 +207,14 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
     const int xl = min(max(x0, 0), w - 4);
     const bool edge = XE && (x0 == -4 || x0 == w);
     const int c0 = hak_refl(x0, w), c1 = hak_refl(x0 + 1, w), c2 = hak_refl(x0 + 2, w), c3 = hak_refl(x0 + 3, w);
+    BsmOut O;
+    {
+        V* lo = LT < GR ? LT : GR;
+        O.r = hak_buf_rsrc(lo);
+        const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
+        O.lt = owns ? xb + (unsigned)((LT - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+        O.gr = owns ? xb + (unsigned)((GR - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+    }
     const int t0 = ybeg - RR;
     const int tend = yend - 1 + RR;
     BsmState<V> S;
@@ -218,15 +228,15 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
 #pragma unroll
     for (int i = 0; i < BS_PD; i++) S.Lq[i] = bsm_load<V, XE>(s, hak_refl(min(t0 + i, h + 3), h), sp, xl, edge, c0, c1, c2, c3);
     for (int tb = t0; tb <= tend; tb += BS_RING) {
-        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
-        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp);
+        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
     }
     return S.tmax;
 }
@@ -271,6 +281,7 @@ bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img
     if (!grad || R < 2 || R > 4 || (w & 3) || w < 16 || h < 16) return false;
     if ((sp % LA) || (img_stride % LA) || (reinterpret_cast<uintptr_t>(img) % (LA * sizeof(In)))) return false;
     if (!hak_stream_pays(hak_base_stream_enabled, w, h, nimg)) return false;
+    if ((lt < grad ? grad - lt : lt - grad) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;   // plane offset + plane size < marker
     BsmTaps<V> tp;
     tp.a = SfTaps<V>{taps1[0], taps1[1], taps1[2]};
     for (int i = 0; i < 5; i++) tp.b[i] = i <= R ? taps_base[i] : V(0);

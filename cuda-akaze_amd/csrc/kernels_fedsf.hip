@@ -60,13 +60,17 @@ __device__ __forceinline__ V4 fs_fetch(const V* __restrict__ L, const int row, c
     }
 }
 
+// smooth and g as one raw buffer (lower pointer): unconditional, countable stores (fed_common.h).  smo / go: per-lane byte
+// offsets (column + plane) or HAK_BUF_OOB for lanes that own nothing
+struct FsOut { __amdgpu_buffer_rsrc_t r; unsigned smo, go; };
+
 // lp / sh: pitch and row count of the plane L points to (= p, h unless DEC)
 template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G, bool DEC>
 __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V* __restrict__ L, V* __restrict__ SMO,
                                         V* __restrict__ GO, V* __restrict__ D, const int p, const int xl,
                                         const int x0, const int w, const int h, const int ybeg, const int yend,
                                         const bool owns, const FedFacs<V, NS>& fac, const SfTaps<V> kk, const float ikc,
-                                        const int lp, const int sh)
+                                        const int lp, const int sh, const FsOut& O)
 {
     using V4 = typename FedV<V>::V4;
     constexpr int GS = FsState<V, NS>::GS, PD = FsState<V, NS>::PD;
@@ -129,7 +133,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         sm.y = sf_conv(c.y, u1.y, d1.y, u2.y, d2.y, kk);
         sm.z = sf_conv(c.z, u1.z, d1.z, u2.z, d2.z, kk);
         sm.w = sf_conv(c.w, u1.w, d1.w, u2.w, d2.w, kk);
-        if (a >= ybeg && a < yend && owns) hak_store_nt(reinterpret_cast<V4*>(SMO + (long)a * p + x0), sm);
+        hak_buf_store_nt(O.r, O.smo + (a >= ybeg && a < yend ? (unsigned)(a * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), sm);
         V sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
         if (XE) {
             sl = le ? sm.y : sl;                            // abs(x-1) = 1
@@ -170,7 +174,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         } else {
             g = mk4(sf_g_as<V>(1.f / den.x), sf_g_as<V>(1.f / den.y), sf_g_as<V>(1.f / den.z), sf_g_as<V>(1.f / den.w));
         }
-        if (WRITE_G && tf >= ybeg && tf < yend && owns) hak_store_nt(reinterpret_cast<V4*>(GO + (long)tf * p + x0), g);
+        if (WRITE_G) hak_buf_store_nt(O.r, O.go + (tf >= ybeg && tf < yend ? (unsigned)(tf * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
         const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
         GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         if (XE) {
@@ -198,6 +202,7 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
             if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
             if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
         } else if (rho >= ybeg && rho < yend && owns) {
+            // kept conditional: an unconditional store means evaluating the last level for every row, which costs ~100 VGPRs
             hak_store_nt(reinterpret_cast<V4*>(D + (long)rho * p + x0), out);
         }
     }
@@ -211,6 +216,15 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
 {
     using V4 = typename FedV<V>::V4;
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
+    FsOut O;
+    {
+        V* lo = SMO;
+        if (WRITE_G) lo = GO < lo ? GO : lo;
+        O.r = hak_buf_rsrc(lo);
+        const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
+        O.smo = owns ? xb + (unsigned)((SMO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+        O.go = WRITE_G && owns ? xb + (unsigned)((GO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+    }
     const int t0 = max(0, ybeg - NS - 4);                   // rp from t0, smooth from t0+2, g from t0+3, level k from t0+3+k
     const int tend = min(yend - 1, h - 1) + NS + 3;         // iteration that emits the strip's last L' row
     FsState<V, NS> S;
@@ -234,19 +248,19 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
     for (int tb = t0; tb <= tend; tb += 6) {
         // reflect injections fire while some stage is at rows 1..2 (t <= NS + 4) or at the virtual rows past h-1
         if (tb <= NS + 4 || tb + 5 >= h) {
-            fs_iter<V, NS, 0, true, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 1, true, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 2, true, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 3, true, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 4, true, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 5, true, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 0, true, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 1, true, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 2, true, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 3, true, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 4, true, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 5, true, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
         } else {
-            fs_iter<V, NS, 0, false, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 1, false, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 2, false, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 3, false, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 4, false, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
-            fs_iter<V, NS, 5, false, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh);
+            fs_iter<V, NS, 0, false, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 1, false, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 2, false, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 3, false, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 4, false, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 5, false, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
         }
     }
 }
@@ -311,6 +325,8 @@ bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, lon
                    bool write_g, int sp = 0, int sh = 0)
 {
     if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
+    // smooth and g are addressed as 32-bit byte offsets from the lower of them: plane offset + plane size < the marker
+    if ((write_g ? (flow < smooth ? smooth - flow : flow - smooth) : 0L) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
     switch (ns) {
     case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
     case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;

@@ -153,7 +153,7 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
 template <typename V, int S, int U, bool XEDGE, bool YEDGE>
 __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
-                                        const __amdgpu_buffer_rsrc_t orsrc, const unsigned ovoff)
+                                        const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
 {
     using V4 = typename FedV<V>::V4;
     constexpr int R = HsGeo<S>::R;
@@ -194,9 +194,9 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         T.Y[pmod(U, R) * 64 + lane] = vy;
         {
             // unconditional buffer stores; rows outside the segment and margin lanes carry the out-of-range bit
-            const unsigned voff = ovoff + (b >= ybeg && b < yend ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB);
-            hak_buf_store_nt(orsrc, voff, a.off_lx, vx);
-            hak_buf_store_nt(orsrc, voff, a.off_ly, vy);
+            const unsigned roff = b >= ybeg && b < yend ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB;
+            hak_buf_store_nt(orsrc, ovoff[0] + roff, vx);
+            hak_buf_store_nt(orsrc, ovoff[1] + roff, vy);
         }
         if (YEDGE) {
 #pragma unroll
@@ -236,7 +236,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_DET
         T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
-        hak_buf_store_nt(orsrc, ovoff + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), a.off_det, d);
+        hak_buf_store_nt(orsrc, ovoff[2] + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), d);
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
     if (a.maps != nullptr) {
@@ -276,7 +276,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
 template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
 __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned ovoff)
+                                         const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
 {
     (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff), ...);
 }
@@ -299,7 +299,9 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
         if (x >= a.psz && (int)(x - a.border + 0.5f) - 1 >= 0 && (int)(x + a.border + 0.5f) + 1 < w) xok |= 1u << k;
     }
     const __amdgpu_buffer_rsrc_t orsrc = hak_buf_rsrc(a.obase);
-    const unsigned ovoff = owns ? (unsigned)x0 * (unsigned)sizeof(V) : HAK_BUF_OOB;
+    // per-plane lane offsets (column + plane); lanes that own nothing carry the out-of-range marker
+    const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
+    const unsigned ovoff[3] = {owns ? xb + a.off_lx : HAK_BUF_OOB, owns ? xb + a.off_ly : HAK_BUF_OOB, owns ? xb + a.off_det : HAK_BUF_OOB};
     HsState<V, S> T;
     T.Y = yring;
     T.cb.buf = cbuf;
@@ -361,11 +363,14 @@ template <typename V>
 bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride, int w, int h, int p, int nimg, int step,
                        V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
 {
-    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2 || (long)h * p * (long)sizeof(V) >= (long)HAK_BUF_OOB) return false;
+    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
     HsArgs<V> a{};
     V* lo = lx < ly ? lx : ly;
     lo = det < lo ? det : lo;
-    if ((lx - lo) >= (1L << 28) || (ly - lo) >= (1L << 28) || (det - lo) >= (1L << 28)) return false;   // soffset is 32-bit bytes
+    {   // plane offset + plane size must stay below the out-of-range marker
+        const long room = (long)HAK_BUF_OOB / (long)sizeof(V) - (long)h * p;
+        if ((lx - lo) >= room || (ly - lo) >= room || (det - lo) >= room) return false;
+    }
     a.obase = lo; a.off_lx = (unsigned)((lx - lo) * sizeof(V)); a.off_ly = (unsigned)((ly - lo) * sizeof(V)); a.off_det = (unsigned)((det - lo) * sizeof(V));
     a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
     long map_stride = 0;
