@@ -282,6 +282,10 @@ def main():
                           "conductivity run inside its first FED launch)", "bound": "hbm",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                # the same launches priced by their measured HBM traffic instead of the unfused byte model: frac > 1 above means
+                # fusion removed traffic, this one says how close the remaining traffic runs to the HBM peak
+                "traffic_GBs": None if traffic is None else round(traffic / avg_s / 1e9, 1),
+                "traffic_frac": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
                 "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls,
                 # end-to-end achieved = all-stage algorithmic bytes per image x images/s of the timed region
