@@ -209,23 +209,26 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
 }
 
 // ---- pass B': the same histogram from the gradient plane pass A left behind (4 B/px read, no recomputation)
+#define HIST_COPIES 8          // private LDS histograms per block, selected by lane: smooth images put most pixels into a few
+                                // bins, and LDS atomics on one address serialise
 __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict__ grad, long stride, int w, int h, int p,
                                                          HakImgState* state, int rows_per_block)
 {
-    __shared__ int shist[HAK_NBINS];
+    __shared__ int shist[HIST_COPIES * HAK_NBINS];
     const int im = blockIdx.y;
     const float* g0 = grad + (long)im * stride;
     const int tid = threadIdx.x;
-    for (int i = tid; i < HAK_NBINS; i += 256) shist[i] = 0;
+    for (int i = tid; i < HIST_COPIES * HAK_NBINS; i += 256) shist[i] = 0;
     const float hmax = __uint_as_float(state[im].hmax_bits);
     const float hfactor = HAK_NBINS / hmax;                         // akazed.cu:2450
     hak_lds_barrier();
     const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, h);
+    int* mine = shist + (tid & (HIST_COPIES - 1)) * HAK_NBINS;
     auto bin = [&](float g) {
         // (int)__fmul_rz(g, factor): exact double product, truncated (akazed.cu:924)
         int hi = (int)((double)g * (double)hfactor);
         hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
-        atomicAdd(&shist[hi], 1);
+        atomicAdd(&mine[hi], 1);
     };
     const int w4 = w >> 2;                                          // rows are 16-byte aligned (pitch % 64 == 0)
     for (int y = y0; y < y1; y++) {
@@ -237,8 +240,12 @@ __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict
         if (tid < (w & 3)) bin(row[4 * w4 + tid]);
     }
     hak_lds_barrier();
-    for (int i = tid; i < HAK_NBINS; i += 256)
-        if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
+    for (int i = tid; i < HAK_NBINS; i += 256) {
+        int sum = 0;
+#pragma unroll
+        for (int c = 0; c < HIST_COPIES; c++) sum += shist[c * HAK_NBINS + i];
+        if (sum) atomicAdd(&state[im].hist[i], sum);
+    }
 }
 
 // host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371)

@@ -266,27 +266,33 @@ __global__ __launch_bounds__(256) void kf_base(const unsigned char* __restrict__
 }
 
 // histogram of the gradient plane kf_base left behind (akazed.cu:3299-3330)
+#define FHIST_COPIES 8         // private LDS histograms per block, selected by lane (LDS atomics on one address serialise)
 __global__ __launch_bounds__(256) void kf_grad_hist_plane(const int* __restrict__ grad, long stride, int w, int h, int p,
                                                           HakImgState* state, int rows_per_block)
 {
-    __shared__ int shist[HAK_NBINS];
+    __shared__ int shist[FHIST_COPIES * HAK_NBINS];
     const int im = blockIdx.y;
     const int* g0 = grad + (long)im * stride;
-    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) shist[i] = 0;
+    for (int i = threadIdx.x; i < FHIST_COPIES * HAK_NBINS; i += 256) shist[i] = 0;
     const int hfactor = (int)(HAK_NBINS / (float)state[im].ihmax * 65536 + 0.5f);                // akazed.cu:4133
     __syncthreads();
+    int* mine = shist + (threadIdx.x & (FHIST_COPIES - 1)) * HAK_NBINS;
     const int y0 = blockIdx.x * rows_per_block, y1 = min(y0 + rows_per_block, h);
     for (int y = y0; y < y1; y++) {
         const int* row = g0 + (long)y * p;
         for (int x = threadIdx.x; x < w; x += 256) {
             int hi = wmul(row[x], hfactor) >> 16;                                                 // akazed.cu:3319
             hi = hi >= HAK_NBINS ? HAK_NBINS - 1 : (hi < 0 ? 0 : hi);
-            atomicAdd(&shist[hi], 1);
+            atomicAdd(&mine[hi], 1);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < HAK_NBINS; i += 256)
-        if (shist[i]) atomicAdd(&state[im].hist[i], shist[i]);
+    for (int i = threadIdx.x; i < HAK_NBINS; i += 256) {
+        int sum = 0;
+#pragma unroll
+        for (int c = 0; c < FHIST_COPIES; c++) sum += shist[c * HAK_NBINS + i];
+        if (sum) atomicAdd(&state[im].hist[i], sum);
+    }
 }
 
 // img (uint8) -> Lt(0,0), contrast factors; `grad_scratch` = a free int32 plane of the arena.  false: R not covered
