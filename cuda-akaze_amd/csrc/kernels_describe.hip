@@ -45,6 +45,14 @@ __device__ __forceinline__ float dsc_fast_atan2(float yv, float xv)
     return r;
 }
 
+// base[byte_off / sizeof(V)] with the byte offset formed in 32 bits: with a wave-uniform base the load takes the
+// `global_load v, v_off, s[base]` form -- one offset VGPR per sample for all three planes instead of a 64-bit address each
+template <typename V>
+__device__ __forceinline__ V dsc_ld(const V* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
+}
+
 template <typename V>
 __device__ __forceinline__ void reduce_rows(const V* acc, V* vals, int nrows, int out_base, int lane)
 {
@@ -86,7 +94,7 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
         hak_point* pt = pts + pi;
         float ptx = pt->x, pty = pt->y;
         const float ptsize = pt->size;
-        const int layer = pt->octave;
+        const int layer = __builtin_amdgcn_readfirstlane(pt->octave);   // one keypoint per wave: plane bases stay in SGPRs
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
         const V* dxd = arena + L.lx(o, s);
@@ -130,9 +138,9 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
                 const int r2 = i * i + j * j;
                 gr2[q] = (tix < 208 && r2 < 36) ? r2 : -1;
                 const int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
-                const long pos = (long)yy * oc.p + xx;
-                gdx[q] = gr2[q] >= 0 ? (float)dxd[pos] : 0.f;
-                gdy[q] = gr2[q] >= 0 ? (float)dyd[pos] : 0.f;
+                const unsigned pos = (unsigned)(yy * oc.p + xx) * (unsigned)sizeof(V);
+                gdx[q] = gr2[q] >= 0 ? (float)dsc_ld(dxd, pos) : 0.f;
+                gdy[q] = gr2[q] >= 0 ? (float)dsc_ld(dyd, pos) : 0.f;
             }
             // valid samples are compacted in ascending thread order through a ballot
             int nvalid = 0;
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
     for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
         const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
-        const int layer = pt->octave;
+        const int layer = __builtin_amdgcn_readfirstlane(pt->octave);   // one keypoint per wave: plane bases stay in SGPRs
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
         const V* imd = arena + L.lt(o, s);
@@ -265,10 +273,10 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
                 int yp = (int)(yf + scale * (k * si + l * co) + 0.5f);  // akazed.cu:1922
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
-                const long pos = (long)yp * oc.p + xp;
-                vim[n] = ok ? imd[pos] : V(0);
-                gdx[n] = ok ? dxd[pos] : V(0);
-                gdy[n] = ok ? dyd[pos] : V(0);
+                const unsigned pos = (unsigned)(yp * oc.p + xp) * (unsigned)sizeof(V);
+                vim[n] = ok ? dsc_ld(imd, pos) : V(0);
+                gdx[n] = ok ? dsc_ld(dxd, pos) : V(0);
+                gdy[n] = ok ? dsc_ld(dyd, pos) : V(0);
             }
 #pragma unroll
             for (int n = 0; n < MAX_SMP; n++) {
@@ -319,8 +327,8 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
                 int yp = (int)(pty * iratio + scale * (k * si + l * co) + 0.5f);
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
-                const long pos = (long)yp * oc.p + xp;
-                const V im = imd[pos], dx = dxd[pos], dy = dyd[pos];
+                const unsigned pos = (unsigned)(yp * oc.p + xp) * (unsigned)sizeof(V);
+                const V im = dsc_ld(imd, pos), dx = dsc_ld(dxd, pos), dy = dsc_ld(dyd, pos);
                 scatter(x, y, im, rot_x(dx, dy, si, co), rot_y(dx, dy, si, co));
             }
             hak_lds_barrier();
