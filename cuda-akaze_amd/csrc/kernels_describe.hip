@@ -250,7 +250,8 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
         auto rot_x = [](V dx, V dy, float si, float co) -> V { return (V)(-dx * si + dy * co); };
         auto rot_y = [](V dx, V dy, float si, float co) -> V { return (V)(dx * co + dy * si); };
         V vim[MAX_SMP], vrx[MAX_SMP], vry[MAX_SMP];
-        int cx[MAX_SMP], cy[MAX_SMP];           // sample grid coordinates; cx < 0 marks "no sample"
+        int cells[MAX_SMP];                     // per sample: its accumulator row in the 2x2 / 3x3 / 4x4 grid as three bytes (0xFF = none),
+                                                // worked out once here instead of in each of the three rounds below
         {
             const float iratio = 1.f / (1 << o);
             const int scale = (int)(ptsize + 0.5f);
@@ -265,8 +266,16 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
                 const int y = i / winsize;
                 const int x = i - winsize * y;
                 const bool ok = i < nsmp;
-                cx[n] = ok ? x : -1;
-                cy[n] = y;
+                {
+                    const int m = max(x, y);
+                    const int r2 = m < 2 * size2 ? 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)) : 0xFF;
+                    const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+                    const int r3 = m < 3 * size3 ? 3 * (4 + y3 * 3 + x3) : 0xFF;
+                    const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
+                    const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+                    const int r4 = m < 4 * size4 ? 39 + 3 * (y4 * 4 + x4) : 0xFF;
+                    cells[n] = ok ? (r2 | (r3 << 8) | (r4 << 16)) : 0xFFFFFF;
+                }
                 const int l = x - size2;
                 const int k = y - size2;
                 int xp = (int)(xf + scale * (k * co - l * si) + 0.5f);  // akazed.cu:1921
@@ -315,7 +324,11 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
             };
 #pragma unroll
             for (int n = 0; n < MAX_SMP; n++)
-                if (cx[n] >= 0) scatter(cx[n], cy[n], vim[n], vrx[n], vry[n]);
+            {
+                add(cells[n] & 0xFF, vim[n], vrx[n], vry[n]);            // 0xFF lies beyond every round's row window
+                add((cells[n] >> 8) & 0xFF, vim[n], vrx[n], vry[n]);
+                add((cells[n] >> 16) & 0xFF, vim[n], vrx[n], vry[n]);
+            }
             for (int i = lane + 64 * MAX_SMP; i < nsmp; i += 64) {      // tail: only for pattern sizes > 10
                 const int y = i / winsize, x = i - winsize * y;
                 const float iratio = 1.f / (1 << o);
