@@ -169,6 +169,50 @@ def test_batch_equals_single(ah, torch, synth, B):
     det.close()
 
 
+def test_large_batch_launch_shapes_equal_single(ah, torch, synth):
+    """the benchmark's regime: a batch big enough that every streaming kernel runs its full 120-128-row segments (a single
+    image makes the launchers shrink the segments until the grid fills the chip: 8 strips x 9 segments x images >= 4096
+    needs 57 images) -- both paths, 64 x 1080p, against the
+    single-image results, which test_full_size_vs_oracle / test_fast_path_1080p pin to the oracle"""
+    w, h, mp, B = 1920, 1080, 10000, 64
+    p = ah.iAlignUp(w, 128)
+    u8s = [synth.scene(w, h, 40 + i) for i in range(2)]
+    singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in u8s]
+    pad = [np.zeros((h, p), np.uint8) for _ in u8s]
+    for q, u in zip(pad, u8s):
+        q[:, :w] = u
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp, batch=B)
+    fsingles = []
+    data = ah.AkazeData()
+    ah.initAkazeData(data, mp, True, True)
+    for q in pad:
+        d8 = torch.from_numpy(q).cuda()
+        det.fastDetectAndCompute(d8.data_ptr(), data, (w, h, p), True)
+        fsingles.append(data.h_data[:data.num_pts].copy())
+    ah.freeAkazeData(data)
+    d_pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+    d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
+    stack = torch.from_numpy(np.stack([synth.to_float(u8s[i % 2], p) for i in range(B)])).cuda()
+    ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), 1))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    nums = d_num.cpu().numpy()
+    allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    for i in range(B):
+        assert nums[i] == len(singles[i % 2]) > 500, i
+        assert_points_equal(allp[i, :nums[i]], singles[i % 2])
+    del stack
+    stack8 = torch.from_numpy(np.stack([pad[i % 2] for i in range(B)])).cuda()
+    ah.check(ah.lib.hak_fast_detect_and_compute_batch(det.ctx, stack8.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), 1))
+    ah.check(ah.lib.hak_sync(det.ctx))
+    nums = d_num.cpu().numpy()
+    allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    for i in range(B):
+        assert nums[i] == len(fsingles[i % 2]) > 500, i
+        assert_points_equal(allp[i, :nums[i]], fsingles[i % 2])
+    det.close()
+
+
 def test_repeat_calls_are_deterministic(ah, torch, synth):
     u8 = _mg().case_scene(640, 360, 13)
     a = gpu_detect(ah, torch, synth, u8)
