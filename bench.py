@@ -9,17 +9,30 @@ max 10000 points (main.cpp:156-166).  One "step" = one pass of the hot path over
 --pairs synthetic pairs per GPU: Akazer::detectAndCompute on both images of every pair + cuMatch,
 ending with host-visible keypoints / descriptors / matches (the reference's timed region,
 main.cpp:199-209, with its D2H copies).  Inputs are resident in HBM before the timer starts.
-Frames shard by independent pair across ranks (weak scaling, no data-path collective); RCCL is used
-only for the barrier, the max-over-ranks time and the trivial result-summary gather.
+Frames shard by independent pair across ranks (no data-path collective); RCCL is used only for the
+barrier, the max-over-ranks time and the trivial result-summary gather.
+  default          weak scaling: --pairs per GPU per step
+  --total-pairs T  strong scaling: T pairs per step in total, rank r takes shard_pairs(T, N, r)
+                   ("pairs/s at G = 1, 2, 4, 8 on the same 512 pairs", BASELINE configs[3])
 
-Extra objects: "roofline" for the dominant kernel (the FED step, 12 B/px/step algorithmic)
-measured with HIP events on the launch stream inside this run; "cpu_baseline" = the CPU oracle
-(kind "port") timed on this box's host cores on a bounded sample (rank 0, N == 1 only).
+Extra objects in the line:
+  "verified"      the timed batch's download compared byte for byte with the CPU oracle on its first pairs
+                  (exit code 3 on a mismatch)
+  "roofline"      the FED kernel family (dominant class): achieved = the compulsory HBM bytes of its launches AS BUILT
+                  (fused: read L [+ g], write L' [+ smooth, g]) / average launch duration from HIP events on the launch
+                  stream in a serial leg of this run; "traffic" = PMC bytes per launch from the rocprofv3 passes committed
+                  under profiles/ (only when those passes were taken on the same kernel sources, else null);
+                  "fusion_gain" = the unfused 12 B/px/step model / the fused bytes; "classes" = the same for every kernel
+                  class; "copy_ceiling_GBs" = a float4 HIP copy kernel timed in this run
+  "cpu_baseline"  the CPU oracle ("port") on this box's host cores, median over a bounded sample (rank 0, N == 1)
+  "configs"       the other BASELINE.json configs measured after the timed region (rank 0, N == 1)
 """
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -31,7 +44,33 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy ceiling)
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+# kernel-name substrings and the sources whose hash ties a PMC pass to the kernels it measured (tools/pmc_traffic.py)
+CLASS_KERNELS = {
+    "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic"),
+    "hessian": ("k_hessian_stream", "k_hessian_fused"),
+    "prologue": ("k_base_stream", "k_base_a", "kf_base", "k_grad_hist_plane", "k_kcontrast2"),
+    "describe": ("k_describe", "k_orient"),
+    "nms": ("k_nms_cand", "k_row_scan", "k_emit", "k_clear_cand_maps"),
+    "match": ("k_match",),
+}
+CLASS_SOURCES = {
+    "fed": ("kernels_fed.hip", "kernels_fedsf.hip", "fed_common.h"),
+    "hessian": ("kernels_hessian_stream.hip", "kernels_hessian.hip", "fed_common.h"),
+    "prologue": ("kernels_base_stream.hip", "kernels_base.hip", "fed_common.h"),
+    "describe": ("kernels_describe.hip",),
+    "nms": ("kernels_detect.hip",),
+    "match": ("kernels_match.hip",),
+}
+
+
+def class_source_hash(klass):
+    h = hashlib.sha256()
+    for f in CLASS_SOURCES[klass]:
+        with open(os.path.join(ROOT, "cuda-akaze_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def shard_pairs(total_pairs, world, rank):
@@ -41,48 +80,283 @@ def shard_pairs(total_pairs, world, rank):
     return lo, min(lo + per, total_pairs)
 
 
-def cpu_baseline(w, h, p, u8_pairs, budget_s=20.0):
-    """the oracle (CPU port of the reference algorithm, OpenMP) on the same 1080p pairs"""
-    # the GPU box gives one GPU a 16-core CPU share; an OpenMP team per hardware thread (256 here)
-    # only oversubscribes it.  Must be set before libgomp initialises (first oracle call).
-    cores = min(16, os.cpu_count() or 1)
+def max_over_ranks(elapsed, device, use_dist):
+    """the step time of the job is the slowest rank's"""
+    if not use_dist:
+        return float(elapsed)
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_summary(pairs, keypoints, matches, device, use_dist):
+    """the trivial result gather: per-rank {pairs, keypoints, matches} summed over ranks"""
+    summary = torch.tensor([int(pairs), int(keypoints), int(matches)], dtype=torch.int64, device=device)
+    if use_dist:
+        allsum = [torch.zeros_like(summary) for _ in range(dist.get_world_size())]
+        dist.all_gather(allsum, summary)
+        summary = torch.stack(allsum).sum(0)
+    return summary.cpu().tolist()
+
+
+def fence(use_dist):
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+# --------------------------------------------------------------------------- CPU oracle legs (checker / baseline)
+def host_cores():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    # a GPU box gives one GPU a 16-core CPU share; an OpenMP team per hardware thread only oversubscribes it
+    return max(1, min(16, n))
+
+
+def oracle_setup():
+    """the oracle for this run: the committed build, or the same sources compiled for this host when a compiler is here.
+    OMP_NUM_THREADS must be set before libgomp initialises (first oracle call)."""
+    cores = host_cores()
     os.environ["OMP_NUM_THREADS"] = str(cores)
     import okz
-    from akaze_hip import synth
     okz.build()
-    imgs = [(synth.to_float(a, p), synth.to_float(b, p)) for a, b in u8_pairs]
-    n, t0 = 0, time.time()
-    # warm-up pair (page-in, OpenMP pool)
-    okz.detect_and_compute(imgs[0][0], w)
-    t0 = time.time()
-    while True:
-        a, b = imgs[n % len(imgs)]
-        r1 = okz.detect_and_compute(a, w)
-        r2 = okz.detect_and_compute(b, w)
+    tmp = os.environ.get("TMPDIR", "/tmp")
+    native = okz.build_native(tmp)
+    if native:
+        okz.load(native)
+    return okz, cores, ("-O3 -march=native" if native else "-O2 (committed build)")
+
+
+def oracle_pairs(okz, synth, u8_pairs, w, p, max_pts, npairs):
+    """oracle results [(pts1 with match fields, pts2)] of the first npairs pairs + per-pair (detect_s, match_s)"""
+    out, times = [], []
+    for a, b in u8_pairs[:npairs]:
+        t0 = time.perf_counter()
+        r1 = okz.detect_and_compute(synth.to_float(a, p), w, max_pts=max_pts)
+        r2 = okz.detect_and_compute(synth.to_float(b, p), w, max_pts=max_pts)
+        t1 = time.perf_counter()
         okz.match(r1.points, r2.points)
-        n += 1
-        el = time.time() - t0
-        if el > budget_s or n >= 40:
+        t2 = time.perf_counter()
+        out.append((r1.points, r2.points))
+        times.append((t1 - t0, t2 - t1))
+    return out, times
+
+
+def verify_batch(want, pts, counts):
+    """byte-for-byte comparison of the timed batch's first images with the oracle"""
+    fields_kp = ("x", "y", "octave", "response", "size", "angle", "features")
+    fields_m = ("match", "distance", "match_x", "match_y")
+    pts_ok, m_ok = True, True
+    for k, (o1, o2) in enumerate(want):
+        for j, o in enumerate((o1, o2)):
+            i = 2 * k + j
+            g = pts[i, :counts[i]]
+            if counts[i] != len(o):
+                pts_ok = False
+                continue
+            for f in fields_kp:
+                pts_ok &= g[f].tobytes() == o[f].tobytes()
+            if j == 0:
+                for f in fields_m:
+                    m_ok &= g[f].tobytes() == o[f].tobytes()
+    return {"images": 2 * len(want), "points_equal": bool(pts_ok), "matches_equal": bool(m_ok),
+            "checker": "CPU oracle (oracle/akaze_oracle.c) on the same seeded pairs, all 104-byte fields"}
+
+
+def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times, budget_s=25.0):
+    """median pairs/s of the oracle over >= 10 pairs (after the warm-up pairs already run for the verification)"""
+    times = list(first_times[1:])                 # the very first pair paid page-in and the OpenMP pool start-up
+    t_start = time.perf_counter()
+    k = 0
+    while len(times) < 10 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
+        _, t = oracle_pairs(okz, synth, [u8_pairs[k % len(u8_pairs)]], w, p, max_pts, 1)
+        times += t
+        k += 1
+        if time.perf_counter() - t_start > 4 * budget_s:
             break
-    return {"value": round(n / el, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{n} synthetic 1920x1080 pairs (detect+describe both images + match), {el:.1f} s, OpenMP oracle"}
+    det = statistics.median(t[0] for t in times)
+    mat = statistics.median(t[1] for t in times)
+    tot = statistics.median(t[0] + t[1] for t in times)
+    return {"value": round(1.0 / tot, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "detect_ms_per_pair": round(det * 1e3, 2), "match_ms_per_pair": round(mat * 1e3, 2),
+            "sample": f"median of {len(times)} synthetic {w}-px-wide pairs (detect+describe both images, then match), "
+                      f"OpenMP oracle built {flags}; OpenCV's cv::AKAZE (main.cpp:344-399) is not installed in this image"}
 
 
+# --------------------------------------------------------------------------- GPU-side helpers
+class Pipeline:
+    """NCTX contexts used round-robin: while batch i runs on the GPU, batch i-1 is synchronised and downloaded"""
+
+    def __init__(self, ah, w, h, p, nimg, max_pts, nctx, octaves=4, upright=False, serial=False, torch_stream=True):
+        self.ah, self.nimg, self.max_pts, self.h, self.p = ah, nimg, max_pts, h, p
+        self.dets, self.d_pts, self.d_num, self.h_pts, self.h_num = [], [], [], [], []
+        for k in range(nctx):
+            dk = ah.Akazer()
+            dk.init((w, h, p), noctaves=octaves, max_pts=max_pts, batch=nimg, upright=bool(upright))
+            if k == 0 and torch_stream:
+                ah.check(ah.lib.hak_set_stream(dk.ctx, C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            if serial:
+                ah.check(ah.lib.hak_set_concurrency(dk.ctx, 0))
+            self.dets.append(dk)
+            self.d_pts.append(torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda"))
+            self.d_num.append(torch.zeros(nimg, dtype=torch.int32, device="cuda"))
+            hp, hn = C.c_void_p(), C.c_void_p()
+            ah.check(ah.lib.hak_host_alloc(C.byref(hp), nimg * max_pts * 104))
+            ah.check(ah.lib.hak_host_alloc(C.byref(hn), nimg * 4))
+            self.h_pts.append(hp)
+            self.h_num.append(hn)
+        self.nctx = nctx
+
+    def enqueue(self, k, d_imgs, npairs=None, fast=False):
+        """detect + describe on 2*npairs images + match of the npairs pairs (default: the whole batch)"""
+        ah = self.ah
+        n = self.nimg if npairs is None else 2 * npairs
+        fn = ah.lib.hak_fast_detect_and_compute_batch if fast else ah.lib.hak_detect_and_compute_batch
+        ah.check(fn(self.dets[k].ctx, d_imgs.data_ptr(), self.h * self.p, self.p, n, self.d_pts[k].data_ptr(), self.d_num[k].data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(self.dets[k].ctx, self.d_pts[k].data_ptr(), self.d_num[k].data_ptr(), n // 2))
+
+    def download(self, k, npairs=None):
+        n = self.nimg if npairs is None else 2 * npairs
+        self.ah.check(self.ah.lib.hak_download_batch(self.dets[k].ctx, self.d_pts[k].data_ptr(), self.d_num[k].data_ptr(), n,
+                                                     self.h_pts[k], self.h_num[k]))
+
+    def run(self, jobs, pre=None):
+        """jobs = list of (d_imgs, npairs); every job's results are host-visible when run() returns"""
+        n, N = len(jobs), self.nctx
+        for i, (imgs, npairs) in enumerate(jobs):
+            if pre:
+                pre(i % N)
+            self.enqueue(i % N, imgs, npairs)
+            if i >= N - 1:
+                j = i - (N - 1)
+                self.download(j % N, jobs[j][1])
+        for j in range(max(0, n - (N - 1)), n):
+            self.download(j % N, jobs[j][1])
+
+    def results(self, k):
+        counts = np.ctypeslib.as_array(C.cast(self.h_num[k], C.POINTER(C.c_int)), shape=(self.nimg,)).copy()
+        pts = np.ctypeslib.as_array(C.cast(self.h_pts[k], C.POINTER(C.c_uint8)),
+                                    shape=(self.nimg * self.max_pts * 104,)).view(self.ah.POINT_DTYPE).reshape(self.nimg, self.max_pts)
+        return counts, pts
+
+    def close(self):
+        for k in range(self.nctx):
+            self.ah.lib.hak_host_free(self.h_pts[k])
+            self.ah.lib.hak_host_free(self.h_num[k])
+            self.dets[k].close()
+        self.d_pts, self.d_num = [], []
+
+
+def fit_batch(B, w, h, max_pts, nctx, floor=16):
+    # arena ~ 19 float planes per octave pyramid + key map + candidate list ~ 31 B/px x 4/3 per image and context
+    # (250 MB at 1080p): 128 pairs x 2 contexts = 127 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
+    free_b = torch.cuda.mem_get_info()[0]
+    while B > floor and 2 * B * (w * h * 125 + 2 * max_pts * 104) * nctx > 0.8 * free_b:
+        B //= 2
+    return B
+
+
+def timed_throughput(pipe, d_imgs, B, steps, warmup):
+    jobs = [(d_imgs, B)]
+    pipe.run(jobs * warmup)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    pipe.run(jobs * steps)
+    torch.cuda.synchronize()
+    return B * steps / (time.perf_counter() - t0)
+
+
+def other_configs(ah, synth, args, rank):
+    """BASELINE.json configs[1] as a single pair, configs[2], configs[3]'s shape on one GPU, configs[4]; never `value`"""
+    out = {}
+    max_pts = 10000
+    # ---- configs[1] literally: ONE 1080p pair at a time, synchronous calls like the reference demo (main.cpp:199-209)
+    w, h = 1920, 1080
+    p = ah.iAlignUp(w, 128)
+    a, b = synth.pair(w, h, 1)
+    d1 = torch.from_numpy(synth.to_float(a, p)).cuda()
+    d2 = torch.from_numpy(synth.to_float(b, p)).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=max_pts)
+    r1, r2 = ah.AkazeData(), ah.AkazeData()
+    ah.initAkazeData(r1, max_pts, True, True)
+    ah.initAkazeData(r2, max_pts, True, True)
+    lat = []
+    for i in range(25):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        det.detectAndCompute(d1.data_ptr(), r1, (w, h, p), True)
+        det.detectAndCompute(d2.data_ptr(), r2, (w, h, p), True)
+        ah.cuMatch(r1, r2, det)
+        if i >= 5:
+            lat.append((time.perf_counter() - t0) * 1e3)
+    out["single_pair_latency_ms"] = round(statistics.median(lat), 3)
+    out["single_pair_keypoints"] = [r1.num_pts, r2.num_pts]
+    ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
+    del d1, d2
+    # ---- configs[2]: 3840x2160, 5 octaves, MLDB-upright
+    w, h = 3840, 2160
+    p = ah.iAlignUp(w, 128)
+    B = fit_batch(16, w, h, max_pts, 2, floor=2)
+    pr = synth.pair(w, h, 2, nshapes=700)
+    d = torch.from_numpy(np.stack([synth.to_float(pr[i % 2], p) for i in range(2 * B)])).cuda()
+    pipe = Pipeline(ah, w, h, p, 2 * B, max_pts, 2, octaves=5, upright=True, torch_stream=False)
+    out["pairs_per_s_4k_5oct_upright"] = round(timed_throughput(pipe, d, B, 3, 1), 1)
+    counts, _ = pipe.results(0)
+    out["keypoints_per_image_4k"] = round(float(counts.mean()), 1)
+    pipe.close(); del d, pipe
+    # ---- configs[3]'s shape on this GPU: a batch of 64 independent 1280x720 pairs per step
+    w, h = 1280, 720
+    p = ah.iAlignUp(w, 128)
+    prs = [synth.pair(w, h, 3 + i) for i in range(4)]
+    d = torch.from_numpy(np.stack([synth.to_float(prs[(i // 2) % 4][i % 2], p) for i in range(128)])).cuda()
+    pipe = Pipeline(ah, w, h, p, 128, max_pts, 2, torch_stream=False)
+    out["pairs_per_s_720p_batch64"] = round(timed_throughput(pipe, d, 64, 6, 2), 1)
+    pipe.close(); del d, pipe
+    # ---- configs[4]: 10k x 10k brute-force Hamming (k_match), HIP events around 20 launches
+    n = 10000
+    q = synth.random_descriptors(n, 7, ah.POINT_DTYPE)
+    t = synth.random_descriptors(n, 8, ah.POINT_DTYPE, planted_from=q, nplanted=4000)
+    dq = torch.from_numpy(q.view(np.uint8).copy()).cuda()
+    dt = torch.from_numpy(t.view(np.uint8).copy()).cuda()
+    for _ in range(3):
+        ah.check(ah.lib.hak_match(None, dq.data_ptr(), n, dt.data_ptr(), n, None))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ah.check(ah.lib.hak_match(None, dq.data_ptr(), n, dt.data_ptr(), n, None))     # synchronous (cuMatch contract)
+    ms = (time.perf_counter() - t0) * 1e3 / 20
+    # SURVEY 8d floor: 1e8 pairs x 8 popcll+add+xor ~ 24 VALU lane-ops per pair / (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
+    floor_ms = 1e8 * 24 / (256 * 4 * 32 * 2.4e9) * 1e3
+    out["match_10k_ms"] = round(ms, 4)
+    out["match_10k_valu_floor_ms"] = round(floor_ms, 4)
+    out["match_10k_frac_of_floor"] = round(floor_ms / ms, 4)
+    return out
+
+
+# --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per step (batch); halved until the arenas fit the free HBM")
+    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="strong scaling: this many pairs per step over ALL ranks (rank r takes shard_pairs), in batches of --pairs")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--octaves", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the oracle comparison of the timed batch")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs measured after the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="one context: no overlap between consecutive steps")
     ap.add_argument("--pipeline", type=int, default=2, help="contexts used round-robin (batches in flight)")
     ap.add_argument("--upload", action="store_true",
-                    help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path")
+                    help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path (default on for N > 1)")
     ap.add_argument("--fast", action="store_true",
                     help="also time the integer FAST path (fastDetectAndCompute, uint8 inputs) on the same pairs")
     ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
@@ -112,215 +386,202 @@ def main():
 
     w, h = args.width, args.height
     p = ah.iAlignUp(w, 128)
-    B = args.pairs
     max_pts = 10000
-    # arena ~ 19 float planes per octave pyramid + key map + candidate list ~ 31 B/px x 4/3 per image and context
-    # (250 MB at 1080p): 128 pairs x 2 contexts = 127 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
-    free_b = torch.cuda.mem_get_info()[0]
-    while B > 16 and 2 * B * (w * h * 125 + 2 * max_pts * 104) * (1 if args.no_pipeline else max(1, args.pipeline)) > 0.8 * free_b:
-        B //= 2
+    NCTX = 1 if args.no_pipeline else max(1, args.pipeline)
+    B = fit_batch(args.pairs, w, h, max_pts, NCTX)
+    strong = args.total_pairs > 0
+    if strong:
+        lo, hi = shard_pairs(args.total_pairs, world, rank)
+        my_pairs = hi - lo
+        B = max(1, min(B, my_pairs)) if my_pairs else 1
+        chunks = [min(B, my_pairs - c) for c in range(0, my_pairs, B)]          # pairs per launch sequence of one step
+    else:
+        lo, my_pairs, chunks = rank * B, B, [B]
     nimg = 2 * B
 
-    # ---- synthetic inputs, resident in HBM (2 distinct seeded pairs per rank, cycled over the batch)
-    u8_pairs = [synth.pair(w, h, 1 + 2 * rank + i) for i in range(2)]
-    host = np.stack([synth.to_float(u8_pairs[(i // 2) % 2][i % 2], p) for i in range(nimg)])
+    # ---- synthetic inputs, resident in HBM: 8 distinct seeded pairs per rank, cycled over the batch
+    NDIST = 8
+    u8_pairs = [synth.pair(w, h, 1 + NDIST * rank + i) for i in range(NDIST)]
+    host = np.stack([synth.to_float(u8_pairs[(i // 2) % NDIST][i % 2], p) for i in range(nimg)])
     d_imgs = torch.from_numpy(host).cuda()
     del host
 
-    # two contexts, used alternately: while batch i runs on the GPU, batch i-1 is synchronised and downloaded
-    # (every step's work still completes inside the timed bracket)
-    NCTX = 1 if args.no_pipeline else max(1, args.pipeline)
-    dets, d_pts_l, d_num_l, h_pts_l, h_num_l = [], [], [], [], []
-    stream = torch.cuda.current_stream()
-    for k in range(NCTX):
-        dk = ah.Akazer()
-        dk.init((w, h, p), noctaves=args.octaves, max_pts=max_pts, batch=nimg, upright=bool(args.upright))
-        if k == 0:
-            ah.check(ah.lib.hak_set_stream(dk.ctx, C.c_void_p(stream.cuda_stream)))
-        if args.serial:
-            ah.check(ah.lib.hak_set_concurrency(dk.ctx, 0))
-        dets.append(dk)
-        d_pts_l.append(torch.zeros(nimg * max_pts * 104, dtype=torch.uint8, device="cuda"))
-        d_num_l.append(torch.zeros(nimg, dtype=torch.int32, device="cuda"))
-        hp, hn = C.c_void_p(), C.c_void_p()
-        ah.check(ah.lib.hak_host_alloc(C.byref(hp), nimg * max_pts * 104))
-        ah.check(ah.lib.hak_host_alloc(C.byref(hn), nimg * 4))
-        h_pts_l.append(hp)
-        h_num_l.append(hn)
-    det, d_pts, d_num, h_pts, h_num = dets[0], d_pts_l[0], d_num_l[0], h_pts_l[0], h_num_l[0]
+    pipe = Pipeline(ah, w, h, p, nimg, max_pts, NCTX, octaves=args.octaves, upright=args.upright, serial=args.serial)
+    step_jobs = [(d_imgs, c) for c in chunks]
 
-    def enqueue(k):
-        ah.check(ah.lib.hak_detect_and_compute_batch(dets[k].ctx, d_imgs.data_ptr(), h * p, p, nimg,
-                                                     d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), 1))
-        ah.check(ah.lib.hak_match_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), B))
-
-    def download(k):
-        ah.check(ah.lib.hak_download_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), nimg,
-                                           h_pts_l[k], h_num_l[k]))
-
-    def run_steps(n):
-        """n steps = n batches through detect + describe + match + download"""
-        for i in range(n):
-            enqueue(i % NCTX)
-            if i >= NCTX - 1:
-                download((i - (NCTX - 1)) % NCTX)
-        for i in range(max(0, n - (NCTX - 1)), n):          # drain the batches still in flight
-            download(i % NCTX)
-
-    def step():
-        enqueue(0)
-        download(0)
-
-    def fence():
-        torch.cuda.synchronize()
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_steps(args.warmup)
-    fence()
+    pipe.run(step_jobs * args.warmup)
+    fence(use_dist)
     t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    pipe.run(step_jobs * args.steps)
+    fence(use_dist)
+    elapsed = max_over_ranks(time.perf_counter() - t0, "cuda", use_dist)
+    last_ctx = (len(step_jobs) * args.steps - 1) % NCTX if step_jobs else 0
+    counts, pts = pipe.results(last_ctx)
+    counts, pts = counts.copy(), pts.copy()
+    last_pairs = chunks[-1] if chunks else 0
 
-    # ---- optional: PCIe-inclusive rate (never `value`): pinned uint8 batch -> H2D -> hak_ingest_u8 -> same steps
+    # ---- PCIe-inclusive rate (never `value`): pinned uint8 batch -> H2D -> hak_ingest_u8 -> same steps
     upload_rate = None
-    if args.upload:
-        h_u8 = torch.from_numpy(np.stack([u8_pairs[(i // 2) % 2][i % 2] for i in range(nimg)])).pin_memory()
+    if (args.upload or world > 1) and my_pairs:
+        h_u8 = torch.from_numpy(np.stack([u8_pairs[(i // 2) % NDIST][i % 2] for i in range(nimg)])).pin_memory()
         d_u8 = torch.empty_like(h_u8, device="cuda")
 
-        def up_step(k):
+        def up(k):
             d_u8.copy_(h_u8, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            ah.check(ah.lib.hak_ingest_u8(dets[k].ctx, d_u8.data_ptr(), h * w, w, d_imgs.data_ptr(), h * p, p, w, h, nimg))
-            enqueue(k)
-        for i in range(2):
-            up_step(i % NCTX); download(i % NCTX)
-        fence()
+            ah.check(ah.lib.hak_ingest_u8(pipe.dets[k].ctx, d_u8.data_ptr(), h * w, w, d_imgs.data_ptr(), h * p, p, w, h, nimg))
+        pipe.run(step_jobs * 2, pre=up)
+        fence(use_dist)
         tu = time.perf_counter()
-        for i in range(args.steps):
-            up_step(i % NCTX)
-            if i >= NCTX - 1:
-                download((i - (NCTX - 1)) % NCTX)
-        for i in range(max(0, args.steps - (NCTX - 1)), args.steps):
-            download(i % NCTX)
-        fence()
-        upload_rate = world * B * args.steps / (time.perf_counter() - tu)
+        pipe.run(step_jobs * args.steps, pre=up)
+        fence(use_dist)
+        el_u = max_over_ranks(time.perf_counter() - tu, "cuda", use_dist)
+        upload_rate = (args.total_pairs if strong else world * B) * args.steps / el_u
+        del h_u8, d_u8
 
     # ---- optional: the integer FAST path on the same pairs (secondary figure, never `value`)
     fast_rate = None
-    if args.fast:
-        d_fu8 = torch.from_numpy(np.stack([np.pad(u8_pairs[(i // 2) % 2][i % 2], ((0, 0), (0, p - w))) for i in range(nimg)])).cuda()
+    if args.fast and my_pairs:
+        d_fu8 = torch.from_numpy(np.stack([np.pad(u8_pairs[(i // 2) % NDIST][i % 2], ((0, 0), (0, p - w))) for i in range(nimg)])).cuda()
 
-        def fast_enqueue(k):
-            ah.check(ah.lib.hak_fast_detect_and_compute_batch(dets[k].ctx, d_fu8.data_ptr(), h * p, p, nimg,
-                                                              d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), 1))
-            ah.check(ah.lib.hak_match_batch(dets[k].ctx, d_pts_l[k].data_ptr(), d_num_l[k].data_ptr(), B))
-        for i in range(2):
-            fast_enqueue(i % NCTX); download(i % NCTX)
-        fence()
+        def fast_run(n):
+            jobs = step_jobs * n
+            for i, (_, c) in enumerate(jobs):
+                pipe.enqueue(i % NCTX, d_fu8, c, fast=True)
+                if i >= NCTX - 1:
+                    j = i - (NCTX - 1)
+                    pipe.download(j % NCTX, jobs[j][1])
+            for j in range(max(0, len(jobs) - (NCTX - 1)), len(jobs)):
+                pipe.download(j % NCTX, jobs[j][1])
+        fast_run(2)
+        fence(use_dist)
         tf = time.perf_counter()
-        for i in range(args.steps):
-            fast_enqueue(i % NCTX)
-            if i >= NCTX - 1:
-                download((i - (NCTX - 1)) % NCTX)
-        for i in range(max(0, args.steps - (NCTX - 1)), args.steps):
-            download(i % NCTX)
-        fence()
-        fast_rate = world * B * args.steps / (time.perf_counter() - tf)
-        enqueue(0); download(0)                      # leave the float results in the host buffers for the summary
-        fence()
+        fast_run(args.steps)
+        fence(use_dist)
+        fast_rate = (args.total_pairs if strong else world * B) * args.steps / max_over_ranks(time.perf_counter() - tf, "cuda", use_dist)
+        del d_fu8
 
-    counts = np.ctypeslib.as_array(C.cast(h_num, C.POINTER(C.c_int)), shape=(nimg,)).copy()
-    pts = np.ctypeslib.as_array(C.cast(h_pts, C.POINTER(C.c_uint8)), shape=(nimg * max_pts * 104,)).view(ah.POINT_DTYPE).reshape(nimg, max_pts)
-    nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(B)))
-    # ---- the trivial result gather (SURVEY 8e): per-rank summary {pairs, keypoints, matches}
-    summary = torch.tensor([B, int(counts.sum()), nmatch], dtype=torch.int64, device="cuda")
-    if use_dist:
-        allsum = [torch.zeros_like(summary) for _ in range(world)]
-        dist.all_gather(allsum, summary)
-        summary = torch.stack(allsum).sum(0)
-    summary = summary.cpu().tolist()
+    nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(last_pairs)))
+    nkp = int(counts[:2 * last_pairs].sum())
+    summary = gather_summary(last_pairs, nkp, nmatch, "cuda", use_dist)
 
-    # ---- roofline leg: same steps with per-launch HIP events on the launch stream
+    # ---- roofline leg: the same launch sequence strictly serially on one stream with per-launch HIP events
+    # (per-kernel durations are only meaningful without overlap; the timed region overlaps the octaves on separate streams)
     roof = None
-    if not args.no_roofline:
-        # per-kernel durations are only meaningful without overlap: the roofline leg runs the same steps
-        # strictly serially on one stream (the timed region above overlaps the octaves on separate streams)
+    if not args.no_roofline and my_pairs and rank == 0:
+        det = pipe.dets[0]
         ah.check(ah.lib.hak_set_concurrency(det.ctx, 0))
         ah.check(ah.lib.hak_prof_reset(det.ctx))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
         for _ in range(nprof):
-            step()
-        ms, n = C.c_double(), C.c_int()
-        ah.check(ah.lib.hak_prof_read(det.ctx, ah.PROF["fed"], C.byref(ms), C.byref(n)))
-        ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
-        tr = det.traffic(int(counts.mean()))
-        bytes_per_launch = tr.fed_bytes * nimg / tr.fed_launches          # algorithmic bytes (hipakaze.h hak_traffic) x images / launches
-        avg_s = ms.value * 1e-3 / n.value
-        achieved = bytes_per_launch / avg_s / 1e9
-        cls = {}
+            pipe.enqueue(0, d_imgs, chunks[0])
+            pipe.download(0, chunks[0])
+        cls_ms, cls_n = {}, {}
         for name, k in ah.PROF.items():
             m2, n2 = C.c_double(), C.c_int()
             ah.check(ah.lib.hak_prof_read(det.ctx, k, C.byref(m2), C.byref(n2)))
-            cls[name] = round(m2.value / nprof, 4)
-        # HBM bytes per FED launch from the PMC passes committed under profiles/ (tools/pmc_traffic.py:
-        # separate FETCH_SIZE / WRITE_SIZE passes, gfx950 FETCH x2 correction); null when not measured
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tfile) and (w, h, args.octaves) == (1920, 1080, 4):
-            # every FED launch covers the whole batch, so bytes scale with B relative to the batch the passes ran at
-            tj = json.load(open(tfile))
-            traffic = round(tj["fed_hbm_bytes_per_launch"] * B / float(tj.get("pairs_per_launch_sequence", 16)))
-        roof = {"kernel": "k_fed_sf<NS> / k_fed_multi<NS> (FED steps 12 B/px/step; +16 B/px where the sublevel's low-pass and "
-                          "conductivity run inside its first FED launch)", "bound": "hbm",
-                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                # the same launches priced by their measured HBM traffic instead of the unfused byte model: frac > 1 above means
-                # fusion removed traffic, this one says how close the remaining traffic runs to the HBM peak
+            cls_ms[name], cls_n[name] = m2.value / nprof, n2.value // nprof
+        ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
+        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0 if args.serial else 1))
+        tr = det.traffic(int(round(nkp / max(1, 2 * last_pairs))))
+        nim = 2 * chunks[0]
+        gb = C.c_double()
+        ah.check(ah.lib.hak_op_copy_probe(2 << 30, 10, C.byref(gb)))           # 2 GiB source + 2 GiB destination, far beyond the caches
+        copy_gbs = gb.value
+        # PMC passes (tools/pmc_traffic.py): bytes per launch sequence of `pmc_pairs` pairs, valid only for the sources they ran on
+        pmc = {}
+        if os.path.exists(PMC_FILE) and (w, h, args.octaves) == (1920, 1080, 4):
+            tj = json.load(open(PMC_FILE))
+            for k, v in tj.get("classes", {}).items():
+                if v.get("source_sha") == class_source_hash(k):
+                    pmc[k] = v["hbm_bytes_per_sequence"] * nim / float(2 * tj["pairs_per_launch_sequence"])
+        algo = {"fed": tr.fed_fused_bytes, "hessian": tr.hessian_bytes, "prologue": tr.prologue_bytes,
+                "describe": tr.describe_bytes, "nms": tr.nms_bytes, "match": None}
+        prof_of = {"fed": ("fed",), "hessian": ("hessian",), "prologue": ("contrast",), "describe": ("describe",), "nms": ("nms",),
+                   "match": ("match",)}
+        classes = []
+        for k in ("fed", "hessian", "describe", "prologue", "nms", "match"):
+            ms = sum(cls_ms[c] for c in prof_of[k])
+            ab = None if algo[k] is None else algo[k] * nim
+            row = {"class": k, "ms": round(ms, 4), "launches": sum(cls_n[c] for c in prof_of[k]),
+                   "algorithmic_bytes": None if ab is None else round(ab), "pmc_bytes": None if k not in pmc else round(pmc[k]),
+                   "frac_peak": None if ab is None or ms <= 0 else round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "frac_copy": None if ab is None or ms <= 0 else round(ab / (ms * 1e-3) / 1e9 / copy_gbs, 4),
+                   "pmc_frac_peak": None if k not in pmc or ms <= 0 else round(pmc[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            classes.append(row)
+        other_ms = sum(cls_ms[c] for c in ("lowpass", "flow", "down", "extrema"))
+        fed_ms, fed_n = cls_ms["fed"], max(1, cls_n["fed"])
+        avg_s = fed_ms * 1e-3 / fed_n
+        bytes_per_launch = tr.fed_fused_bytes * nim / fed_n
+        achieved = bytes_per_launch / avg_s / 1e9
+        traffic = None if "fed" not in pmc else pmc["fed"] / fed_n
+        unfused_GBs = tr.fed_bytes * nim / fed_n / avg_s / 1e9
+        total_pairs_timed = (args.total_pairs if strong else world * B) * args.steps
+        roof = {"kernel": "FED family k_fed_sf<NS> / k_fed_multi<NS>: NS <= 4 explicit steps per launch (k_fed_sf also the sublevel's "
+                          "low-pass and conductivity); bytes = read L (+ g), write L' (+ smooth, + g) of every launch",
+                "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None if traffic is None else round(traffic),
                 "traffic_GBs": None if traffic is None else round(traffic / avg_s / 1e9, 1),
                 "traffic_frac": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
+                "copy_ceiling_GBs": round(copy_gbs, 1), "frac_copy": round(achieved / copy_gbs, 4),
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
-                "launches_per_step": tr.fed_launches, "ms_per_step_by_class": cls,
-                # SURVEY 8d: end-to-end achieved = all-stage algorithmic bytes per image x images/s of the timed region
-                "end_to_end": {"all_stage_bytes_per_image": round(tr.all_stage_bytes),
-                               "achieved_GBs": round(tr.all_stage_bytes * 2.0 * world * B * args.steps / elapsed / 1e9, 1),
-                               "frac_of_peak": round(tr.all_stage_bytes * 2.0 * world * B * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 4)},
-                "mode": "serial leg (one stream); rocprof counterpart: profiles/*_serial_kernel_stats.csv from `bench.py --serial`"}
+                "launches_per_step": fed_n,
+                # the unfused model of SURVEY 8d (12 B/px per STEP + 16 B/px of low-pass and conductivity) priced at the same time:
+                # how much HBM traffic temporal fusion removed -- a gain, not a utilisation
+                "unfused_model_GBs": round(unfused_GBs, 1), "fusion_gain": round(tr.fed_bytes / tr.fed_fused_bytes, 3),
+                "classes": classes, "other_classes_ms": round(other_ms, 4),
+                "serial_ms_per_step": round(sum(cls_ms.values()), 3),
+                "end_to_end": {"all_stage_bytes_per_image_unfused_model": round(tr.all_stage_bytes),
+                               "unfused_model_GBs": round(tr.all_stage_bytes * 2.0 * total_pairs_timed / elapsed / 1e9, 1)},
+                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r02_*_serial_kernel_stats.csv"}
 
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(w, h, p, u8_pairs)
+    # ---- the oracle legs: verification of the timed batch, then the CPU baseline (rank 0)
+    verified, cpu = None, None
+    if rank == 0 and my_pairs and not args.no_verify:
+        okz, cores, flags = oracle_setup()
+        nver = min(2, last_pairs)
+        if args.octaves != 4 or args.upright:
+            verified = {"images": 0, "note": "verification covers the default configuration only"}
+        else:
+            want, first_times = oracle_pairs(okz, synth, u8_pairs, w, p, max_pts, nver)
+            verified = verify_batch(want, pts, counts)
+            if world == 1 and not args.no_cpu_baseline and (w, h) == (1920, 1080):
+                cpu = cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times)
+
+    pipe.close()
+    del d_imgs
+    extra = None
+    if rank == 0 and world == 1 and not args.no_configs and not strong and (w, h, args.octaves) == (1920, 1080, 4):
+        torch.cuda.empty_cache()
+        extra = other_configs(ah, synth, args, rank)
 
     if rank == 0:
-        total_pairs = world * B * args.steps
+        total_pairs = (args.total_pairs if strong else world * B) * args.steps
         out = {
             "metric": "pairs_per_sec_detect_describe_match_1080p", "value": round(total_pairs / elapsed, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"configs[1]: {w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
-                       "pairs_per_step_per_gpu": B, "octave_streams": "serial" if args.serial else "concurrent", "step_pipeline": NCTX, "sharding": "independent pairs per rank, no data-path collective",
-                       "keypoints_per_image": round(summary[1] / (2.0 * summary[0]), 1),
-                       "matches_per_pair": round(summary[2] / float(summary[0]), 1)},
-            "roofline": roof, "cpu_baseline": cpu,
+                       "pairs_per_step_per_gpu": my_pairs if strong else B, "pairs_per_launch_sequence": B,
+                       "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
+                       "octave_streams": "serial" if args.serial else "concurrent", "step_pipeline": NCTX,
+                       "sharding": "independent pairs per rank, no data-path collective",
+                       "keypoints_per_image": round(summary[1] / max(1.0, 2.0 * summary[0]), 1),
+                       "matches_per_pair": round(summary[2] / max(1.0, float(summary[0])), 1)},
+            "verified": verified, "roofline": roof, "cpu_baseline": cpu, "configs": extra,
             "upload_inclusive_pairs_per_s": None if upload_rate is None else round(upload_rate, 1),
             "fast_path_pairs_per_s": None if fast_rate is None else round(fast_rate, 1),
         }
         print(json.dumps(out))
-    for k in range(NCTX):
-        ah.lib.hak_host_free(h_pts_l[k])
-        ah.lib.hak_host_free(h_num_l[k])
-        dets[k].close()
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0 and verified and verified.get("images") and not (verified["points_equal"] and verified["matches_equal"]):
+        print("bench.py: the timed batch differs from the oracle", file=sys.stderr)
+        sys.exit(3)
 
 
 if __name__ == "__main__":

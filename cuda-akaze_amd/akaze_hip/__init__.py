@@ -59,7 +59,8 @@ class hak_config(C.Structure):
 
 class hak_traffic(C.Structure):
     _fields_ = [("fed_px_steps", C.c_double), ("fed_bytes", C.c_double), ("all_stage_bytes", C.c_double),
-                ("fed_launches", C.c_int)]
+                ("fed_launches", C.c_int), ("fed_fused_bytes", C.c_double), ("hessian_bytes", C.c_double),
+                ("prologue_bytes", C.c_double), ("describe_bytes", C.c_double), ("nms_bytes", C.c_double)]
 
 
 PROF = dict(fed=0, lowpass=1, flow=2, hessian=3, contrast=4, down=5, extrema=6, nms=7, describe=8, match=9)
@@ -114,6 +115,8 @@ SYMBOLS = {
     "hak_op_rcp_check": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     "hak_op_smooth_flow": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "hak_op_hessian": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hak_op_copy_probe": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_double)]),
+    "hak_op_gather_probe": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 
 if not os.path.exists(LIB_PATH):
@@ -241,8 +244,6 @@ class Akazer:
         w, h, p = whp0
         if self._ctx is None or self._ctx_wh != (w, h):       # akaze.cpp:109: size differs from init -> new arena
             self._make_ctx(w, h)
-        if result.max_pts < self._cfg.max_pts:
-            raise HakError("AkazeData smaller than the detector's max_pts")
         n = C.c_int(0)
         hptr = result.h_data.ctypes.data if result.h_data is not None else None
         check(lib.hak_detect_and_compute(self.ctx, image, p, result.d_data, result.max_pts, C.byref(n), hptr, int(desc)))
@@ -253,8 +254,6 @@ class Akazer:
         w, h, p = whp0
         if self._ctx is None or self._ctx_wh != (w, h):
             self._make_ctx(w, h)
-        if result.max_pts < self._cfg.max_pts:
-            raise HakError("AkazeData smaller than the detector's max_pts")
         n = C.c_int(0)
         hptr = result.h_data.ctypes.data if result.h_data is not None else None
         check(lib.hak_fast_detect_and_compute(self.ctx, image, p, result.d_data, result.max_pts, C.byref(n), hptr, int(desc)))

@@ -159,7 +159,7 @@ struct hak_ctx {
     bool concurrent = true;
     // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
     bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
-    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int conc; hipStream_t st; };
+    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; };
     static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
     hipGraphExec_t graph_exec[NGRAPH] = {};
     GraphKey gkey[NGRAPH] = {};
@@ -167,6 +167,7 @@ struct hak_ctx {
     bool prof_on = false;
     ProfClass prof[HAK_PROF_COUNT];
     int fed_launches = 0;
+    double fed_fused_bytes = 0;     // compulsory HBM bytes per image of the FED launches as enqueued (read L [+ g], write L' [+ smooth, g])
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
     int fuse_head = 1;              // octave heads through the decimating k_fed_sf variant (env HAK_FUSE_HEAD=0 disables)
     int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
@@ -203,6 +204,8 @@ static int build_plan(hak_ctx* c, int w, int h)
     if (cfg.noctaves < 1 || cfg.noctaves > HAK_MAX_OCTAVES) return fail("noctaves out of range");
     if (cfg.max_scale < 1 || cfg.max_scale > HAK_MAX_SCALES) return fail("max_scale out of range");
     if (w < 80 || h < 80) return fail("image smaller than 80 px");
+    // candidate entries pack full-resolution coordinates as (y << 16) | x (kernels_detect.hip, kernels_hessian*.hip)
+    if (w > 65535 || h > 65535) return fail("image larger than 65535 px in one dimension");
     HakLayout& L = c->L;
     memset(&L, 0, sizeof(L));
     L.ms = cfg.max_scale;
@@ -299,6 +302,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
     { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
     { const char* e = getenv("HAK_BASE_STREAM"); hak_base_stream_enabled = e ? atoi(e) : 1; }
+    { const char* e = getenv("HAK_HESS_CBUF"); const int v = e ? atoi(e) : 256; hak_hessian_cbuf_cap = v < 1 ? 1 : (v > 256 ? 256 : v); }
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
@@ -345,7 +349,9 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
 extern "C" void hak_destroy(hak_ctx* c)
 {
     if (!c) return;
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    // only the context's own streams: a caller-provided stream (hak_set_stream) may already have been destroyed by its
+    // owner; callers that used one must synchronise it themselves before destroying the context
+    if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (int o = 0; o < HAK_MAX_OCTAVES; o++) {
         if (c->oct_stream[o]) { (void)hipStreamSynchronize(c->oct_stream[o]); (void)hipStreamDestroy(c->oct_stream[o]); }
@@ -385,7 +391,7 @@ extern "C" int hak_sync(hak_ctx* c)
 
 // ------------------------------------------------------- the launch sequence
 static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                          hak_point* d_points, int* d_num_pts, int desc)
+                          hak_point* d_points, int* d_num_pts, int desc, int max_pts)
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
@@ -395,6 +401,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
     c->fed_launches = 0;
+    c->fed_fused_bytes = 0;
 
     hak_launch_reset_state(st, c->state, nimg);        // (the key map is all zero here: hak_create / k_clear_cand_maps)
     if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
@@ -434,7 +441,10 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                     fused_first = hak_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
                                                          nimg, c->taps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
                                                          c->state, o, G > 1);
-                    if (fused_first) c->fed_launches++;
+                    if (fused_first) {
+                        c->fed_launches++;       // reads the even rows of Lt(o-1,0), writes smooth, L' (+ g for later launches)
+                        c->fed_fused_bytes += 2.0 * L.oct[o - 1].w * L.oct[o - 1].h + (G > 1 ? 12.0 : 8.0) * oc.w * oc.h;
+                    }
                 }
                 // otherwise decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
                 float* first = (G % 2 == 0) ? Lt : tmp;
@@ -460,7 +470,10 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 ProfScope ps(c, HAK_PROF_FED, st);
                 fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
                                                 lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
-                if (fused_first) c->fed_launches++;
+                if (fused_first) {
+                    c->fed_launches++;           // reads L, writes smooth, L' (+ g for later launches)
+                    c->fed_fused_bytes += (G > 1 ? 16.0 : 12.0) * oc.w * oc.h;
+                }
             }
             if (s != 0 && !fused_first) {                                         // akaze.cpp:403-404 in one pass
                 ProfScope ps(c, HAK_PROF_LOWPASS, st);
@@ -478,6 +491,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                         ProfScope ps(c, HAK_PROF_FED, st);
                         hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
                         c->fed_launches++;
+                        c->fed_fused_bytes += 12.0 * oc.w * oc.h;   // reads L and g, writes L'
                     }
                     done += ns;
                     src = dst;
@@ -497,9 +511,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         for (int o = 1; o < L.noct; o++)
             if (hipStreamWaitEvent(st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
-      hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts); }
+      hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts); }
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
-      hak_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
+      hak_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     c->maps_dirty = false;
     return 0;
@@ -508,7 +522,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
 // ------------------------------------------------------- integer FAST path
 // Akazer::fastDetectAndCompute / fastDetect (akaze.cpp:153-201, 506-743): same orchestration on int32 planes.
 static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long image_stride, int pitch, int nimg,
-                               hak_point* d_points, int* d_num_pts, int desc)
+                               hak_point* d_points, int* d_num_pts, int desc, int max_pts)
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
@@ -587,8 +601,8 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             }
         }
     }
-    hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, cfg.max_pts, d_num_pts, 1);
-    hakf_launch_describe(st, b, L, c->dtab, d_points, cfg.max_pts, cfg.descriptor_pattern_size, cfg.upright, desc);
+    hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts, 1);
+    hakf_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc);
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     c->maps_dirty = false;
     return 0;
@@ -600,16 +614,16 @@ extern "C" int hak_fast_detect_and_compute_batch(hak_ctx* c, const unsigned char
     if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
     if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    return enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    return enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts);
 }
 
 extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_image, int pitch, hak_point* d_points, int max_pts,
                                            int* num_pts, hak_point* h_points, int desc)
 {
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
-    if (max_pts < c->cfg.max_pts) return fail("point array smaller than cfg.max_pts");
+    if (max_pts < 1) return fail("max_pts < 1");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    if (enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
+    if (enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts)) return 1;
     HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *num_pts = c->h_num[0];
@@ -620,14 +634,14 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
 
 // enqueue one detect+describe sequence: replay the captured graph when the arguments repeat, else capture it
 static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                      hak_point* d_points, int* d_num_pts, int desc)
+                      hak_point* d_points, int* d_num_pts, int desc, int max_pts)
 {
     if (!c->use_graph || c->prof_on)
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
     hak_ctx::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.img = d_images; key.stride = image_stride; key.pitch = pitch; key.nimg = nimg; key.pts = d_points;
-    key.num = d_num_pts; key.desc = desc; key.conc = c->concurrent ? 1 : 0; key.st = c->stream;
+    key.num = d_num_pts; key.desc = desc; key.max_pts = max_pts; key.conc = c->concurrent ? 1 : 0; key.st = c->stream;
     int slot = -1, victim = 0;
     for (int i = 0; i < hak_ctx::NGRAPH; i++) {
         if (c->graph_exec[i] && memcmp(&key, &c->gkey[i], sizeof(key)) == 0) slot = i;
@@ -644,9 +658,9 @@ static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int 
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         c->use_graph = false;                                   // e.g. legacy default stream: fall back to eager launches
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
     }
-    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -665,16 +679,16 @@ extern "C" int hak_detect_and_compute_batch(hak_ctx* c, const float* d_images, l
     if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
     if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    return run_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc);
+    return run_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts);
 }
 
 extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitch, hak_point* d_points, int max_pts,
                                       int* num_pts, hak_point* h_points, int desc)
 {
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
-    if (max_pts < c->cfg.max_pts) return fail("point array smaller than cfg.max_pts");
+    if (max_pts < 1) return fail("max_pts < 1");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc)) return 1;
+    if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts)) return 1;
     HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *num_pts = c->h_num[0];
@@ -936,6 +950,15 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
     out->fed_bytes = 12.0 * pxsteps + folded;
     out->all_stage_bytes = all;
     out->fed_launches = launches;
+    // per-class compulsory bytes of the launches AS BUILT (fused): what each class must move per image even with perfect
+    // reuse inside a launch.  The FED figure is accumulated by the launch sequence itself (valid after the first detect call).
+    out->fed_fused_bytes = c->fed_fused_bytes;
+    double lvl_px = 0;
+    for (int o = 0; o < L.noct; o++) lvl_px += (double)L.ms * L.oct[o].w * L.oct[o].h;
+    out->hessian_bytes = 16.0 * lvl_px;                                           // read smooth, write Lx, Ly, det
+    out->prologue_bytes = 16.0 * L.oct[0].w * L.oct[0].h;                         // read img, write Lt + gradient; re-read gradient (histogram)
+    out->describe_bytes = (872.0 + 5292.0) * npts_hint;                           // sampled bytes per keypoint (orientation + MLDB)
+    out->nms_bytes = 104.0 * npts_hint;
     return 0;
 }
 
@@ -1054,5 +1077,24 @@ extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, 
 {
     hak_launch_hessian_level(nullptr, s, lx, ly, det, 0, w, h, p, 1, step, nullptr, nullptr, nullptr, 0, 0, 0.f);
     HIP_TRY(hipDeviceSynchronize());
+    return 0;
+}
+
+extern "C" int hak_op_copy_probe(long bytes, int iters, double* gbytes_per_s)
+{
+    if (bytes < 16 || iters < 1 || !gbytes_per_s) return fail("bad probe argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    bytes &= ~15L;
+    double ms = 0;
+    if (hak_launch_copy_probe(bytes, iters, &ms) || ms <= 0) return fail("copy probe failed");
+    *gbytes_per_s = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;                      // read + write
+    return 0;
+}
+
+extern "C" int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch)
+{
+    if (bytes < 4096 || blocks < 1 || per_lane < 4 || iters < 1 || !ms_per_launch) return fail("bad probe argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    if (hak_launch_gather_probe(bytes & ~127L, blocks, per_lane & ~3, iters, ms_per_launch)) return fail("gather probe failed");
     return 0;
 }

@@ -213,6 +213,7 @@ static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
     return strips * ((h + 31) / 32) * nimg >= 2048;
 }
 extern int hak_hessian_stream_enabled;
+extern int hak_hessian_cbuf_cap;       // tile kernel: staged candidates per block (env HAK_HESS_CBUF, tests only)
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
@@ -302,6 +303,10 @@ void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L,
 // descriptors (kernels_describe.hip)
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
                          hak_point* points, int max_pts, int patsize, int upright, int desc);
+
+// bandwidth probes (kernels_probe.hip)
+int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy);
+int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
 
 // matcher (kernels_match.hip)
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,

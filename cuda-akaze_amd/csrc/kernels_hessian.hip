@@ -89,7 +89,7 @@ template <typename V, int S, bool INTERIOR>
 __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__ oy, V* __restrict__ od,
                                              int w, int h, int p, int x0, int y0, V fac1, V fac2,
                                              V* __restrict__ sm, V* __restrict__ sx, V* __restrict__ sy, int lane, int wv,
-                                             const HakExtremaArgs<V>& ex, int img, unsigned long long* cbuf, int* ccnt)
+                                             const HakExtremaArgs<V>& ex, int img, unsigned long long* cbuf, int* ccnt, const int ccap)
 {
     using G = HessGeo<S>;
     constexpr int SW = G::SW, DW = G::DW, DH = G::DH, EW = G::EW, EH = G::EH, TY = G::TY;
@@ -238,14 +238,23 @@ __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__
             // list slots: reserving them in the global counter needs an atomic WITH return, and waiting for it drains the
             // wave's outstanding stores and prefetch loads (s_waitcnt vmcnt(0)).  Candidates are staged in a per-block LDS
             // buffer (LDS atomic: a short lgkmcnt wait) and flushed by the tile loop; only an overflow goes direct.
-            int base = 0;
-            if (lane == 0) base = atomicAdd(ccnt, __popcll(m));
-            base = __builtin_amdgcn_readfirstlane(base);
-            const bool direct = base + __popcll(m) > HF_CBUF;                 // wave-uniform
-            if (direct) {
-                if (lane == 0) { atomicSub(ccnt, __popcll(m)); base = atomicAdd(&ex.state[img].ncand, __popcll(m)); }
-                base = __builtin_amdgcn_readfirstlane(base);
+            // The reservation never publishes a count it cannot back: a compare-and-swap loop either claims [base, base + n)
+            // inside the buffer or leaves ccnt untouched and sends this row's candidates straight to the global list
+            // (an add followed by a compensating subtract let a third wave claim slots above the final count).
+            const int n = __popcll(m);
+            int base = 0, direct = 0;
+            if (lane == 0) {
+                int old = *(volatile int*)ccnt;
+                for (;;) {
+                    if (old + n > ccap) { direct = 1; break; }
+                    const int prev = atomicCAS(ccnt, old, old + n);
+                    if (prev == old) break;
+                    old = prev;
+                }
+                base = direct ? atomicAdd(&ex.state[img].ncand, n) : old;
             }
+            base = __builtin_amdgcn_readfirstlane(base);
+            direct = __builtin_amdgcn_readfirstlane(direct);                  // wave-uniform
             if (hit) {
                 const int fx = x << ex.octave, fy = y << ex.octave;
                 const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)ex.layer);
@@ -264,7 +273,7 @@ template <typename V, int S>
 __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restrict__ src, V* __restrict__ lx,
                                                        V* __restrict__ ly, V* __restrict__ det, long stride,
                                                        int w, int h, int p, V fac1, V fac2, int tiles_per_block,
-                                                       int ntx, int nby, int nimg, HakExtremaArgs<V> ex)
+                                                       int ntx, int nby, int nimg, HakExtremaArgs<V> ex, int ccap)
 {
     using G = HessGeo<S>;
     __shared__ V sm[G::SH * G::SW];
@@ -305,13 +314,13 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
     for (int ty = ty0; ty < ty1; ty++) {
         const int y0 = ty * G::TY;
         hak_lds_barrier();                                        // previous tile's readers of sm / sx / sy are done
-        if (ex.maps != nullptr && ccnt > HF_CBUF / 2) flush();    // (ccnt is stable here: every wave passed the barrier)
+        if (ex.maps != nullptr && ccnt > ccap / 2) flush();    // (ccnt is stable here: every wave passed the barrier)
         hess_commit<V, S>(P, sm, lane, wv);
         hak_lds_barrier();
         if (ty + 1 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
-        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt);
-        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt);
+        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
+        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
     }
     if (ex.maps != nullptr) {
         __syncthreads();
@@ -325,6 +334,12 @@ static void deriv_factors(float& fac1, float& fac2)
     fac1 = 1.f / (2.f * (wv + 2.f));
     fac2 = wv * fac1;
 }
+
+// process-wide mode (0 never / 1 by size / 2 always), refreshed from HAK_HESS_STREAM by every hak_create
+int hak_hessian_stream_enabled = 1;
+// staged candidates per block actually used (1..HF_CBUF); HAK_HESS_CBUF shrinks it so that the tests can drive the
+// overflow path of the staging buffer with ordinary images
+int hak_hessian_cbuf_cap = HF_CBUF;
 
 template <typename V, int S>
 static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride,
@@ -340,7 +355,7 @@ static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, lon
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
-    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex);
+    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex, hak_hessian_cbuf_cap);
 }
 
 template <typename V>
@@ -356,8 +371,6 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
     return ex;
 }
 
-// process-wide mode (0 never / 1 by size / 2 always), refreshed from HAK_HESS_STREAM by every hak_create
-int hak_hessian_stream_enabled = 1;
 
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
 // extrema were handled here; false means the caller must run the stand-alone extrema kernel.

@@ -94,13 +94,8 @@ namespace akaze
     void Akazer::detectAndCompute(float* image, AkazeData& result, int3 whp0, const bool desc)   // akaze.cpp:101-150
     {
         ensureContext(whp0.x, whp0.y);                // other size than init(): new arena (akaze.cpp:114-117)
-        if (result.max_pts < cfg.max_pts) {
-            // the reference clamps to result.max_pts (akaze.cpp:246, 451); rebuild the context for the smaller capacity
-            cfg.max_pts = result.max_pts;
-            hak_destroy(ctx);
-            ctx = nullptr;
-            ensureContext(whp0.x, whp0.y);
-        }
+        // the clamp of THIS call is result.max_pts, as the reference's setMaxNumPoints(result.max_pts) (akaze.cpp:246, 451);
+        // nothing in the context is sized by it, so neither a smaller nor a larger AkazeData rebuilds anything
         if (hak_detect_and_compute(ctx, image, whp0.z, result.d_data, result.max_pts, &result.num_pts, result.h_data, desc ? 1 : 0))
             die("detectAndCompute");
     }
@@ -108,12 +103,6 @@ namespace akaze
     void Akazer::fastDetectAndCompute(unsigned char* image, AkazeData& result, int3 whp0, const bool desc)   // akaze.cpp:153-201
     {
         ensureContext(whp0.x, whp0.y);
-        if (result.max_pts < cfg.max_pts) {
-            cfg.max_pts = result.max_pts;
-            hak_destroy(ctx);
-            ctx = nullptr;
-            ensureContext(whp0.x, whp0.y);
-        }
         if (hak_fast_detect_and_compute(ctx, image, whp0.z, result.d_data, result.max_pts, &result.num_pts, result.h_data, desc ? 1 : 0))
             die("fastDetectAndCompute");
     }

@@ -2,7 +2,13 @@
 // reads two binary PGMs (or synthesises a pair), uploads them, runs detectAndCompute on both images
 // `nrepeats` times and cuMatch once, and prints the same five result lines.
 //
-//   hipakaze_demo [device] [left.pgm right.pgm] [nrepeats]
+//   hipakaze_demo [device] [left.pgm right.pgm] [nrepeats] [--dump file] [--api-checks]
+//
+// --dump file   writes the host-side results as raw 104-byte AkazePoint records:
+//               int32 n1, n2, then n1 + n2 records of the float path (image 1 after cuMatch),
+//               then int32 f1, f2 and f1 + f2 records of the FAST path (image 1 after cuMatch).
+// --api-checks  additionally drives Akazer through the call patterns of akaze.cpp:101-150 that the demo loop does not:
+//               an AkazeData smaller and larger than the default capacity, and an image size other than init()'s.
 #include "akaze.h"
 #include <cmath>
 #include <cstring>
@@ -54,11 +60,35 @@ static void synthPair(std::vector<unsigned char>& a, std::vector<unsigned char>&
         b[(size_t)y * w + x] = a[(size_t)std::min(h - 1, y + 20) * w + std::min(w - 1, x + 20)];
 }
 
+static void dumpPoints(std::ofstream& f, const akaze::AkazeData& a, const akaze::AkazeData& b)
+{
+    const int n[2] = {a.num_pts, b.num_pts};
+    f.write((const char*)n, sizeof(n));
+    f.write((const char*)a.h_data, sizeof(akaze::AkazePoint) * (size_t)a.num_pts);
+    f.write((const char*)b.h_data, sizeof(akaze::AkazePoint) * (size_t)b.num_pts);
+}
+
 int main(int argc, char** argv)
 {
     std::cout << "===== Registration by HIP-AKAZE (MI355X) =====" << std::endl;
+    std::string dumpPath;
+    bool apiChecks = false;
+    {   // strip the options; what is left are the reference demo's positional arguments (main.cpp:131-135)
+        int n = 1;
+        for (int i = 1; i < argc; i++) {
+            if (!strcmp(argv[i], "--dump") && i + 1 < argc) dumpPath = argv[++i];
+            else if (!strcmp(argv[i], "--api-checks")) apiChecks = true;
+            else argv[n++] = argv[i];
+        }
+        argc = n;
+    }
     int devNum = argc > 1 ? std::atoi(argv[1]) : 0;
     int nrepeats = argc > 4 ? std::atoi(argv[4]) : 100;
+    std::ofstream dump;
+    if (!dumpPath.empty()) {
+        dump.open(dumpPath, std::ios::binary);
+        if (!dump) { std::cerr << "cannot open " << dumpPath << std::endl; return 1; }
+    }
     std::vector<unsigned char> l8, r8;
     int w = 1920, h = 1080, w2 = 0, h2 = 0;
     if (argc > 3) {
@@ -116,6 +146,8 @@ int main(int argc, char** argv)
               << "Time of detection and computation: " << (t2 - t1) / nrepeats << std::endl
               << "Time of matching AKAZE keypoints:   " << (t3 - t2) << std::endl;
 
+    if (dump.is_open()) dumpPoints(dump, akaze_data1, akaze_data2);
+
     // match post-processing (build-side addition): ratio 4/5 + cross-check, compacted on the device
     std::vector<hak_match_pair> good(akaze_data1.num_pts > 0 ? akaze_data1.num_pts : 1);
     float t4 = timer.read();
@@ -145,8 +177,41 @@ int main(int argc, char** argv)
               << "Number of accepted matches: " << nmatch << std::endl
               << "Time of detection and computation: " << (f2 - f1) / nrepeats << std::endl
               << "Time of matching AKAZE keypoints:   " << (f3 - f2) << std::endl;
+    if (dump.is_open()) dumpPoints(dump, akaze_data1, akaze_data2);
     CHECK(hipFree(fimg1));
     CHECK(hipFree(fimg2));
+
+    if (apiChecks) {
+        // (a) an AkazeData smaller than the default capacity clamps THIS call (akaze.cpp:246 setMaxNumPoints(result.max_pts)) ...
+        std::cout << "===== API checks =====" << std::endl;
+        akaze::AkazeData small, large;
+        akaze::initAkazeData(small, 500, true, true);
+        akaze::initAkazeData(large, 20000, true, true);
+        detector->detectAndCompute(img1, small, whp1, true);
+        std::cout << "small AkazeData (500): " << small.num_pts << std::endl;
+        // ... and does not shrink later calls; a larger one is not clamped to the default 10000 either
+        detector->detectAndCompute(img1, large, whp1, true);
+        std::cout << "large AkazeData (20000): " << large.num_pts << std::endl;
+        detector->detectAndCompute(img1, akaze_data1, whp1, true);
+        std::cout << "default AkazeData again: " << akaze_data1.num_pts << std::endl;
+        int same = small.num_pts <= large.num_pts;
+        for (int i = 0; i < small.num_pts && same; i++)                       // the clamp keeps the raster-order prefix
+            same = memcmp(&small.h_data[i], &large.h_data[i], 85) == 0;
+        std::cout << "small is a prefix of large: " << (same ? "yes" : "NO") << std::endl;
+        // (b) a size other than init()'s: new arena (akaze.cpp:109-117), then back
+        int3 whpc; whpc.x = w / 2 / 4 * 4; whpc.y = h / 2; whpc.z = iAlignUp(whpc.x, 128);
+        float* crop = NULL;
+        CHECK(hipMalloc((void**)&crop, sizeof(float) * (size_t)whpc.y * whpc.z));
+        CHECK(hipMemcpy2D(crop, sizeof(float) * whpc.z, limg.data(), sizeof(float) * w, sizeof(float) * whpc.x, whpc.y, hipMemcpyHostToDevice));
+        detector->detectAndCompute(crop, large, whpc, true);
+        std::cout << "top-left quarter (" << whpc.x << "x" << whpc.y << "): " << large.num_pts << std::endl;
+        if (dump.is_open()) dumpPoints(dump, small, large);
+        detector->detectAndCompute(img1, large, whp1, true);
+        std::cout << "full size again: " << large.num_pts << std::endl;
+        CHECK(hipFree(crop));
+        akaze::freeAkazeData(small);
+        akaze::freeAkazeData(large);
+    }
 
     akaze::freeAkazeData(akaze_data1);
     akaze::freeAkazeData(akaze_data2);

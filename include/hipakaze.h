@@ -88,8 +88,11 @@ int hak_set_concurrency(hak_ctx* ctx, int on);
 
 /* ---- Akazer::detectAndCompute (akaze.h:29, akaze.cpp:101-150), one image,
  * synchronous.  d_image: device float32, pitch elements per row.  d_points:
- * device array of max_pts points.  *num_pts (host) receives the count; when
- * h_points != NULL the points are copied to it (whole 104-byte records). */
+ * device array of max_pts points; max_pts is also this call's clamp, as the
+ * reference's setMaxNumPoints(result.max_pts) (akaze.cpp:246, 451) -- it may be
+ * smaller or larger than cfg.max_pts (which sizes the batch entry points).
+ * *num_pts (host) receives the count; when h_points != NULL the points are
+ * copied to it (whole 104-byte records). */
 int hak_detect_and_compute(hak_ctx* ctx, const float* d_image, int pitch,
                            hak_point* d_points, int max_pts, int* num_pts,
                            hak_point* h_points, int desc);
@@ -192,6 +195,13 @@ typedef struct hak_traffic {
                                 low-pass / conductivity bytes of every octave head that does the same */
     double all_stage_bytes;  /* all-stage compulsory bytes per image, keypoint part for npts_hint points */
     int fed_launches;        /* FED kernel launches per batch */
+    /* compulsory HBM bytes per image of each kernel class AS BUILT (after fusion): what its launches must move even with
+       perfect reuse inside a launch -- the numerator of the per-class roofline fractions in bench.py */
+    double fed_fused_bytes;  /* FED launches as enqueued by the last detect call: read L (+ g), write L' (+ smooth, + g) */
+    double hessian_bytes;    /* 16 B/px per level: read smooth, write Lx, Ly, det */
+    double prologue_bytes;   /* 16 B/px of octave 0: read image, write Lt(0,0) + gradient plane, re-read it for the histogram */
+    double describe_bytes;   /* (872 + 5292) B sampled per keypoint (orientation + MLDB) x npts_hint */
+    double nms_bytes;        /* 104 B record per keypoint x npts_hint */
 } hak_traffic;
 int hak_query_traffic(const hak_ctx* ctx, int npts_hint, hak_traffic* out);
 
@@ -221,6 +231,15 @@ int hak_op_rcp_check(unsigned lo_bits, unsigned hi_bits, unsigned long long* mis
 int hak_op_smooth_flow(const float* d_src, float* d_smooth, float* d_flow, int w, int h, int p,
                        int diffusivity, float kcontrast);                                               /* hLowPass(var 1) + hFlow, akaze.cpp:403-404 */
 int hak_op_hessian(const float* d_src, float* d_lx, float* d_ly, float* d_det, int w, int h, int p, int step); /* hHessianDeterminant 2531 */
+
+/* ---- bandwidth ceilings of the box (SURVEY 8d "copy-kernel ceiling"; not on the hot path).
+ * hak_op_copy_probe: float4 copy of `bytes` with the streaming kernels' access shape (16 B/lane, nt stores), `iters`
+ * times; *gbytes_per_s = (read + write bytes) / average kernel time.
+ * hak_op_gather_probe: `blocks` x 256 lanes each gather `per_lane` dwords from pseudo-random 128-byte lines of a
+ * `bytes`-sized buffer (the descriptor's access shape), `iters` times; *ms_per_launch = average kernel time.  Used to
+ * calibrate the FETCH_SIZE counter for 4-byte gathers. */
+int hak_op_copy_probe(long bytes, int iters, double* gbytes_per_s);
+int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
 
 #ifdef __cplusplus
 }

@@ -42,6 +42,28 @@ def build(force=False):
         subprocess.check_call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL)
 
 
+def build_native(outdir):
+    """bench.py's cpu_baseline leg only: the same sources compiled for the host the bench runs on
+    (-O3 -march=native; still -ffp-contract=off -fno-fast-math, so results stay bit-identical -- bench.py checks that by
+    verifying the GPU results against THIS build).  Returns the library path, or None when the compiler is unavailable."""
+    out = os.path.join(outdir, "liboracle_native.so")
+    cmd = ["gcc", "-O3", "-march=native", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-fopenmp", "-Wno-unknown-pragmas",
+           "-shared", "-o", out, os.path.join(_HERE, "akaze_oracle.c"), os.path.join(_HERE, "akaze_oracle_fast.c"), "-lm"]
+    try:
+        subprocess.check_call(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        return None
+    return out
+
+
+def load(path):
+    """switch the module to another build of the oracle library (before or after the first call)"""
+    global _lib, LIB
+    LIB = path
+    _lib = None
+    return lib()
+
+
 _lib = None
 _fp = C.POINTER(C.c_float)
 _ip = C.POINTER(C.c_int)
@@ -50,7 +72,8 @@ _ip = C.POINTER(C.c_int)
 def lib():
     global _lib
     if _lib is None:
-        build()
+        if LIB == os.path.join(_HERE, "liboracle.so"):
+            build()
         _lib = C.CDLL(LIB)
         _lib.okz_arena_floats.restype = C.c_long
         _lib.okz_kcontrast.restype = C.c_float

@@ -18,14 +18,12 @@ def _worker(rank, world, port, total_pairs, out):
     import bench
     dist.init_process_group("gloo", rank=rank, world_size=world)
     lo, hi = bench.shard_pairs(total_pairs, world, rank)
-    # per-rank summary {pairs, keypoints, matches}: fake but rank-dependent counts
-    summary = torch.tensor([hi - lo, sum(range(lo, hi)) * 2, sum(range(lo, hi))], dtype=torch.int64)
-    gathered = [torch.zeros_like(summary) for _ in range(world)]
-    dist.all_gather(gathered, summary)
-    t = torch.tensor([0.5 + rank], dtype=torch.float64)
+    # the functions bench.main() itself runs over RCCL: per-rank summary {pairs, keypoints, matches} (fake but
+    # rank-dependent counts), barrier, max-over-ranks step time
+    total = bench.gather_summary(hi - lo, sum(range(lo, hi)) * 2, sum(range(lo, hi)), "cpu", True)
     dist.barrier()
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    out[rank] = (lo, hi, torch.stack(gathered).sum(0).tolist(), float(t.item()))
+    tmax = bench.max_over_ranks(0.5 + rank, "cpu", True)
+    out[rank] = (lo, hi, total, tmax)
     dist.destroy_process_group()
 
 

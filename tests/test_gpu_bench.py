@@ -1,0 +1,63 @@
+"""bench.py as the driver runs it, in a fresh child process on the GPU box: the JSON contract, the self-verification
+against the oracle, the per-class roofline table, and the torch.distributed (RCCL) code path with one rank
+(HAK_BENCH_FORCE_DIST=1: init_process_group("nccl"), barrier, MAX all-reduce, summary all-gather on the MI355X)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(extra, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM"):      # the bench runs the library's default kernel selection
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, capture_output=True, text=True, timeout=timeout,
+                       env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_contract_verified_and_roofline():
+    out = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs"])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "verified"):
+        assert k in out, k
+    assert out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f32"
+    assert out["value"] > 100 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 0.01
+    v = out["verified"]
+    assert v["images"] == 4 and v["points_equal"] and v["matches_equal"]
+    r = out["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert 3000 < r["copy_ceiling_GBs"] < 8000
+    assert r["fusion_gain"] > 1.0
+    names = [c["class"] for c in r["classes"]]
+    assert names[:4] == ["fed", "hessian", "describe", "prologue"]
+    for c in r["classes"]:
+        assert c["ms"] > 0
+        if c["frac_peak"] is not None:
+            assert 0.0 < c["frac_peak"] <= 1.0, c
+
+
+def test_bench_rccl_path_with_one_rank_weak_and_strong():
+    """barrier / all_reduce(MAX) / all_gather over RCCL on the MI355X (world size 1), in both scaling modes"""
+    env = {"HAK_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"}
+    weak = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs", "--no-roofline"], env)
+    assert weak["scaling"] == "weak" and weak["config"]["total_pairs_per_step"] == 16 and weak["verified"]["points_equal"]
+    env["MASTER_PORT"] = "29612"
+    strong = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--total-pairs", "40", "--width", "1280", "--height", "720",
+                        "--no-cpu-baseline", "--no-configs", "--no-roofline", "--upload"], env)
+    assert strong["scaling"] == "strong" and strong["config"]["total_pairs_per_step"] == 40
+    assert strong["config"]["pairs_per_launch_sequence"] == 16            # 40 pairs = launch sequences of 16 + 16 + 8
+    assert abs(strong["value"] - 40 * 2 / (strong["ms_per_step"] * 2e-3)) / strong["value"] < 0.01
+    assert strong["verified"]["points_equal"] and strong["verified"]["matches_equal"]
+    assert strong["upload_inclusive_pairs_per_s"] > 0

@@ -1,0 +1,119 @@
+"""GPU run of the REAL drop-in layer: the C++ `akaze::Akazer` / `initAkazeData` / `cuMatch` of include/akaze.h
+(cuda-akaze_amd/host/akaze.cpp -> libakaze_hip.so) driven by the counterpart of the reference demo
+(host/main.cpp -> hipakaze_demo, the reference's main.cpp:128-300) as a fresh process, on the reference's own bundled
+pair data/left.pgm / right.pgm (committed as pixel data in tests/golden/left_right_u8.npz).
+
+Checked against the committed oracle goldens: the printed counts, every 104-byte AkazePoint record the demo's host
+arrays hold after detectAndCompute x2 + cuMatch (float path and integer FAST path), and the call patterns of
+akaze.cpp:101-150 the demo loop does not take (AkazeData smaller / larger than the default capacity, a size other
+than init()'s)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, assert_points_equal
+
+pytestmark = pytest.mark.gpu
+
+DEMO = os.path.join(ROOT, "cuda-akaze_amd", "hipakaze_demo")
+
+
+def write_pgm(path, u8):
+    h, w = u8.shape
+    with open(path, "wb") as f:
+        f.write(b"P5\n%d %d\n255\n" % (w, h))
+        f.write(np.ascontiguousarray(u8).tobytes())
+
+
+def read_dump(path, ah):
+    """[(pts_a, pts_b), ...] in the order the demo wrote them"""
+    raw = open(path, "rb").read()
+    out, off = [], 0
+    while off < len(raw):
+        n1, n2 = np.frombuffer(raw, np.int32, 2, off)
+        off += 8
+        a = np.frombuffer(raw, ah.POINT_DTYPE, n1, off).copy()
+        off += 104 * int(n1)
+        b = np.frombuffer(raw, ah.POINT_DTYPE, n2, off).copy()
+        off += 104 * int(n2)
+        out.append((a, b))
+    return out
+
+
+@pytest.fixture(scope="module")
+def demo_run(ah, golden, tmp_path_factory):
+    assert os.path.exists(DEMO), "hipakaze_demo is missing: __graft_entry__.build() compiles it"
+    d = tmp_path_factory.mktemp("dropin")
+    left, right, dump = str(d / "left.pgm"), str(d / "right.pgm"), str(d / "points.bin")
+    write_pgm(left, golden.lr_u8["left"])
+    write_pgm(right, golden.lr_u8["right"])
+    env = dict(os.environ)
+    for k in ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM"):      # the demo runs the library's default kernel selection
+        env.pop(k, None)
+    r = subprocess.run([DEMO, "0", left, right, "3", "--dump", dump, "--api-checks"], capture_output=True, text=True,
+                       timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    return r.stdout, read_dump(dump, ah)
+
+
+def _counts(text, label):
+    return [int(v) for v in re.findall(re.escape(label) + r"\s*(\d+)", text)]
+
+
+def test_demo_prints_the_oracle_counts(demo_run):
+    out, _ = demo_run
+    assert _counts(out, "Number of features1:") == [3544, 3733]          # float path, then FAST path
+    assert _counts(out, "Number of features2:") == [4695, 4996]
+    assert _counts(out, "Number of accepted matches:")[0] == 2400
+    assert "Image size = (1280,960)" in out
+
+
+def test_demo_records_equal_the_goldens(demo_run, golden):
+    _, dumps = demo_run
+    (f1, f2), (q1, q2) = dumps[0], dumps[1]
+    g = golden.lr
+    assert_points_equal(f1, g["pts1"], fields=("x", "y", "octave", "response", "size", "angle", "features",
+                                               "match", "distance", "match_x", "match_y"))
+    assert_points_equal(f2, g["pts2"])
+    fast = np.load(os.path.join(GOLDEN, "fast_oracle.npz"))
+    assert_points_equal(q1, fast["left_pts"])
+    assert_points_equal(q2, fast["right_pts"])
+
+
+def test_demo_fast_matches_equal_the_oracle(demo_run, okz):
+    _, dumps = demo_run
+    q1, q2 = dumps[1]
+    o1, o2 = q1.copy(), q2.copy()
+    for f in ("match", "distance", "match_x", "match_y"):
+        o1[f] = 0
+    okz.match(o1, o2)
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(q1[f], o1[f]), f
+
+
+def test_akazer_capacity_and_size_changes(demo_run, golden, okz, ah, synth_mod):
+    """akaze.cpp:246/451 (per-call clamp = result.max_pts, no lasting effect) and akaze.cpp:109-117 (new arena for another size)"""
+    out, dumps = demo_run
+    g = golden.lr["pts1"]
+    assert _counts(out, "small AkazeData (500):") == [500]
+    assert _counts(out, "large AkazeData (20000):") == [len(g)]
+    assert _counts(out, "default AkazeData again:") == [len(g)]
+    assert "small is a prefix of large: yes" in out
+    assert _counts(out, "full size again:") == [len(g)]
+    small, crop = dumps[2]
+    assert_points_equal(small, g[:500])                                   # the clamp keeps the raster-order prefix
+    left = golden.lr_u8["left"]
+    cw, chh = left.shape[1] // 2 // 4 * 4, left.shape[0] // 2
+    sub = np.ascontiguousarray(left[:chh, :cw])
+    r = okz.detect_and_compute(synth_mod.to_float(sub, ah.iAlignUp(cw, 128)), cw, max_pts=20000)
+    assert len(r.points) > 200
+    assert_points_equal(crop, r.points)
+
+
+@pytest.fixture(scope="module")
+def synth_mod():
+    from akaze_hip import synth
+    return synth

@@ -169,15 +169,17 @@ def test_batch_equals_single(ah, torch, synth, B):
     det.close()
 
 
-def test_large_batch_launch_shapes_equal_single(ah, torch, synth):
+def test_large_batch_launch_shapes_equal_single(ah, okz, torch, synth):
     """the benchmark's regime: a batch big enough that every streaming kernel runs its full 120-128-row segments (a single
     image makes the launchers shrink the segments until the grid fills the chip: 8 strips x 9 segments x images >= 4096
-    needs 57 images) -- both paths, 64 x 1080p, against the
-    single-image results, which test_full_size_vs_oracle / test_fast_path_1080p pin to the oracle"""
+    needs 57 images) -- both paths, 64 x 1080p, against the oracle run live on the same two scenes (and against the
+    single-image GPU results)"""
     w, h, mp, B = 1920, 1080, 10000, 64
     p = ah.iAlignUp(w, 128)
     u8s = [synth.scene(w, h, 40 + i) for i in range(2)]
     singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in u8s]
+    for u, s1 in zip(u8s, singles):
+        assert_points_equal(s1, okz.detect_and_compute(synth.to_float(u, p), w, max_pts=mp).points)
     pad = [np.zeros((h, p), np.uint8) for _ in u8s]
     for q, u in zip(pad, u8s):
         q[:, :w] = u
@@ -191,6 +193,8 @@ def test_large_batch_launch_shapes_equal_single(ah, torch, synth):
         det.fastDetectAndCompute(d8.data_ptr(), data, (w, h, p), True)
         fsingles.append(data.h_data[:data.num_pts].copy())
     ah.freeAkazeData(data)
+    for u, s1 in zip(u8s, fsingles):
+        assert_points_equal(s1, okz.fast_detect_and_compute(u, max_pts=mp).points)
     d_pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
     d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
     stack = torch.from_numpy(np.stack([synth.to_float(u8s[i % 2], p) for i in range(B)])).cuda()
@@ -211,6 +215,83 @@ def test_large_batch_launch_shapes_equal_single(ah, torch, synth):
         assert nums[i] == len(fsingles[i % 2]) > 500, i
         assert_points_equal(allp[i, :nums[i]], fsingles[i % 2])
     det.close()
+
+
+class default_knobs:
+    """run with the kernel-selection environment knobs UNSET (conftest forces the streaming kernels on everywhere), so
+    that hak_stream_pays() picks tile or streaming kernels per launch by itself, as in production"""
+    KNOBS = ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM")
+
+    def __init__(self, ah):
+        self.ah = ah
+
+    def __enter__(self):
+        self.saved = {k: os.environ.pop(k, None) for k in self.KNOBS}
+
+    def __exit__(self, *exc):
+        for k, v in self.saved.items():
+            if v is not None:
+                os.environ[k] = v
+        det = self.ah.Akazer()                       # hak_create re-reads the environment: restore the process-wide modes
+        det.init((128, 96, 128), max_pts=10)
+        det.close()
+
+
+def test_720p_batch64_default_kernel_selection_vs_oracle(ah, okz, torch, synth):
+    """BASELINE.json configs[3]'s shape (a batch of independent 1280x720 frames) with the library's own kernel selection:
+    64 images make octaves 0-1 take the streaming kernels and octaves 2-3 the tile kernels (hak_stream_pays); every
+    image's keypoints, descriptors and every pair's matches against the oracle run live on the four distinct scenes"""
+    w, h, mp, B = 1280, 720, 10000, 64
+    p = ah.iAlignUp(w, 128)
+    pairs = [synth.pair(w, h, 50 + i) for i in range(2)]
+    u8s = [pairs[0][0], pairs[0][1], pairs[1][0], pairs[1][1]]
+    want = [okz.detect_and_compute(synth.to_float(u, p), w, max_pts=mp).points for u in u8s]
+    for k in range(2):
+        okz.match(want[2 * k], want[2 * k + 1])
+    stack = torch.from_numpy(np.stack([synth.to_float(u8s[i % 4], p) for i in range(B)])).cuda()
+    d_pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+    d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
+    with default_knobs(ah):
+        det = ah.Akazer()
+        det.init((w, h, p), max_pts=mp, batch=B)
+        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B // 2))
+        ah.check(ah.lib.hak_sync(det.ctx))
+        det.close()
+    nums = d_num.cpu().numpy()
+    allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    for i in range(B):
+        assert nums[i] == len(want[i % 4]) > 300, i
+        fields = ("x", "y", "octave", "response", "size", "angle", "features")
+        if i % 2 == 0:
+            fields += ("match", "distance", "match_x", "match_y")
+        assert_points_equal(allp[i, :nums[i]], want[i % 4], fields=fields)
+
+
+def test_1080p_default_kernel_selection_vs_oracle(ah, okz, torch, synth):
+    """single-image call and a 16-image batch at 1080p with the knobs unset: the tile kernels (single image) and the mix
+    the size rule picks at 16 images, both against the oracle"""
+    w, h, mp = 1920, 1080, 10000
+    p = ah.iAlignUp(w, 128)
+    u8 = synth.scene(w, h, 44)
+    want = okz.detect_and_compute(synth.to_float(u8, p), w, max_pts=mp).points
+    with default_knobs(ah):
+        got = gpu_detect(ah, torch, synth, u8, max_pts=mp)
+        B = 16
+        stack = torch.from_numpy(np.stack([synth.to_float(u8, p)] * B)).cuda()
+        d_pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+        d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
+        det = ah.Akazer()
+        det.init((w, h, p), max_pts=mp, batch=B)
+        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), 1))
+        ah.check(ah.lib.hak_sync(det.ctx))
+        det.close()
+    assert_points_equal(got, want)
+    nums = d_num.cpu().numpy()
+    allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+    for i in range(B):
+        assert nums[i] == len(want)
+        assert_points_equal(allp[i, :nums[i]], want)
 
 
 def test_repeat_calls_are_deterministic(ah, torch, synth):

@@ -53,7 +53,7 @@ def test_bad_arguments_return_errors(ah, torch):
         lambda: lib.hak_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, p, 3, pts.data_ptr(), num.data_ptr(), 1),
         lambda: lib.hak_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, w - 1, 2, pts.data_ptr(), num.data_ptr(), 1),
         lambda: lib.hak_detect_and_compute_batch(None, img.data_ptr(), h * p, p, 2, pts.data_ptr(), num.data_ptr(), 1),
-        lambda: lib.hak_detect_and_compute(det.ctx, img.data_ptr(), p, pts.data_ptr(), 499, C.byref(n), None, 1),
+        lambda: lib.hak_detect_and_compute(det.ctx, img.data_ptr(), p, pts.data_ptr(), 0, C.byref(n), None, 1),
         lambda: lib.hak_fast_detect_and_compute_batch(det.ctx, img.data_ptr(), h * p, p, 0, pts.data_ptr(), num.data_ptr(), 1),
         lambda: lib.hak_fast_detect_and_compute(det.ctx, None, p, pts.data_ptr(), 500, C.byref(n), None, 1),
         lambda: lib.hak_match_batch(det.ctx, pts.data_ptr(), None, 1),
@@ -71,7 +71,7 @@ def test_bad_arguments_return_errors(ah, torch):
     lib.hak_default_config(C.byref(cfg))
     ctx = C.c_void_p()
     for (cw, ch, field, val) in ((0, 100, None, None), (100, -1, None, None), (79, 200, None, None), (256, 192, "noctaves", 0),
-                                 (256, 192, "max_scale", 0), (256, 192, "noctaves", 99)):
+                                 (256, 192, "max_scale", 0), (256, 192, "noctaves", 99), (65536, 96, None, None), (96, 70000, None, None)):
         c2 = ah.hak_config.from_buffer_copy(cfg)
         if field:
             setattr(c2, field, val)
@@ -212,14 +212,30 @@ def test_knn2_with_context_scratch_and_repeat(ah, okz, torch, synth):
     det.close()
 
 
+_ALT_ORACLE = {}
+
+
+def _alt_oracle(okz, synth, ah, u8, w, h, mp):
+    """oracle bytes (float path records + FAST path records) of the scene the alternatives test runs, computed once"""
+    if "v" not in _ALT_ORACLE:
+        a = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, max_pts=mp).points
+        b = okz.fast_detect_and_compute(u8, max_pts=mp).points
+        _ALT_ORACLE["v"] = (a, b)
+    return _ALT_ORACLE["v"]
+
+
 @pytest.mark.parametrize("env", [{"HAK_FUSE_SF": "0"}, {"HAK_HESS_STREAM": "0"}, {"HAK_FED_MAX_FUSE": "1"}, {"HAK_GRAPH": "0", "HAK_SERIAL": "1"},
                                  {"HAK_FUSE_SF": "1", "HAK_HESS_STREAM": "1"},          # the default size rule
                                  {"HAK_FUSE_HEAD": "0"}, {"HAK_BASE_STREAM": "0"}, {"HAK_BASE_STREAM": "1"},
-                                 {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0", "HAK_FED_MAX_FUSE": "2"}],
+                                 {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0", "HAK_FED_MAX_FUSE": "2"},
+                                 # tile Hessian with a 4-entry candidate staging buffer: nearly every row with a candidate takes the
+                                 # overflow path of the reservation (direct global slots) next to staged ones
+                                 {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "4"}, {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
-def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
+def test_kernel_alternatives_are_bit_identical(ah, okz, torch, synth, env):
     """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
-    persistent planes: the fused / streaming kernels and the tile kernels they replace are interchangeable"""
+    persistent planes: the fused / streaming kernels and the tile kernels they replace are interchangeable -- and equal
+    to the oracle (both paths), so this is not a self-comparison"""
     w, h, mp = 960, 540, 4000
     p = ah.iAlignUp(w, 128)
     u8 = synth.scene(w, h, 21)
@@ -234,21 +250,23 @@ def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
         data = ah.AkazeData()
         ah.initAkazeData(data, mp, True, True)
         det.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
-        pts = data.h_data[:data.num_pts].copy().tobytes()
+        both = [data.h_data[:data.num_pts].copy()]
+        pts = both[0].tobytes()
         planes = [det.plane(kind, o, s).tobytes() for o in range(len(det.geometry())) for s in range(4) for kind in (0, 1, 2, 3)]
         det.fastDetectAndCompute(img8.data_ptr(), data, (w, h, p), True)          # the integer path shares the knobs
         assert data.num_pts > 100
-        pts += data.h_data[:data.num_pts].copy().tobytes()
+        both.append(data.h_data[:data.num_pts].copy())
+        pts += both[1].tobytes()
         planes += [det.plane(kind, o, s).tobytes() for o in range(len(det.geometry())) for s in range(4) for kind in (0, 1, 2, 3)]
         ah.freeAkazeData(data)
         det.close()
-        return pts, planes
+        return pts, planes, both
 
-    ref_pts, ref_planes = run()
+    ref_pts, ref_planes, _ = run()
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
-        alt_pts, alt_planes = run()
+        alt_pts, alt_planes, alt_both = run()
     finally:
         for k, v in saved.items():
             if v is None:
@@ -262,6 +280,9 @@ def test_kernel_alternatives_are_bit_identical(ah, torch, synth, env):
     assert len(ref_pts) > 104 * 100
     assert alt_pts == ref_pts
     assert alt_planes == ref_planes
+    want = _alt_oracle(okz, synth, ah, u8, w, h, mp)
+    assert_points_equal(alt_both[0], want[0])
+    assert_points_equal(alt_both[1], want[1])
 
 
 def test_download_batch_pinned_and_pageable(ah, torch, synth):

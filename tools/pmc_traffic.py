@@ -49,6 +49,23 @@ def main():
         fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
         fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows,
         pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "128")))
+    # per kernel class (bench.py CLASS_KERNELS): bytes per launch sequence + the hash of the sources the pass ran on, so that
+    # bench.py refuses the figure once a kernel of the class has changed.  FETCH_SIZE is doubled only for the classes whose
+    # loads are 16 B/lane streams (the case MI355X_MICROARCH.md calibrates); 4-byte gathers (describe / orient, NMS,
+    # matcher staging) are taken as reported -- tools/pmc_gather_calib.py measures that case.
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import CLASS_KERNELS, class_source_hash
+    nseq = int(os.environ.get("HAK_PMC_SEQUENCES", "2"))          # launch sequences in the profiled run (warmup 1 + steps 1)
+    classes = {}
+    for k, names in CLASS_KERNELS.items():
+        rs = [r for r in rows if any(n in r["kernel"] for n in names)]
+        f = sum(r["fetch_size_bytes"] for r in rs)
+        w = sum(r["write_size_bytes"] for r in rs)
+        dbl = k in ("fed", "hessian", "prologue")
+        classes[k] = dict(fetch_size_bytes=f, write_size_bytes=w, fetch_doubled=dbl, dispatches=sum(r["dispatches"] for r in rs),
+                          hbm_bytes_per_sequence=((2.0 if dbl else 1.0) * f + w) / nseq, source_sha=class_source_hash(k))
+    summary["classes"] = classes
+    summary["launch_sequences"] = nseq
     json.dump(summary, open(out + ".json", "w"), indent=1)
     with open(out + ".csv", "w") as f:
         f.write("kernel,dispatches,FETCH_SIZE_bytes,WRITE_SIZE_bytes\n")
