@@ -26,7 +26,8 @@ except ImportError:          # pure C-ABI use without PyTorch
     _torch = None
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "libhipakaze.so")
+# HAK_LIB selects another build of the same library (A/B measurements of compiler flags / kernel variants); never a fallback
+LIB_PATH = os.environ.get("HAK_LIB") or os.path.join(os.path.dirname(_HERE), "libhipakaze.so")
 
 FLEN = 61            # akaze_structures.h:29
 MAX_DIST = 96        # akazed.cu:11

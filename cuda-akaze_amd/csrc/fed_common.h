@@ -94,31 +94,49 @@ __device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsig
 
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
 
-// horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 0..4
-template <typename V> struct GHrow { V h0, h1, h2, h3, h4; };
+// horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 1..4 (h4 needs the right lane's g.x)
+template <typename V> struct GHrow { V h1, h2, h3, h4; };
+__device__ __forceinline__ float vneg(float a) { return -a; }
+__device__ __forceinline__ int vneg(int a) { return (int)(0u - (unsigned)a); }
 
-// one output row (4 px per lane) of one level
+// One output row (4 px per lane) of one FED level from shared flux products.
+//   horizontal: P[j] = (g[x0+j-1] + g[x0+j]) * (L[x0+j] - L[x0+j-1]);  term_E(x) = P[x+1], term_W(x) = -P[x] exactly, so
+//               (tE + tW) = P[j+1] - P[j] bit for bit.  P[0] is the left lane's P[4] -- the same two operands in the same
+//               order -- and arrives by ONE wave shift instead of being recomputed (shift + subtract + multiply).
+//   vertical:   Q[r] = (g[r] + g[r+1]) * (L[r+1] - L[r]);  term_S(r) = Q[r], term_N(r) = -Q[r-1] exactly (IEEE addition
+//               commutes, negating a factor negates the product), so  ((tE + tW) + tS) + tN = ((P[j+1] - P[j]) + Qn) - Qp.
+//               Each Q row is formed once and serves the row above and the row below it.
+// Reflect-101 (akazed.cu:1251-1254): x == 0: tW = tE -> P[0] := -P[1];  x == w-1: tE = tW -> P[4] := -P[3];  the callers
+// do the same in y: row 0: Qp := -Qn, row h-1: Qn := -Qp.  Same value and same rounding as the reference expression
+//   (f+fE)(LE-L) + (f+fW)(LW-L) + (f+fS)(LS-L) + (f+fN)(LN-L)  then  fma(stepfac, sum, L)    (akazed.cu:1259-1263)
+// for both element types (integer arithmetic wraps, so the regroupings are exact there too).
 template <bool XEDGE, typename V, typename V4>
-__device__ __forceinline__ V4 fed_row(const V4 Lc, const V4 Ln, const V4 Ls, const GHrow<V>& gh,
-                                      const V4 gvS, const V4 gvN, int x0, int w, V stepfac)
+__device__ __forceinline__ V4 fed_row(const V4 Lc, const GHrow<V>& gh, const V4 Qn, const V4 Qp, int x0, int w, V stepfac)
 {
-    V Ll = wave_shr1(Lc.w), Lr = wave_shl1(Lc.x);
-    if (XEDGE) {
-        // reflect-101 in x: abs(x-1) = 1 at x == 0; borderAdd(x,1,w) = w-2 at x == w-1 (w % 4 == 0 here,
-        // so x == w-1 is the lane's last component); the matching g-sums were folded into gh already
-        Ll = x0 == 0 ? Lc.y : Ll;
-        Lr = x0 + 3 == w - 1 ? Lc.z : Lr;
-    }
-    // d[j] = L[x0+j] - L[x0+j-1], P[j] = h[j] * d[j]
-    const V d0 = vsub(Lc.x, Ll), d1 = vsub(Lc.y, Lc.x), d2 = vsub(Lc.z, Lc.y), d3 = vsub(Lc.w, Lc.z), d4 = vsub(Lr, Lc.w);
-    const V P0 = vmul(gh.h0, d0), P1 = vmul(gh.h1, d1), P2 = vmul(gh.h2, d2), P3 = vmul(gh.h3, d3), P4 = vmul(gh.h4, d4);
+    const V Lr = wave_shl1(Lc.x);
+    const V d1 = vsub(Lc.y, Lc.x), d2 = vsub(Lc.z, Lc.y), d3 = vsub(Lc.w, Lc.z), d4 = vsub(Lr, Lc.w);
+    const V P1 = vmul(gh.h1, d1), P2 = vmul(gh.h2, d2), P3 = vmul(gh.h3, d3);
+    V P4 = vmul(gh.h4, d4);
+    if (XEDGE) P4 = x0 + 3 == w - 1 ? vneg(P3) : P4;         // borderAdd(x,1,w) = w-2 (w % 4 == 0: x == w-1 is the last component)
+    V P0 = wave_shr1(P4);                                   // (executes with every lane active: not inside the select)
+    if (XEDGE) P0 = x0 == 0 ? vneg(P1) : P0;                // abs(x-1) = 1
     V4 o;
-    // ((tE + tW) + tS) + tN ; tE = P[e+1], tW = -P[e]
-    o.x = vstep(stepfac, vadd(vadd(vsub(P1, P0), vmul(gvS.x, vsub(Ls.x, Lc.x))), vmul(gvN.x, vsub(Ln.x, Lc.x))), Lc.x);
-    o.y = vstep(stepfac, vadd(vadd(vsub(P2, P1), vmul(gvS.y, vsub(Ls.y, Lc.y))), vmul(gvN.y, vsub(Ln.y, Lc.y))), Lc.y);
-    o.z = vstep(stepfac, vadd(vadd(vsub(P3, P2), vmul(gvS.z, vsub(Ls.z, Lc.z))), vmul(gvN.z, vsub(Ln.z, Lc.z))), Lc.z);
-    o.w = vstep(stepfac, vadd(vadd(vsub(P4, P3), vmul(gvS.w, vsub(Ls.w, Lc.w))), vmul(gvN.w, vsub(Ln.w, Lc.w))), Lc.w);
+    o.x = vstep(stepfac, vsub(vadd(vsub(P1, P0), Qn.x), Qp.x), Lc.x);
+    o.y = vstep(stepfac, vsub(vadd(vsub(P2, P1), Qn.y), Qp.y), Lc.y);
+    o.z = vstep(stepfac, vsub(vadd(vsub(P3, P2), Qn.z), Qp.z), Lc.z);
+    o.w = vstep(stepfac, vsub(vadd(vsub(P4, P3), Qn.w), Qp.w), Lc.w);
     return o;
+}
+// Q[r] of one level: gv = g[r] + g[r+1], Ln = row r+1, Lc = row r
+template <typename V, typename V4>
+__device__ __forceinline__ V4 fed_q(const V4 gv, const V4 Ln, const V4 Lc)
+{
+    return mk4(vmul(gv.x, vsub(Ln.x, Lc.x)), vmul(gv.y, vsub(Ln.y, Lc.y)), vmul(gv.z, vsub(Ln.z, Lc.z)), vmul(gv.w, vsub(Ln.w, Lc.w)));
+}
+template <typename V4> __device__ __forceinline__ V4 vneg4(const V4 a) { return mk4(vneg(a.x), vneg(a.y), vneg(a.z), vneg(a.w)); }
+template <typename V4> __device__ __forceinline__ V4 vsel4(const bool c, const V4 a, const V4 b)
+{
+    return mk4(c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z, c ? a.w : b.w);
 }
 
 

@@ -14,26 +14,30 @@
 //
 // The kernel is VALU-issue-bound (rocprof: 4 waves/SIMD x 26 % VALU-active), so the inner loop is
 // written for instruction count:
-//   * the pair sums (g+gE), (g+gS) are formed ONCE per g row (GH: 5 horizontal sums per lane,
+//   * the pair sums (g+gE), (g+gS) are formed ONCE per g row (GH: 4 horizontal sums per lane,
 //     GV: 4 vertical sums) and reused by all NS levels and by both pixels that share the pair
 //     -- (g+gE) of pixel x and (g+gW) of pixel x+1 are the same IEEE sum;
-//   * the horizontal flux product P = (g[x-1]+g[x]) * (L[x]-L[x-1]) is shared: term_E(x-1) = P,
-//     term_W(x) = -P exactly, so  (tE + tW) = P[x+1] - P[x]  bit for bit;
+//   * the flux products are shared in both directions (fed_common.h fed_row): horizontally
+//     P = (g[x-1]+g[x]) * (L[x]-L[x-1]) gives term_E(x-1) = P, term_W(x) = -P exactly, and a lane's P[0] is its left
+//     neighbour's P[4] (one wave shift); vertically Q = (g[y]+g[y+1]) * (L[y+1]-L[y]) gives term_S(y) = Q,
+//     term_N(y+1) = -Q, so a level keeps ONE L row and ONE Q row between iterations: 8.5 VALU per pixel and step
+//     instead of the 16 of the per-pixel expression;
 //   * the register windows rotate statically (loop unrolled by 6 with compile-time slots) instead
 //     of being shifted with v_mov;
 //   * border selects (reflect-101) are applied where a row / column IS a border, not per pixel.
 //
 // Bit-exactness: every level evaluates the reference's per-pixel expression in the reference's
 // order  ((tE + tW) + tS) + tN  then fma(stepfac, sum, L), and the reflect-101 rule (abs /
-// borderAdd, akazed.cu:1251-1254) is applied at EVERY level (mirroring level-0 rows instead would
-// swap the S and N terms and change roundings).
+// borderAdd, akazed.cu:1251-1254) is applied at EVERY level, as sign flips of the flux products at the
+// image border (mirroring level-0 rows instead would swap the S and N terms and change roundings).
 #include "fed_common.h"
 
 template <typename V, int NS>
 struct FedState {
     using V4 = typename FedV<V>::V4;
-    static constexpr int GS = 6;        // slots of the g-sum ring (needs NS + 2 <= GS)
-    V4 Lw[NS][3];                       // level k (0 = input): ring of 3 rows, slot = (row - origin) mod 3
+    static constexpr int GS = 6;        // slots of the g-sum rings (needs NS + 1 <= GS; divides the unroll factor)
+    V4 Lw[NS][2];                       // level j (0 = input): its two newest rows, slot = (row - origin) mod 2
+    V4 Qw[NS][2];                       // vertical flux products of level j: Q[r] at slot (r - origin) mod 2
     GHrow<V> GH[GS];                    // ring: horizontal sums of g row r        at slot (r - origin) mod GS
     V4 GV[GS];                          // ring: g[r] + g[r+1]                     at slot (r - origin) mod GS
     V4 gprev;                           // g row t-1
@@ -43,9 +47,9 @@ struct FedState {
 
 // One row-iteration.  Everything is computed unconditionally: a level-k row outside the range this
 // strip can produce exactly is garbage that no valid row ever reads (validity shrinks one row per
-// level exactly like the halo), so the body is branch-free except for the final store and the two
-// reflect-101 injections:  row -1 := row 1 (written when row 1 is produced) and row h := row h-2
-// (written at the iteration that would produce row h) -- for every level and for the g-sum ring.
+// level exactly like the halo), so the body is branch-free except for the final store and the
+// reflect-101 rule in y, which only touches the flux rows:  Q[-1] := -Q[0] when a level is at row 0 and
+// Q[h-1] := -Q[h-2] when it is at row h-1 (fed_common.h) -- no mirrored L or g rows are ever needed.
 template <typename V, int NS, int U, bool YEDGE, bool XE>
 __device__ __forceinline__ void fed_iter(FedState<V, NS>& S, const int t, const V* __restrict__ L,
                                          const V* __restrict__ G, V* __restrict__ D, const int p, const int xl,
@@ -54,45 +58,36 @@ __device__ __forceinline__ void fed_iter(FedState<V, NS>& S, const int t, const 
 {
     using V4 = typename FedV<V>::V4;
     constexpr int GS = FedState<V, NS>::GS;
-    // ---- level 0: input row t arrives (prefetched); request row t+1 (clamped: rows past the image are never used)
+    // ---- level 0: input row t arrives (prefetched); request row t+PD (clamped: rows past the image are never used)
     {
         constexpr int PD = FedState<V, NS>::PD;
         const V4 g = S.Gq[pmod(U, PD)];
-        S.Lw[0][pmod(U, 3)] = S.Lq[pmod(U, PD)];
+        S.Lw[0][pmod(U, 2)] = S.Lq[pmod(U, PD)];
         // bytes in flight, not issue rate, bound this kernel (one row ahead = 2 KB per wave < latency x bandwidth):
         // keep PD rows of L and g outstanding per wave
         const long nrow = (long)min(t + PD, h - 1) * p + xl;
         S.Lq[pmod(U, PD)] = *reinterpret_cast<const V4*>(L + nrow);
         S.Gq[pmod(U, PD)] = *reinterpret_cast<const V4*>(G + nrow);
-        const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
-        GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
-        if (XE) {                                           // only the strips that hold image column 0 or w-1
-            gh.h0 = x0 == 0 ? gh.h1 : gh.h0;                // (g+gW) at x == 0 is (g+gE)
-            gh.h4 = x0 + 3 == w - 1 ? gh.h3 : gh.h4;        // (g+gE) at x == w-1 is (g+gW)
-        }
-        S.GH[pmod(U, GS)] = gh;
+        const V gr = wave_shl1(g.x);
+        S.GH[pmod(U, GS)] = GHrow<V>{vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         S.GV[pmod(U - 1, GS)] = mk4(vadd(S.gprev.x, g.x), vadd(S.gprev.y, g.y), vadd(S.gprev.z, g.z), vadd(S.gprev.w, g.w));
         S.gprev = g;
-        if (YEDGE && t == 1) {                              // abs(y-1) = 1: row -1 := row 1, GV[-1] := GV[0]
-            S.Lw[0][pmod(U - 2, 3)] = S.Lw[0][pmod(U, 3)];
-            S.GV[pmod(U - 2, GS)] = S.GV[pmod(U - 1, GS)];
-        }
-        if (YEDGE && t == h) {                              // borderAdd(y,1,h) = h-2: row h := row h-2, GV[h-1] := GV[h-2]
-            S.Lw[0][pmod(U, 3)] = S.Lw[0][pmod(U - 2, 3)];
-            S.GV[pmod(U - 1, GS)] = S.GV[pmod(U - 2, GS)];
-        }
     }
-    // ---- levels 1..NS: level k produces row t-k from level k-1's ring (rows t-k-1, t-k, t-k+1)
+    // ---- levels 1..NS: level k produces row rho = t-k from level k-1's rows rho, rho+1 and its flux rows Q[rho-1], Q[rho]
 #pragma unroll
     for (int k = 1; k <= NS; k++) {
         const int rho = t - k;
-        const V4 out = fed_row<XE, V, V4>(S.Lw[k - 1][pmod(U - k, 3)], S.Lw[k - 1][pmod(U - k - 1, 3)],
-                                           S.Lw[k - 1][pmod(U - k + 1, 3)], S.GH[pmod(U - k, GS)],
-                                           S.GV[pmod(U - k, GS)], S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
+        const V4 Lc = S.Lw[k - 1][pmod(U - k, 2)];                              // row rho   of level k-1
+        V4 Qn = fed_q<V, V4>(S.GV[pmod(U - k, GS)], S.Lw[k - 1][pmod(U - k + 1, 2)], Lc);    // Q[rho] (row rho+1 is this iteration's)
+        V4 Qp = S.Qw[k - 1][pmod(U - k - 1, 2)];                                // Q[rho-1]
+        if (YEDGE) {                                        // (selects on values: a branch here keeps the rings out of registers)
+            Qp = vsel4(rho == 0, vneg4(Qn), Qp);            // abs(y-1) = 1
+            Qn = vsel4(rho == h - 1, vneg4(Qp), Qn);        // borderAdd(y,1,h) = h-2
+        }
+        S.Qw[k - 1][pmod(U - k, 2)] = Qn;
+        const V4 out = fed_row<XE, V, V4>(Lc, S.GH[pmod(U - k, GS)], Qn, Qp, x0, w, fac.f[k - 1]);
         if (k < NS) {
-            S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
-            if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
-            if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
+            S.Lw[k < NS ? k : 0][pmod(U - k, 2)] = out;
         } else if (rho >= ybeg && rho < yend && owns) {
             hak_store_nt(reinterpret_cast<V4*>(D + (long)rho * p + x0), out);
         }
@@ -112,10 +107,10 @@ __device__ __forceinline__ void fed_strip(const V* __restrict__ L, const V* __re
     FedState<V, NS> S;
     const V z = 0;
 #pragma unroll
-    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = mk4(z, z, z, z);
+    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Qw[k][0] = S.Qw[k][1] = mk4(z, z, z, z);
 #pragma unroll
     for (int i = 0; i < FedState<V, NS>::GS; i++) {
-        S.GH[i] = GHrow<V>{z, z, z, z, z};
+        S.GH[i] = GHrow<V>{z, z, z, z};
         S.GV[i] = mk4(z, z, z, z);
     }
     S.gprev = mk4(z, z, z, z);
@@ -125,8 +120,8 @@ __device__ __forceinline__ void fed_strip(const V* __restrict__ L, const V* __re
         S.Lq[i] = *reinterpret_cast<const V4*>(L + row);
         S.Gq[i] = *reinterpret_cast<const V4*>(G + row);
     }
-    for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 3 / mod 6: static per unrolled body
-        // the reflect injections can only fire while some level is at row 1 or row h
+    for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 2 / mod 6: static per unrolled body
+        // the reflect rule can only fire while some level is at row 0 (t <= NS) or at row h-1
         if (tb <= NS || tb + 5 >= h) {
             fed_iter<V, NS, 0, true, XE>(S, tb + 0, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);
             fed_iter<V, NS, 1, true, XE>(S, tb + 1, L, G, D, p, xl, x0, w, h, ybeg, yend, owns, fac);

@@ -39,7 +39,8 @@ struct FsState {
     V4 Rp[6];                           // row-pass rows t-5 .. t
     V4 Sm[3];                           // smooth rows a-2 .. a (a = t-2)       slot = iteration mod 3
     V SmL[3], SmR[3];                   // smooth at columns x0-1 and x0+4 of those rows
-    V4 Lw[NS][3];                       // FED level k >= 1 windows ([0] unused: level 0 reads Lr)
+    V4 Lw[NS][2];                       // FED level k >= 1: its two newest rows ([0] unused: level 0 reads Lr)
+    V4 Qw[NS][2];                       // vertical flux products of level j (fed_common.h fed_row), slot = row mod 2
     GHrow<V> GH[GS];
     V4 GV[GS];
     V4 gprev;
@@ -80,8 +81,6 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         const V4 Lc = S.Lq[pmod(U, PD)];
         S.Lr[pmod(U, 6)] = Lc;
         S.Lq[pmod(U, PD)] = fs_fetch<DEC, V, V4>(L, min(t + PD, h - 1), lp, xl, sh);
-        if (YEDGE && t == 1) S.Lr[pmod(U - 2, 6)] = Lc;                              // FED: row -1 := row 1
-        if (YEDGE && t == h) S.Lr[pmod(U, 6)] = S.Lr[pmod(U - 2, 6)];                // FED: row h := row h-2
     }
     // ---- row pass of the Gaussian on row t (akazed.cu:227-239)
     {
@@ -112,14 +111,16 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         rp.w = sf_conv(c.w, l1.w, r1.w, l2.w, r2.w, kk);
         S.Rp[pmod(U, 6)] = rp;
         if (YEDGE) {
-            if (t == 1) S.Rp[pmod(U - 2, 6)] = rp;                                   // row -1 := row 1
-            if (t == 2) S.Rp[pmod(U - 4, 6)] = rp;                                   // row -2 := row 2
+            // selects on values, not conditional stores: two adjacent `if (t == ..) ring[slot] = rp` are merged by the optimiser
+            // into ONE store through a pointer phi, which keeps the whole ring in scratch memory
+            S.Rp[pmod(U - 2, 6)] = vsel4(t == 1, rp, S.Rp[pmod(U - 2, 6)]);          // row -1 := row 1
+            S.Rp[pmod(U - 4, 6)] = vsel4(t == 2, rp, S.Rp[pmod(U - 4, 6)]);          // row -2 := row 2
             if constexpr (!DEC) {
-                if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 2, 6)];                 // row h   := row h-2
-                if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 4, 6)];             // row h+1 := row h-3
+                S.Rp[pmod(U, 6)] = vsel4(t == h, S.Rp[pmod(U - 2, 6)], S.Rp[pmod(U, 6)]);        // row h   := row h-2
+                S.Rp[pmod(U, 6)] = vsel4(t == h + 1, S.Rp[pmod(U - 4, 6)], S.Rp[pmod(U, 6)]);    // row h+1 := row h-3
             } else {                                                                 // source-extent mirror, even source height
-                if (t == h) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 1, 6)];                 // row h   := row h-1
-                if (t == h + 1) S.Rp[pmod(U, 6)] = S.Rp[pmod(U - 3, 6)];             // row h+1 := row h-2
+                S.Rp[pmod(U, 6)] = vsel4(t == h, S.Rp[pmod(U - 1, 6)], S.Rp[pmod(U, 6)]);        // row h   := row h-1
+                S.Rp[pmod(U, 6)] = vsel4(t == h + 1, S.Rp[pmod(U - 3, 6)], S.Rp[pmod(U, 6)]);    // row h+1 := row h-2
             }
         }
     }
@@ -175,32 +176,29 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
             g = mk4(sf_g_as<V>(1.f / den.x), sf_g_as<V>(1.f / den.y), sf_g_as<V>(1.f / den.z), sf_g_as<V>(1.f / den.w));
         }
         if (WRITE_G) hak_buf_store_nt(O.r, O.go + (tf >= ybeg && tf < yend ? (unsigned)(tf * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
-        const V gl = wave_shr1(g.w), gr = wave_shl1(g.x);
-        GHrow<V> gh{vadd(gl, g.x), vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
-        if (XE) {
-            gh.h0 = le ? gh.h1 : gh.h0;                     // (g+gW) at x == 0 is (g+gE)
-            gh.h4 = re ? gh.h3 : gh.h4;                     // (g+gE) at x == w-1 is (g+gW)
-        }
-        S.GH[pmod(U, GS)] = gh;
+        const V gr = wave_shl1(g.x);
+        S.GH[pmod(U, GS)] = GHrow<V>{vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         S.GV[pmod(U - 1, GS)] = mk4(vadd(S.gprev.x, g.x), vadd(S.gprev.y, g.y), vadd(S.gprev.z, g.z), vadd(S.gprev.w, g.w));
         S.gprev = g;
-        if (YEDGE && tf == 1) S.GV[pmod(U - 2, GS)] = S.GV[pmod(U - 1, GS)];        // GV[-1] := GV[0]
-        if (YEDGE && tf == h) S.GV[pmod(U - 1, GS)] = S.GV[pmod(U - 2, GS)];        // GV[h-1] := GV[h-2]
     }
-    // ---- FED levels 1..NS: level k produces row tf-k from level k-1's rows tf-k-1, tf-k, tf-k+1
+    // ---- FED levels 1..NS: level k produces row rho = tf-k from level k-1's rows rho, rho+1 and its flux rows Q[rho-1], Q[rho]
+    // (fed_common.h fed_row; reflect-101 in y = sign flips of the flux rows at rows 0 and h-1)
 #pragma unroll
     for (int k = 1; k <= NS; k++) {
         const int rho = tf - k;
-        // level 0 = the L ring (row tf-j lives in slot U-3-j); levels >= 1 = their 3-row windows
-        const V4 Lc = k == 1 ? S.Lr[pmod(U - 3 - 1, 6)] : S.Lw[k - 1][pmod(U - k, 3)];
-        const V4 Ln = k == 1 ? S.Lr[pmod(U - 3 - 2, 6)] : S.Lw[k - 1][pmod(U - k - 1, 3)];
-        const V4 Ls = k == 1 ? S.Lr[pmod(U - 3, 6)] : S.Lw[k - 1][pmod(U - k + 1, 3)];
-        const V4 out = fed_row<XE, V, V4>(Lc, Ln, Ls, S.GH[pmod(U - k, GS)], S.GV[pmod(U - k, GS)],
-                                                      S.GV[pmod(U - k - 1, GS)], x0, w, fac.f[k - 1]);
+        // level 0 = the L ring (row tf-j lives in slot U-3-j); levels >= 1 = their two newest rows
+        const V4 Lc = k == 1 ? S.Lr[pmod(U - 3 - 1, 6)] : S.Lw[k - 1][pmod(U - k, 2)];
+        const V4 Ls = k == 1 ? S.Lr[pmod(U - 3, 6)] : S.Lw[k - 1][pmod(U - k + 1, 2)];
+        V4 Qn = fed_q<V, V4>(S.GV[pmod(U - k, GS)], Ls, Lc);
+        V4 Qp = S.Qw[k - 1][pmod(U - k - 1, 2)];
+        if (YEDGE) {                                        // (selects on values: a branch here keeps the rings out of registers)
+            Qp = vsel4(rho == 0, vneg4(Qn), Qp);            // abs(y-1) = 1
+            Qn = vsel4(rho == h - 1, vneg4(Qp), Qn);        // borderAdd(y,1,h) = h-2
+        }
+        S.Qw[k - 1][pmod(U - k, 2)] = Qn;
+        const V4 out = fed_row<XE, V, V4>(Lc, S.GH[pmod(U - k, GS)], Qn, Qp, x0, w, fac.f[k - 1]);
         if (k < NS) {
-            S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = out;
-            if (YEDGE && rho == 1) S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)] = out;                                   // row -1 := row 1
-            if (YEDGE && rho == h) S.Lw[k < NS ? k : 0][pmod(U - k, 3)] = S.Lw[k < NS ? k : 0][pmod(U - k - 2, 3)];  // row h := row h-2
+            S.Lw[k < NS ? k : 0][pmod(U - k, 2)] = out;
         } else if (rho >= ybeg && rho < yend && owns) {
             // kept conditional: an unconditional store means evaluating the last level for every row, which costs ~100 VGPRs
             hak_store_nt(reinterpret_cast<V4*>(D + (long)rho * p + x0), out);
@@ -235,10 +233,10 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
 #pragma unroll
     for (int i = 0; i < 3; i++) { S.Sm[i] = z4; S.SmL[i] = z; S.SmR[i] = z; }
 #pragma unroll
-    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Lw[k][2] = z4;
+    for (int k = 0; k < NS; k++) S.Lw[k][0] = S.Lw[k][1] = S.Qw[k][0] = S.Qw[k][1] = z4;
 #pragma unroll
     for (int i = 0; i < FsState<V, NS>::GS; i++) {
-        S.GH[i] = GHrow<V>{z, z, z, z, z};
+        S.GH[i] = GHrow<V>{z, z, z, z};
         S.GV[i] = z4;
     }
     S.gprev = z4;
