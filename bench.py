@@ -329,8 +329,8 @@ def other_configs(ah, synth, args, rank):
     for _ in range(20):
         ah.check(ah.lib.hak_match(None, dq.data_ptr(), n, dt.data_ptr(), n, None))     # synchronous (cuMatch contract)
     ms = (time.perf_counter() - t0) * 1e3 / 20
-    # SURVEY 8d floor: 1e8 pairs x 8 popcll+add+xor ~ 24 VALU lane-ops per pair / (256 CU x 4 SIMD x 32 lanes x 2.4 GHz)
-    floor_ms = 1e8 * 24 / (256 * 4 * 32 * 2.4e9) * 1e3
+    # SURVEY 8d floor: 1e8 pairs x ~32 VALU lane-ops (8 x 64-bit XOR + 8 x popcount-64) / (256 CU x 64 lanes x 2.4 GHz) = 0.08 ms
+    floor_ms = 1e8 * 32 / (256 * 64 * 2.4e9) * 1e3
     out["match_10k_ms"] = round(ms, 4)
     out["match_10k_valu_floor_ms"] = round(floor_ms, 4)
     out["match_10k_frac_of_floor"] = round(floor_ms / ms, 4)

@@ -702,6 +702,7 @@ extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point*
     // ctx may be NULL (cuMatch is a free function in the reference): default stream, no profiling
     if (!d_pts1 || (!d_pts2 && n2 > 0)) return fail("null argument");
     if (n1 <= 0) return 0;
+    if (n2 >= (1 << 20)) return fail("more than 2^20 - 1 train points");         // k_match packs distance << 20 | index
     hipStream_t st = c ? c->stream : nullptr;
     if (c) {
         ProfScope ps(c, HAK_PROF_MATCH);
@@ -721,6 +722,7 @@ extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num
 {
     if (!c || !d_points || !d_num_pts || npairs < 1) return fail("bad argument");
     const long mp = c->cfg.max_pts;
+    if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");   // k_match packs distance << 20 | index
     { ProfScope ps(c, HAK_PROF_MATCH);
       hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs); }
     if (hipGetLastError() != hipSuccess) return fail("match launch failed");

@@ -25,6 +25,7 @@
 // Requires w % 4 == 0 and 1 <= S <= 4; everything else takes the LDS tile kernel.
 #include "fed_common.h"
 #include <utility>
+#include <cstdlib>
 
 namespace {
 
@@ -33,6 +34,12 @@ template <int S> struct HsGeo {
     static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
     static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
+#ifndef HAK_HS_MINW3
+#define HAK_HS_MINW3 0
+#endif
+    // waves per SIMD the register allocator must make room for: S = 3 needs 187 VGPRs unconstrained (2 waves); capped at 168
+    // it spills ~26 dwords outside the row loop's critical path and runs 3 waves (A/B: see DESIGN.md)
+    static constexpr int MINW = (HAK_HS_MINW3 && S == 3) ? 3 : (S <= 2 ? 3 : 2);
 };
 
 #define HS_CBUF 256
@@ -325,7 +332,7 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
 template <typename V, int S>
-__global__ __launch_bounds__(256) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
+__global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
 {
     using G = HsGeo<S>;
     __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
@@ -372,6 +379,9 @@ bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long 
         if ((lx - lo) >= room || (ly - lo) >= room || (det - lo) >= room) return false;
     }
     a.obase = lo; a.off_lx = (unsigned)((lx - lo) * sizeof(V)); a.off_ly = (unsigned)((ly - lo) * sizeof(V)); a.off_det = (unsigned)((det - lo) * sizeof(V));
+    // timing experiments only (results become wrong): drop the det / the Lx, Ly stores in hardware (out-of-range offsets)
+    if (getenv("HAK_EXP_HS_NODET")) a.off_det = HAK_BUF_OOB;
+    if (getenv("HAK_EXP_HS_NOLXY")) { a.off_lx = HAK_BUF_OOB; a.off_ly = HAK_BUF_OOB; }
     a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
     long map_stride = 0;
     if (b) {

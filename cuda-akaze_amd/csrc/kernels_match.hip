@@ -8,11 +8,11 @@
 // Distances are over exactly the 61 descriptor bytes (D9: the reference reads
 // 3 bytes past them); n2 < 16 and n2 == 0 are handled (D10).
 //
-// Mapping: a 256-thread block owns 16 queries x 16 residue classes.  Thread
-// (q, c) keeps query q's 64-byte descriptor in 16 VGPRs and walks class c with
-// 16 x (v_xor, v_bcnt) per train descriptor; the train descriptors are staged
-// through LDS in tiles of 128 (coalesced, once per block) and read back with
-// broadcast ds_read_b128; classes are merged through LDS.
+// Mapping: a 256-thread block owns 32 queries x 16 residue classes.  Thread
+// (q, c) keeps the 64-byte descriptors of two queries in 32 VGPRs and walks class c with
+// 16 x (v_xor, v_bcnt) per distance; the train descriptors are staged through LDS
+// in tiles of 256 (coalesced, once per block) and read back with broadcast
+// ds_read_b128, each read serving two distances; classes are merged through LDS.
 #include "hak_internal.h"
 
 #define MQ 16      // queries per block
@@ -27,13 +27,14 @@ __device__ __forceinline__ void load_desc(const hak_point* p, unsigned int d[16]
     d[15] = f[15] & 0xFFu;                      // byte 60 only; bytes 61..63 are struct padding
 }
 
-#define MT 128     // train descriptors staged per LDS tile (8 per residue class)
+#define MT 256     // train descriptors staged per LDS tile (16 per residue class)
 
 // 64-byte descriptors of train records [j0, j0 + MT) -> LDS, byte 60 masked (bytes 61..63 are struct padding).
 // Cooperative and coalesced: thread t copies dword (t & 15) of records t >> 4, (t >> 4) + 16, ...
 __device__ __forceinline__ void stage_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (*tile)[16], int tid)
 {
     const int d = tid & 15;
+#pragma unroll 4
     for (int r = tid >> 4; r < MT; r += 16) {
         const int j = j0 + r;
         unsigned int v = 0;
@@ -42,67 +43,110 @@ __device__ __forceinline__ void stage_train(const hak_point* __restrict__ pts2, 
     }
 }
 
+// v_bcnt_u32_b32 computes popcount(x) + acc in ONE instruction; left to itself the compiler takes sixteen plain popcounts
+// and rebuilds the sum as a tree of v_add3 (7 extra instructions per distance)
+__device__ __forceinline__ unsigned bcnt_acc(unsigned x, unsigned acc)
+{
+    unsigned r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
+// key = (Hamming distance << 16) | (train index - j0) of one residue-class candidate, accumulated on top of `seed` = the
+// index part: 16 x (v_xor, v_bcnt) + one shift-or
+__device__ __forceinline__ unsigned hamming_key(const unsigned int (&q)[16], const uint4 t0, const uint4 t1, const uint4 t2,
+                                                const uint4 t3, const unsigned idx)
+{
+    unsigned d = bcnt_acc(q[0] ^ t0.x, 0u);
+    d = bcnt_acc(q[1] ^ t0.y, d); d = bcnt_acc(q[2] ^ t0.z, d); d = bcnt_acc(q[3] ^ t0.w, d);
+    d = bcnt_acc(q[4] ^ t1.x, d); d = bcnt_acc(q[5] ^ t1.y, d); d = bcnt_acc(q[6] ^ t1.z, d); d = bcnt_acc(q[7] ^ t1.w, d);
+    d = bcnt_acc(q[8] ^ t2.x, d); d = bcnt_acc(q[9] ^ t2.y, d); d = bcnt_acc(q[10] ^ t2.z, d); d = bcnt_acc(q[11] ^ t2.w, d);
+    d = bcnt_acc(q[12] ^ t3.x, d); d = bcnt_acc(q[13] ^ t3.y, d); d = bcnt_acc(q[14] ^ t3.z, d); d = bcnt_acc(q[15] ^ t3.w, d);
+    return (d << 20) | idx;
+}
+
+// Mapping: a 256-thread block owns 16 * NQ queries x 16 residue classes; thread (q, c) keeps the descriptors of NQ queries
+// (q, q + 16) in 16 * NQ VGPRs and walks class c: with NQ = 2 every train descriptor read from LDS (four broadcast
+// ds_read_b128) serves two distances.  Two train descriptors are in flight per iteration.  The class minimum is tracked as
+// one packed key (distance << 20 | train index): an unsigned minimum keeps the smallest distance and, among equal
+// distances, the smallest index -- the reference's "first strict minimum in ascending order" (akazed.cu:2176-2187) -- in
+// one v_min_u32 instead of compare + two selects.  Requires n2 < 2^20 (checked by the launcher).
+// NQ = 1 is used when NQ = 2 would leave the chip with fewer than ~2 blocks per CU (one big pair, e.g. 10k x 10k).
+template <int NQ>
 __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_point* pts2_base,
                                                const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                int n1_host, int n2_host, long stride1, long stride2, int count_stride)
 {
-    __shared__ int sdist[MC][MQ];
-    __shared__ int sidx[MC][MQ];
-    __shared__ unsigned int tile[MT][16];               // 8 KB: every train descriptor is fetched once per block, not once per query group
+    constexpr int QB = MQ * NQ;                          // queries per block
+    __shared__ unsigned skey[MC][QB];
+    __shared__ unsigned int tile[MT][16];               // 16 KB: every train descriptor is fetched once per block
     const int pair = blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
     hak_point* pts1 = pts1_base + (long)pair * stride1;
     const hak_point* pts2 = pts2_base + (long)pair * stride2;
     const int q = threadIdx.x & (MQ - 1), c = threadIdx.x >> 4;     // lane = q + 16*(c%4): 4 classes per wave
-    for (int q0 = blockIdx.x * MQ; q0 < n1; q0 += gridDim.x * MQ) {
-        const int qi = q0 + q;
-        unsigned int qd[16];
-        if (qi < n1) load_desc(pts1 + qi, qd);
-        else {
+    for (int q0 = blockIdx.x * QB; q0 < n1; q0 += gridDim.x * QB) {
+        unsigned int qd[NQ][16];
+        unsigned best[NQ];
 #pragma unroll
-            for (int k = 0; k < 16; k++) qd[k] = 0;
+        for (int a = 0; a < NQ; a++) {
+#pragma unroll
+            for (int k = 0; k < 16; k++) qd[a][k] = 0;
+            if (q0 + q + MQ * a < n1) load_desc(pts1 + q0 + q + MQ * a, qd[a]);
+            best[a] = 0xFFFFFFFFu;
         }
-        int best = 1 << 30, besti = -1;
         for (int j0 = 0; j0 < n2; j0 += MT) {
             __syncthreads();                                        // previous tile's readers are done
             stage_train(pts2, j0, n2, tile, threadIdx.x);
             __syncthreads();
             const int jn = min(MT, n2 - j0);
-            for (int r = c; r < jn; r += MC) {                      // j = j0 + r keeps the residue class: MT % MC == 0
+            int r = c;                                              // j = j0 + r keeps the residue class: MT % MC == 0
+            for (; r + MC < jn; r += 2 * MC) {
                 const uint4* t4 = reinterpret_cast<const uint4*>(tile[r]);
-                int dist = 0;
+                const uint4* u4 = reinterpret_cast<const uint4*>(tile[r + MC]);
+                const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];   // 16 lanes read the same 16 bytes: LDS broadcast
+                const uint4 u0 = u4[0], u1 = u4[1], u2 = u4[2], u3 = u4[3];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint4 t = t4[k];                          // 16 lanes read the same 16 bytes: LDS broadcast
-                    dist += __popcll(((unsigned long long)(qd[4 * k + 1] ^ t.y) << 32) | (qd[4 * k] ^ t.x));
-                    dist += __popcll(((unsigned long long)(qd[4 * k + 3] ^ t.w) << 32) | (qd[4 * k + 2] ^ t.z));
+                for (int a = 0; a < NQ; a++) {
+                    best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + r)));
+                    best[a] = min(best[a], hamming_key(qd[a], u0, u1, u2, u3, (unsigned)(j0 + r + MC)));
                 }
-                if (dist < best) { best = dist; besti = j0 + r; }  // strict: first minimum of the class
+            }
+            if (r < jn) {
+                const uint4* t4 = reinterpret_cast<const uint4*>(tile[r]);
+                const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
+#pragma unroll
+                for (int a = 0; a < NQ; a++) best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + r)));
             }
         }
-        sdist[c][q] = best;
-        sidx[c][q] = besti;
+#pragma unroll
+        for (int a = 0; a < NQ; a++) skey[c][q + MQ * a] = best[a];
         __syncthreads();
-        if (c == 0 && qi < n1) {
-            int bc = 0;
-            for (int t = 1; t < MC; t++)
-                if (sdist[t][q] < sdist[bc][q]) bc = t;
-            const int dmin = sdist[bc][q];
-            int nflag = 0;
-            for (int t = 0; t < MC; t++) nflag += dmin < sdist[t][q] ? 1 : 0;       // akazed.cu:2206
-            hak_point* p1 = pts1 + qi;
-            const int bi = sidx[bc][q];
-            if (bi >= 0 && nflag == MC - 1 && dmin < HAK_MAX_DIST) {                // akazed.cu:2223
-                p1->match = bi;
-                p1->distance = dmin;
-                p1->match_x = pts2[bi].x;
-                p1->match_y = pts2[bi].y;
-            } else {
-                p1->match = -1;
-                p1->distance = -1;
-                p1->match_x = -1.f;
-                p1->match_y = -1.f;
+        if (c < NQ) {                                               // class-c threads finish queries q + 16 c
+            const int qq = q + MQ * c, qi = q0 + qq;
+            if (qi < n1) {
+                // distances only (key >> 20): the accept rule compares class minima, not indices (akazed.cu:2190-2223)
+                int bc = 0;
+                for (int t = 1; t < MC; t++)
+                    if ((skey[t][qq] >> 20) < (skey[bc][qq] >> 20)) bc = t;
+                const unsigned kmin = skey[bc][qq];
+                const int dmin = (int)(kmin >> 20);
+                int nflag = 0;
+                for (int t = 0; t < MC; t++) nflag += (unsigned)dmin < (skey[t][qq] >> 20) ? 1 : 0;   // akazed.cu:2206
+                hak_point* p1 = pts1 + qi;
+                const int bi = (int)(kmin & 0xFFFFFu);
+                if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {  // akazed.cu:2223
+                    p1->match = bi;
+                    p1->distance = dmin;
+                    p1->match_x = pts2[bi].x;
+                    p1->match_y = pts2[bi].y;
+                } else {
+                    p1->match = -1;
+                    p1->distance = -1;
+                    p1->match_x = -1.f;
+                    p1->match_y = -1.f;
+                }
             }
         }
         __syncthreads();
@@ -239,10 +283,15 @@ void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pt
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs)
 {
-    int nq = n1_dev ? 0 : n1_host;
-    int gx = n1_dev ? 640 : (nq + MQ - 1) / MQ;
+    // two queries per thread halve the LDS traffic per distance but also the number of blocks: only when the grid still
+    // covers the chip a few times (batched pairs); one big pair (10k x 10k) keeps one query per thread
+    const int nq = n1_dev ? 0 : n1_host;
+    const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;
+    const int qb = two ? 2 * MQ : MQ;
+    int gx = n1_dev ? (two ? 320 : 640) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
     dim3 grid(gx, npairs);
-    k_match<<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2);
+    if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2);
+    else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2);
 }

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on the GPU box (run via gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r01_e
+#   bash tools/refresh_profiles.sh r02_c
 # Every profiler run is wrapped in `timeout`; PMC passes are separate runs without any trace option.
 set -u
 TAG=${1:-r02_x}
@@ -16,6 +16,15 @@ P="python3 $R/bench.py --steps 1 --warmup 1 --serial --no-pipeline --no-cpu-base
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcF -- $P > $OUT/pmcF.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcW -- $P > $OUT/pmcW.log 2>&1
 python3 $R/tools/pmc_traffic.py $OUT/pmcF $OUT/pmcW $OUT/pmc_traffic > $OUT/pmc_traffic.log 2>&1
+# SQ counters (two passes of 8): wave cycles / waits / active instruction classes, then instruction counts
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
+    --output-format csv -d $OUT/sqA -- $P > $OUT/sqA.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES \
+    --output-format csv -d $OUT/sqB -- $P > $OUT/sqB.log 2>&1
+python3 $R/tools/pmc_summary.py --table $OUT/sqA $OUT/sqB > $OUT/sq_counters.txt 2>&1
 find $OUT -name "*kernel_stats.csv" | head
 tail -1 $OUT/bench.json | cut -c1-400
-cat $OUT/pmc_traffic.log | cut -c1-400
+cat $OUT/pmc_traffic.log | cut -c1-600
+# keep the merged-back payload small: the raw per-dispatch counter dumps are summarised above
+rm -rf $OUT/pmcF $OUT/pmcW $OUT/sqA $OUT/sqB
+find $OUT -name "*kernel_trace.csv" -delete
