@@ -170,23 +170,6 @@ template <typename V> __device__ __forceinline__ V sf_g_as(float g);
 template <> __device__ __forceinline__ float sf_g_as<float>(float g) { return g; }
 template <> __device__ __forceinline__ int sf_g_as<int>(float g) { return (int)(g * 65536 + 0.5f); }
 
-// ---- dilated Scharr / determinant / key helpers of the Hessian kernels (kernels_hessian.hip, kernels_hessian_stream.hip)
-// Shared by both pipelines: V = float (akaze) and V = int (fastakaze 16.16 fixed point,
-// akazed.cu:3339-3403: every weighted sum is followed by >> 16; the determinant is not shifted).
-__device__ __forceinline__ float hs_d(float f1, float f2, float a, float b) { return f1 * a + f2 * b; }
-__device__ __forceinline__ int hs_d(int f1, int f2, int a, int b)
-{
-    return (int)((unsigned)f1 * (unsigned)a + (unsigned)f2 * (unsigned)b) >> 16;
-}
-__device__ __forceinline__ float hs_det(float dxx, float dyy, float dxy) { return dxx * dyy - dxy * dxy; }
-__device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
-{
-    return (int)((unsigned)dxx * (unsigned)dyy - (unsigned)dxy * (unsigned)dxy);
-}
-__device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
-__device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
-
-
 // ---- 1 / d for the PM_G2 conductivity g = 1 / (1 + dif2).  hipcc's correctly rounded float division costs ~11 instructions
 // (v_div_scale x2, v_rcp, four fmas, v_div_fmas, v_div_fixup).  For 1 <= d < 2^64 the three-instruction sequence below --
 // v_rcp_f32 plus one Newton step with explicit fmas -- returns the identical bits: checked exhaustively over all 2^29

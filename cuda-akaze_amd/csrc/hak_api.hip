@@ -174,6 +174,7 @@ struct hak_ctx {
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
+    bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
     bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
 };
 
@@ -222,7 +223,7 @@ static int build_plan(hak_ctx* c, int w, int h)
     long off = 0;
     for (int o = 0; o < noct; o++) {
         L.oct[o].plane = (long)L.oct[o].h * L.oct[o].p;
-        L.lvl_off[o] = off;       off += 4L * L.ms * L.oct[o].plane;
+        L.lvl_off[o] = off;       off += 3L * L.ms * L.oct[o].plane;      // Lt[ms] + interleaved {Lx, Ly}[ms] (2 planes each)
         L.smooth_off[o] = off;    off += L.oct[o].plane;
         L.flow_off[o] = off;      off += L.oct[o].plane;
         L.tmp_off[o] = off;       off += L.oct[o].plane;
@@ -272,6 +273,9 @@ static int build_plan(hak_ctx* c, int w, int h)
         c->htab.sigma_size[l] = c->plan[l].sigma_size;
     }
     for (int r2 = 0; r2 < 36; r2++) c->htab.orient_w[r2] = hak_expf(-r2 * 0.08f);  // akazed.cu:1697
+    hak_deriv_factors(&c->htab.fac1, &c->htab.fac2);
+    c->htab.ifac1 = (int)(c->htab.fac1 * 65536 + 0.5f);                           // akazed.cu:4183-4184
+    c->htab.ifac2 = (int)(c->htab.fac2 * 65536 + 0.5f);
     hak_compare_indices(c->htab.comp1, c->htab.comp2);
     for (int b = 0; b < 61; b++)
         for (int i = 0; i < 8; i++) {
@@ -400,6 +404,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     float* A = c->arena;
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
+    c->last_fast = false;
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
 
@@ -421,13 +426,14 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             float* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
                 { ProfScope ps(c, HAK_PROF_CONTRAST, st);                          // akaze.cpp:329-332 in two passes over img
-                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, A + L.det(0, 0) /* free until the Hessian of (0,0) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
+                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp /* free until the FED cycle of (0,1) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
                                         c->taps_base, c->base_R, c->state, cfg.per, L.noct); }
                 if (c->concurrent) (void)hipEventRecord(c->ev_ready[0], st);       // Lt(0,0) + contrast factors ready
                 { ProfScope ps(c, HAK_PROF_HESSIAN, st);
-                  if (!hak_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                  // (the determinant goes to HBM only in the dilation > 4 fallback: `flow` is free here and at every later call)
+                  if (!hak_launch_hessian_level(st, Lt, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
                                                 lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
-                      hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
+                      hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]); }
                 continue;
             }
             const int n = lp.nsteps;
@@ -499,9 +505,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
             }
             { ProfScope ps(c, HAK_PROF_HESSIAN, st);                              // akaze.cpp:423
-              if (!hak_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+              if (!hak_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
                                             lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
-                  hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold); }
+                  hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]); }
         }
         // akaze.cpp:431-433 hCalcExtremaMap: fused into the per-level Hessian kernel above
         if (c->concurrent && o > 0) (void)hipEventRecord(c->ev_done[o], st);
@@ -531,6 +537,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     const long S = L.arena;
     HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
     const int idthreshold = 65;                                                   // akaze.cpp:559
+    c->last_fast = true;
     hakf_launch_reset(st, c->state, nimg);              // (the key map is all zero here: hak_create / k_clear_cand_maps)
     if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
     c->maps_dirty = true;
@@ -544,16 +551,16 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             int* Lt = A + L.lt(o, s);
             if (o == 0 && s == 0) {                                               // akaze.cpp:589-623
                 // one fused pass + a histogram pass over the gradient plane it leaves in det(0,0) (free until the Hessian below)
-                if (!hakf_launch_base_level(st, d_images, image_stride, pitch, Lt, A + L.det(0, 0), S, oc.w, oc.h, oc.p, nimg, c->itaps1,
+                if (!hakf_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp, S, oc.w, oc.h, oc.p, nimg, c->itaps1,
                                             c->itaps_base, c->base_R, c->state, cfg.per, L.noct)) {
                     hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
                     hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
                     hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
                 }
-                if (!hakf_launch_hessian_level(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+                if (!hakf_launch_hessian_level(st, Lt, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
                                                lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
-                    hakf_launch_hessian(st, Lt, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-                    hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+                    hakf_launch_hessian(st, Lt, A + L.dxy(o, s), flow, S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                    hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold, L.flow_off[o]);
                 }
                 continue;
             }
@@ -594,10 +601,10 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 done += ns;
                 src = dst;
             }
-            if (!hakf_launch_hessian_level(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg,
+            if (!hakf_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
                                            lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
-                hakf_launch_hessian(st, smooth, A + L.lx(o, s), A + L.ly(o, s), A + L.det(o, s), S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-                hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold);
+                hakf_launch_hessian(st, smooth, A + L.dxy(o, s), flow, S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold, L.flow_off[o]);
             }
         }
     }
@@ -904,11 +911,32 @@ extern "C" int hak_debug_plane(hak_ctx* c, int img, int kind, int o, int s, floa
 {
     if (!c || img < 0 || img >= c->cfg.batch || o < 0 || o >= c->L.noct || s < 0 || s >= c->L.ms) return fail("bad plane");
     const HakLayout& L = c->L;
-    long off = kind == HAK_PLANE_LT ? L.lt(o, s) : kind == HAK_PLANE_DET ? L.det(o, s) : kind == HAK_PLANE_LX ? L.lx(o, s) : L.ly(o, s);
+    const HakOct oc = L.oct[o];
     HIP_TRY(hipStreamSynchronize(c->stream));
-    HIP_TRY(hipMemcpy2D(h_dst, sizeof(float) * L.oct[o].w, c->arena + (long)img * L.arena + off, sizeof(float) * L.oct[o].p,
-                        sizeof(float) * L.oct[o].w, L.oct[o].h, hipMemcpyDeviceToHost));
-    return 0;
+    const float* arena = c->arena + (long)img * L.arena;
+    if (kind == HAK_PLANE_LT) {
+        HIP_TRY(hipMemcpy2D(h_dst, sizeof(float) * oc.w, arena + L.lt(o, s), sizeof(float) * oc.p, sizeof(float) * oc.w, oc.h, hipMemcpyDeviceToHost));
+        return 0;
+    }
+    // Lx / Ly live interleaved; the determinant is not stored at all (HakLayout): both are produced here, for the tests, by
+    // the unfused kernels from the stored derivative plane
+    float* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, sizeof(float) * 2 * (size_t)oc.plane));
+    int rc = 0;
+    const float* src = tmp;
+    if (kind == HAK_PLANE_DET) {
+        const int step = c->plan[(size_t)o * L.ms + s].sigma_size;
+        if (c->last_fast) hakf_launch_det(nullptr, reinterpret_cast<const int*>(arena + L.dxy(o, s)), reinterpret_cast<int*>(tmp), 0, oc.w, oc.h, oc.p, 1, step);
+        else hak_launch_hessian(nullptr, arena + L.dxy(o, s), tmp, 0, oc.w, oc.h, oc.p, 1, step);
+    } else {
+        hak_launch_deinterleave(nullptr, arena + L.dxy(o, s), tmp, tmp + oc.plane, oc.w, oc.h, oc.p);
+        if (kind == HAK_PLANE_LY) src = tmp + oc.plane;
+    }
+    if (hipDeviceSynchronize() != hipSuccess) rc = fail("debug plane kernel");
+    if (!rc && hipMemcpy2D(h_dst, sizeof(float) * oc.w, src, sizeof(float) * oc.p, sizeof(float) * oc.w, oc.h, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail("debug plane copy");
+    (void)hipFree(tmp);
+    return rc;
 }
 
 extern "C" int hak_debug_kcontrast(hak_ctx* c, int img, float* kc)
@@ -957,7 +985,7 @@ extern "C" int hak_query_traffic(const hak_ctx* c, int npts_hint, hak_traffic* o
     out->fed_fused_bytes = c->fed_fused_bytes;
     double lvl_px = 0;
     for (int o = 0; o < L.noct; o++) lvl_px += (double)L.ms * L.oct[o].w * L.oct[o].h;
-    out->hessian_bytes = 16.0 * lvl_px;                                           // read smooth, write Lx, Ly, det
+    out->hessian_bytes = 12.0 * lvl_px;                                           // read smooth, write the interleaved {Lx, Ly} plane
     out->prologue_bytes = 16.0 * L.oct[0].w * L.oct[0].h;                         // read img, write Lt + gradient; re-read gradient (histogram)
     out->describe_bytes = (872.0 + 5292.0) * npts_hint;                           // sampled bytes per keypoint (orientation + MLDB)
     out->nms_bytes = 104.0 * npts_hint;
@@ -1077,8 +1105,14 @@ extern "C" int hak_op_nld_steps(const float* src, const float* flow, float* dst,
 
 extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, int w, int h, int p, int step)
 {
-    hak_launch_hessian_level(nullptr, s, lx, ly, det, 0, w, h, p, 1, step, nullptr, nullptr, nullptr, 0, 0, 0.f);
-    HIP_TRY(hipDeviceSynchronize());
+    // the kernels write the derivatives interleaved (HakLayout); the test interface keeps the reference's three planes
+    float* dxy = nullptr;
+    HIP_TRY(hipMalloc((void**)&dxy, sizeof(float) * 2 * (size_t)h * p));
+    hak_launch_hessian_level(nullptr, s, dxy, det, true, 0, w, h, p, 1, step, nullptr, nullptr, nullptr, 0, 0, 0.f);
+    hak_launch_deinterleave(nullptr, dxy, lx, ly, w, h, p);
+    const hipError_t e = hipDeviceSynchronize();
+    (void)hipFree(dxy);
+    if (e != hipSuccess) return fail(std::string("hak_op_hessian: ") + hipGetErrorString(e));
     return 0;
 }
 

@@ -14,19 +14,20 @@ struct HakOct {
 };
 
 // Per-image arena (floats). Planes persist until the descriptors are done.
-//   per (octave o, sublevel s): Lt, det, Lx, Ly                 persistent
-//   per octave: smooth, flow, tmp                                scratch
+//   per (octave o, sublevel s): Lt (1 plane) and Dxy (2 planes' worth: the first derivatives INTERLEAVED, element
+//                               (y, x) = {Lx, Ly} at dxy + 2 * (y * p + x))                      persistent
+//   per octave: smooth, flow, tmp                                                                  scratch
+// The determinant is never stored: its only consumers are the extrema test (fused into the Hessian kernels) and the
+// sub-pixel refinement of the ~2 k keypoints, which re-evaluates the nine values it needs from Dxy (hak_det_at).
 struct HakLayout {
     int noct, ms;
     HakOct oct[HAK_MAX_OCTAVES];
-    long lvl_off[HAK_MAX_OCTAVES];              // start of the 4*ms persistent planes of octave o
+    long lvl_off[HAK_MAX_OCTAVES];              // start of the 3*ms persistent planes of octave o
     long smooth_off[HAK_MAX_OCTAVES], flow_off[HAK_MAX_OCTAVES], tmp_off[HAK_MAX_OCTAVES];
     long arena;                                 // floats per image
 
-    __host__ __device__ long lt(int o, int s) const { return lvl_off[o] + (long)(0 * ms + s) * oct[o].plane; }
-    __host__ __device__ long det(int o, int s) const { return lvl_off[o] + (long)(1 * ms + s) * oct[o].plane; }
-    __host__ __device__ long lx(int o, int s) const { return lvl_off[o] + (long)(2 * ms + s) * oct[o].plane; }
-    __host__ __device__ long ly(int o, int s) const { return lvl_off[o] + (long)(3 * ms + s) * oct[o].plane; }
+    __host__ __device__ long lt(int o, int s) const { return lvl_off[o] + (long)s * oct[o].plane; }
+    __host__ __device__ long dxy(int o, int s) const { return lvl_off[o] + (long)(ms + 2 * s) * oct[o].plane; }
 };
 
 // Per-image device scalars.
@@ -48,6 +49,8 @@ struct HakTables {
     float borders[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
     int sigma_size[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
     float orient_w[36];                                // exp(-r2*0.08f)
+    float fac1, fac2;                                  // dilated-Scharr factors (akazed.cu:2537-2539); FAST: ifac = (int)(fac * 65536 + 0.5f)
+    int ifac1, ifac2;
     int comp1[488], comp2[488];                        // MLDB pair table (akazed.cu:65-159)
     unsigned char comp_packed[64 * 16];                // per descriptor byte: 8 x (idx1, idx2) as bytes
 };
@@ -99,6 +102,41 @@ static inline unsigned hak_xcd_grid(int nbx, int nby, int nimg) { return (unsign
 __device__ __forceinline__ void hak_lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// ---- dilated Scharr / determinant / key helpers of the Hessian kernels (kernels_hessian.hip, kernels_hessian_stream.hip,
+// kernels_scalespace.hip) and of the keypoint refinement.  Shared by both pipelines: V = float (akaze) and V = int
+// (fastakaze 16.16 fixed point, akazed.cu:3339-3403: every weighted sum is followed by >> 16; the determinant is not shifted).
+__device__ __forceinline__ float hs_d(float f1, float f2, float a, float b) { return f1 * a + f2 * b; }
+__device__ __forceinline__ int hs_d(int f1, int f2, int a, int b)
+{
+    return (int)((unsigned)f1 * (unsigned)a + (unsigned)f2 * (unsigned)b) >> 16;
+}
+__device__ __forceinline__ float hs_det(float dxx, float dyy, float dxy) { return dxx * dyy - dxy * dxy; }
+__device__ __forceinline__ int hs_det(int dxx, int dyy, int dxy)
+{
+    return (int)((unsigned)dxx * (unsigned)dyy - (unsigned)dxy * (unsigned)dxy);
+}
+__device__ __forceinline__ unsigned hs_key_bits(float v) { return __float_as_uint(v); }     // positive floats order like their bits
+__device__ __forceinline__ unsigned hs_key_bits(int v) { return (unsigned)v; }              // positive ints
+
+// Hessian determinant of one level at (x, y), re-evaluated from the interleaved derivative plane with the expressions and
+// the reflect-101 index rule of the Hessian kernels (akazed.cu:1318-1330): bit-identical to the value those kernels
+// compared in their extrema test.  The determinant plane itself is never written (hak_internal.h HakLayout).
+template <typename V>
+__device__ __forceinline__ V hak_det_at(const V* __restrict__ dxy, int x, int y, int S, int w, int h, int p, V f1, V f2)
+{
+    const long x0 = hak_refl(x - S, w), x1 = x, x2 = hak_refl(x + S, w);
+    const long o0 = (long)hak_refl(y - S, h) * p, o1 = (long)y * p, o2 = (long)hak_refl(y + S, h) * p;
+    const V xul = dxy[2 * (o0 + x0)], xuc = dxy[2 * (o0 + x1)], xur = dxy[2 * (o0 + x2)];
+    const V xcl = dxy[2 * (o1 + x0)], xcr = dxy[2 * (o1 + x2)];
+    const V xll = dxy[2 * (o2 + x0)], xlc = dxy[2 * (o2 + x1)], xlr = dxy[2 * (o2 + x2)];
+    const V yul = dxy[2 * (o0 + x0) + 1], yuc = dxy[2 * (o0 + x1) + 1], yur = dxy[2 * (o0 + x2) + 1];
+    const V yll = dxy[2 * (o2 + x0) + 1], ylc = dxy[2 * (o2 + x1) + 1], ylr = dxy[2 * (o2 + x2) + 1];
+    const V dxx = hs_d(f1, f2, xur + xlr - xul - xll, xcr - xcl);
+    const V dxy_ = hs_d(f1, f2, xlr + xll - xur - xul, xlc - xuc);
+    const V dyy = hs_d(f1, f2, ylr + yll - yur - yul, ylc - yuc);
+    return hs_det(dxx, dyy, dxy_);
 }
 
 // ------------------------------------------------- deterministic float32 math
@@ -214,16 +252,18 @@ static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
 }
 extern int hak_hessian_stream_enabled;
 extern int hak_hessian_cbuf_cap;       // tile kernel: staged candidates per block (env HAK_HESS_CBUF, tests only)
-bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+// dxy: interleaved {Lx, Ly} plane (2 * h * p elements).  det: where the determinant goes -- the fused kernels write it only
+// when store_det is set (stage tests); the launch sequence passes a scratch plane that only the dilation > 4 fallback fills.
+bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
-bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
                                 const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
-bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
-bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
@@ -267,17 +307,20 @@ int hak_fed_groups(int n, int max_fuse, int w);
 int hak_fed_group_size(int n, int G, int g);
 void hak_launch_fed_group(hipStream_t st, const float* src, const float* flow, float* dst, long stride,
                           int w, int h, int p, int nimg, const float* tau, int ns);
-void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly, long stride,
+void hak_launch_derivate(hipStream_t st, const float* src, float* dxy, long stride,
                          int w, int h, int p, int nimg, int step);
-void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
+void hak_launch_hessian(hipStream_t st, const float* dxy, float* det, long stride,
                         int w, int h, int p, int nimg, int step);
+void hak_deriv_factors(float* fac1, float* fac2);            // akazed.cu:2537-2539
+// interleaved {a, b} plane (pitch 2p) -> two dense planes (pitch p); bytes are copied, so it serves both element types
+void hak_launch_deinterleave(hipStream_t st, const float* ab, float* a, float* b, int w, int h, int p);
 
 void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, float* dst, long dst_stride,
                           int dp, int w, int h, int nimg);
 
 // detector tail (kernels_detect.hip)
 void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
-                              int s, float dthreshold);
+                              int s, float dthreshold, long det_off);
 void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d_num, long max_pts, int nimg, hak_point* h_points,
                          int* h_num);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
@@ -295,8 +338,10 @@ void hakf_launch_contrast(hipStream_t st, const int* smooth, long stride, int w,
 void hakf_launch_flow(hipStream_t st, const int* src, int* dst, long stride, int w, int h, int p, int nimg, int type,
                       const HakImgState* state, int octave);
 void hakf_launch_nld_step(hipStream_t st, const int* src, const int* flow, int* dst, long stride, int w, int h, int p, int nimg, float tau);
-void hakf_launch_hessian(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride, int w, int h, int p, int nimg, int step);
-void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold);
+void hakf_launch_hessian(hipStream_t st, const int* src, int* dxy, int* det, long stride, int w, int h, int p, int nimg, int step);
+void hakf_launch_det(hipStream_t st, const int* dxy, int* det, long stride, int w, int h, int p, int nimg, int step);
+void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold,
+                         long det_off);
 void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
                           int patsize, int upright, int desc);
 

@@ -53,6 +53,17 @@ __device__ __forceinline__ V dsc_ld(const V* base, unsigned byte_off)
     return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + byte_off);
 }
 
+// both first derivatives of one sample: ONE 8-byte gather from the interleaved {Lx, Ly} plane (HakLayout) -- one sector
+// instead of two per sample; byte_off = element offset of the pixel * sizeof(V), as for dsc_ld
+template <typename V> struct DscV2;
+template <> struct DscV2<float> { using T = float2; };
+template <> struct DscV2<int> { using T = int2; };
+template <typename V>
+__device__ __forceinline__ typename DscV2<V>::T dsc_ld2(const V* base, unsigned byte_off)
+{
+    return *reinterpret_cast<const typename DscV2<V>::T*>(reinterpret_cast<const char*>(base) + 2u * byte_off);
+}
+
 template <typename V>
 __device__ __forceinline__ void reduce_rows(const V* acc, V* vals, int nrows, int out_base, int lane)
 {
@@ -97,17 +108,27 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
         const int layer = __builtin_amdgcn_readfirstlane(pt->octave);   // one keypoint per wave: plane bases stay in SGPRs
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
-        const V* dxd = arena + L.lx(o, s);
-        const V* dyd = arena + L.ly(o, s);
+        const V* dxyd = arena + L.dxy(o, s);
         if constexpr (FAST) {
+            // refinement on the integer determinant (akazed.cu:3600), re-evaluated from the derivative plane (hak_det_at): lanes
+            // 0..8 take one value of the 3x3 neighbourhood each, lane 0 finishes
+            int dvl = 0;
+            {
+                const int y = (int)pty >> o, x = (int)ptx >> o;
+                if (lane < 9)
+                    dvl = hak_det_at<int>(dxyd, x + lane % 3 - 1, y + lane / 3 - 1, tab->sigma_size[layer], oc.w, oc.h, oc.p, tab->ifac1, tab->ifac2);
+            }
+            int dv[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#pragma unroll
+                for (int i = 0; i < 3; i++) dv[j][i] = __shfl(dvl, 3 * j + i);
             if (lane == 0) {
-                const int* detd = arena + L.det(o, s);
-                const int y = (int)pty >> o, x = (int)ptx >> o, p = oc.p;
-                const long idx = (long)y * p + x;
-                const int v2 = detd[idx] + detd[idx];
-                const int dx = (detd[idx + 1] - detd[idx - 1]) >> 1, dy = (detd[idx + p] - detd[idx - p]) >> 1;
-                const int dxx = detd[idx + 1] + detd[idx - 1] - v2, dyy = detd[idx + p] + detd[idx - p] - v2;
-                const int dxy = (detd[idx + p + 1] + detd[idx - p - 1] - detd[idx - p + 1] - detd[idx + p - 1]) >> 2;
+                const int y = (int)pty >> o, x = (int)ptx >> o;
+                const int v2 = dv[1][1] + dv[1][1];
+                const int dx = (dv[1][2] - dv[1][0]) >> 1, dy = (dv[2][1] - dv[0][1]) >> 1;
+                const int dxx = dv[1][2] + dv[1][0] - v2, dyy = dv[2][1] + dv[0][1] - v2;
+                const int dxy = (dv[2][2] + dv[0][0] - dv[0][2] - dv[2][0]) >> 2;
                 const int dd = dsc_add(dsc_mul(dxx, dyy), -dsc_mul(dxy, dxy));
                 const float idd = dd != 0 ? (1.f / dd) : 0.f;
                 const float dst0 = idd * dsc_add(dsc_mul(dxy, dy), -dsc_mul(dyy, dx));
@@ -139,8 +160,11 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
                 gr2[q] = (tix < 208 && r2 < 36) ? r2 : -1;
                 const int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
                 const unsigned pos = (unsigned)(yy * oc.p + xx) * (unsigned)sizeof(V);
-                gdx[q] = gr2[q] >= 0 ? (float)dsc_ld(dxd, pos) : 0.f;
-                gdy[q] = gr2[q] >= 0 ? (float)dsc_ld(dyd, pos) : 0.f;
+                if (gr2[q] >= 0) {
+                    const auto d2 = dsc_ld2(dxyd, pos);
+                    gdx[q] = (float)d2.x;
+                    gdy[q] = (float)d2.y;
+                } else gdx[q] = gdy[q] = 0.f;
             }
             // valid samples are compacted in ascending thread order through a ballot
             int nvalid = 0;
@@ -237,8 +261,7 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
         const int o = layer / L.ms, s = layer - o * L.ms;
         const HakOct oc = L.oct[o];
         const V* imd = arena + L.lt(o, s);
-        const V* dxd = arena + L.lx(o, s);
-        const V* dyd = arena + L.ly(o, s);
+        const V* dxyd = arena + L.dxy(o, s);
         float angle = 0.f;
 
         if (!upright) angle = pt->angle;                            // written by k_orient
@@ -284,8 +307,11 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
                 yp = min(max(yp, 0), oc.h - 1);
                 const unsigned pos = (unsigned)(yp * oc.p + xp) * (unsigned)sizeof(V);
                 vim[n] = ok ? dsc_ld(imd, pos) : V(0);
-                gdx[n] = ok ? dsc_ld(dxd, pos) : V(0);
-                gdy[n] = ok ? dsc_ld(dyd, pos) : V(0);
+                if (ok) {
+                    const auto d2 = dsc_ld2(dxyd, pos);
+                    gdx[n] = d2.x;
+                    gdy[n] = d2.y;
+                } else gdx[n] = gdy[n] = V(0);
             }
 #pragma unroll
             for (int n = 0; n < MAX_SMP; n++) {
@@ -341,8 +367,9 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
                 xp = min(max(xp, 0), oc.w - 1);
                 yp = min(max(yp, 0), oc.h - 1);
                 const unsigned pos = (unsigned)(yp * oc.p + xp) * (unsigned)sizeof(V);
-                const V im = dsc_ld(imd, pos), dx = dsc_ld(dxd, pos), dy = dsc_ld(dyd, pos);
-                scatter(x, y, im, rot_x(dx, dy, si, co), rot_y(dx, dy, si, co));
+                const V im = dsc_ld(imd, pos);
+                const auto d2 = dsc_ld2(dxyd, pos);
+                scatter(x, y, im, rot_x(d2.x, d2.y, si, co), rot_y(d2.x, d2.y, si, co));
             }
             hak_lds_barrier();
             reduce_rows(acc, vals, min(ACC_ROWS, 87 - r0), r0, lane);

@@ -23,11 +23,11 @@ __device__ __forceinline__ int key_layer(unsigned long long k) { return (int)(0x
 __global__ __launch_bounds__(256) void k_extrema(const float* __restrict__ base, long stride, unsigned long long* maps,
                                                  long map_stride, unsigned long long* cand, long cand_cap,
                                                  HakImgState* state, HakLayout L, const HakTables* __restrict__ tab,
-                                                 int octave, int s, float threshold)
+                                                 int octave, int s, float threshold, long det_off)
 {
     const int img = blockIdx.z;
     const HakOct oc = L.oct[octave];
-    const float* det = base + (long)img * stride + L.det(octave, s);
+    const float* det = base + (long)img * stride + det_off;        // scratch plane filled by the unfused k_hessian
     const int layer = octave * L.ms + s;
     const float border = tab->borders[layer];
     const int psz = (int)tab->borders[octave * L.ms];               // akazed.cu:2572
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void k_row_scan(int* rowcount, int h, HakImgSt
     for (int i = beg; i < end; i++) { int t = rc[i]; rc[i] = run; run += t; }
 }
 
-// emit survivors in raster order + gRefine (akazed.cu:1615-1662); one wave per row
+// emit survivors in raster order; one wave per row
 __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, long stride,
                                               const unsigned long long* __restrict__ maps, long map_stride,
                                               HakLayout L, const HakTables* __restrict__ tab,
@@ -140,7 +140,6 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
     const int lane = threadIdx.x & 63;
     if (y >= h) return;
     const unsigned long long* map = maps + (long)img * map_stride;
-    const float* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
     int row_base = rowstart[(long)img * h + y];
     for (int w0 = 0; w0 < words_per_row; w0 += 64) {
@@ -160,30 +159,8 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
                 int x = (w0 + lane) * 64 + bit;
                 unsigned long long k = map[(long)y * p0 + x];
                 int layer = key_layer(k);
-                int o = layer / L.ms, s = layer - o * L.ms;
-                float px = (float)x, py = (float)y;
-                // refine on the det plane of the winning level
-                const float* det = arena + L.det(o, s);
-                int pp = L.oct[o].p;
-                int yy = y >> o, xx = x >> o;
-                long id = (long)yy * pp + xx;
-                float c = det[id];
-                float v2 = c + c;
-                float dx = 0.5f * (det[id + 1] - det[id - 1]);
-                float dy = 0.5f * (det[id + pp] - det[id - pp]);
-                float dxx = det[id + 1] + det[id - 1] - v2;
-                float dyy = det[id + pp] + det[id - pp] - v2;
-                float dxy = 0.25f * (det[id + pp + 1] + det[id - pp - 1] - det[id - pp + 1] - det[id + pp - 1]);
-                float dd = dxx * dyy - dxy * dxy;
-                float idd = dd != 0.f ? 1.f / dd : 0.f;
-                float dst0 = idd * (dxy * dy - dyy * dx);
-                float dst1 = idd * (dxy * dx - dxx * dy);
-                bool weak = dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f;
-                if (!weak && !fast) {                               // FAST path refines on its int planes (kernels_fast.hip)
-                    int ratio = 1 << o;
-                    py = ratio * (yy + dst1);
-                    px = ratio * (xx + dst0);
-                }
+                // integer position; the sub-pixel refinement (akazed.cu:1615-1662) follows in k_refine, sixteen lanes per keypoint
+                const float px = (float)x, py = (float)y;
                 hak_point* pt = pts + idx;
                 pt->x = px;
                 pt->y = py;
@@ -205,13 +182,62 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
     }
 }
 
+// gRefine (akazed.cu:1615-1662) on the determinant of the winning level.  The determinant plane is not stored (HakLayout):
+// the nine values of the 3x3 neighbourhood are re-evaluated from the level's derivative plane, bit-identical to what the
+// Hessian kernel had in its extrema test (hak_det_at) -- one lane per value (14 gathers each), sixteen lanes per keypoint,
+// so the 126 gathers of a keypoint are in flight together instead of in one lane's dependency chain.
+__global__ __launch_bounds__(256) void k_refine(const float* __restrict__ base, long stride, HakLayout L,
+                                                const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
+                                                hak_point* points, int max_pts)
+{
+    const int img = blockIdx.y;
+    const int n = state[img].num_pts;
+    if (blockIdx.x * 16 >= n) return;                               // (block-uniform)
+    const int g = threadIdx.x & 15;
+    const int lane = threadIdx.x & 63;
+    const int kp = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool live = kp < n;
+    hak_point* pt = points + (long)img * max_pts + (live ? kp : 0);
+    const int layer = live ? pt->octave : 0;
+    const int o = layer / L.ms, s = layer - o * L.ms;
+    const HakOct oc = L.oct[o];
+    const int x = live ? (int)pt->x : 0, y = live ? (int)pt->y : 0;     // still the integer full-resolution position
+    const int xx = x >> o, yy = y >> o;
+    float d = 0.f;
+    if (live && g < 9)
+        d = hak_det_at<float>(base + (long)img * stride + L.dxy(o, s), xx + g % 3 - 1, yy + g / 3 - 1, tab->sigma_size[layer], oc.w, oc.h,
+                              oc.p, tab->fac1, tab->fac2);
+    const int g0 = lane & ~15;
+    const float d00 = __shfl(d, g0 + 0), d01 = __shfl(d, g0 + 1), d02 = __shfl(d, g0 + 2);
+    const float d10 = __shfl(d, g0 + 3), d11 = __shfl(d, g0 + 4), d12 = __shfl(d, g0 + 5);
+    const float d20 = __shfl(d, g0 + 6), d21 = __shfl(d, g0 + 7), d22 = __shfl(d, g0 + 8);
+    if (live && g == 0) {
+        const float v2 = d11 + d11;
+        const float dx = 0.5f * (d12 - d10);
+        const float dy = 0.5f * (d21 - d01);
+        const float dxx = d12 + d10 - v2;
+        const float dyy = d21 + d01 - v2;
+        const float dxy = 0.25f * (d22 + d00 - d02 - d20);
+        const float dd = dxx * dyy - dxy * dxy;
+        const float idd = dd != 0.f ? 1.f / dd : 0.f;
+        const float dst0 = idd * (dxy * dy - dyy * dx);
+        const float dst1 = idd * (dxy * dx - dxx * dy);
+        const bool weak = dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f;
+        if (!weak) {
+            const int ratio = 1 << o;
+            pt->y = ratio * (yy + dst1);
+            pt->x = ratio * (xx + dst0);
+        }
+    }
+}
+
 void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave,
-                              int s, float dthreshold)
+                              int s, float dthreshold, long det_off)
 {
     const HakOct oc = L.oct[octave];
     dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, b.nimg);
     k_extrema<<<grid, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, b.cand, b.cand_cap, b.state, L, tab,
-                                    octave, s, dthreshold);
+                                    octave, s, dthreshold, det_off);
 }
 
 // The key map is sparse: only candidate pixels are ever written.  Instead of clearing the whole 8 B/px map before every
@@ -245,6 +271,8 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
     dim3 g3((h + 3) / 4, 1, b.nimg);
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
+    if (!fast)                                                      // (the FAST path refines on its int planes: k_orient<int>)
+        k_refine<<<dim3((max_pts + 15) / 16, b.nimg), 256, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts);
     k_clear_cand_maps<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, p);
 }
 

@@ -377,13 +377,13 @@ void hakf_launch_nld_step(hipStream_t st, const int* src, const int* flow, int* 
     kf_nld_step<<<grid, 256, 0, st>>>(src, flow, dst, stride, w, h, p, stepfac);
 }
 
-// ---- akazed.cu:3339 gDerivate, 3371 gHessianDeterminant
-__global__ __launch_bounds__(256) void kf_derivate(const int* __restrict__ src, int* __restrict__ lx, int* __restrict__ ly, long stride,
+// ---- akazed.cu:3339 gDerivate, 3371 gHessianDeterminant (unfused fallback for dilations > 4 and debug planes);
+// dxy = interleaved {Lx, Ly} (HakLayout)
+__global__ __launch_bounds__(256) void kf_derivate(const int* __restrict__ src, int* __restrict__ dxy, long stride,
                                                    int w, int h, int p, int step, int fac1, int fac2)
 {
     const int* s = src + (long)blockIdx.z * stride;
-    int* ox = lx + (long)blockIdx.z * stride;
-    int* oy = ly + (long)blockIdx.z * stride;
+    int2* o = reinterpret_cast<int2*>(dxy + (long)blockIdx.z * stride);
     const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
     if (x >= w) return;
     const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
@@ -392,45 +392,51 @@ __global__ __launch_bounds__(256) void kf_derivate(const int* __restrict__ src, 
         const int* r1 = s + (long)y * p;
         const int* r2 = s + (long)hak_refl(y + step, h) * p;
         const int ul = r0[x0], uc = r0[x], ur = r0[x2], cl = r1[x0], cr = r1[x2], ll = r2[x0], lc = r2[x], lr = r2[x2];
-        ox[(long)y * p + x] = wadd(wmul(fac1, ur + lr - ul - ll), wmul(fac2, cr - cl)) >> 16;
-        oy[(long)y * p + x] = wadd(wmul(fac1, lr + ll - ur - ul), wmul(fac2, lc - uc)) >> 16;
+        o[(long)y * p + x] = make_int2(wadd(wmul(fac1, ur + lr - ul - ll), wmul(fac2, cr - cl)) >> 16,
+                                       wadd(wmul(fac1, lr + ll - ur - ul), wmul(fac2, lc - uc)) >> 16);
     }
 }
-__global__ __launch_bounds__(256) void kf_hessian(const int* __restrict__ lx, const int* __restrict__ ly, int* __restrict__ det, long stride,
+__global__ __launch_bounds__(256) void kf_hessian(const int* __restrict__ dxy, int* __restrict__ det, long stride,
                                                   int w, int h, int p, int step, int fac1, int fac2)
 {
-    const int* dx = lx + (long)blockIdx.z * stride;
-    const int* dy = ly + (long)blockIdx.z * stride;
+    const int* d = dxy + (long)blockIdx.z * stride;
     int* o = det + (long)blockIdx.z * stride;
     const int x = blockIdx.x * FT_X + (threadIdx.x & 63), y0 = blockIdx.y * FT_Y + (threadIdx.x >> 6);
     if (x >= w) return;
-    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
-    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
-        const long o0 = (long)hak_refl(y - step, h) * p, o1 = (long)y * p, o2 = (long)hak_refl(y + step, h) * p;
-        const int dxx = wadd(wmul(fac1, dx[o0 + x2] + dx[o2 + x2] - dx[o0 + x0] - dx[o2 + x0]), wmul(fac2, dx[o1 + x2] - dx[o1 + x0])) >> 16;
-        const int dxy = wadd(wmul(fac1, dx[o2 + x2] + dx[o2 + x0] - dx[o0 + x2] - dx[o0 + x0]), wmul(fac2, dx[o2 + x] - dx[o0 + x])) >> 16;
-        const int dyy = wadd(wmul(fac1, dy[o2 + x2] + dy[o2 + x0] - dy[o0 + x2] - dy[o0 + x0]), wmul(fac2, dy[o2 + x] - dy[o0 + x])) >> 16;
-        o[o1 + x] = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
-    }
+    for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4)
+        o[(long)y * p + x] = hak_det_at<int>(d, x, y, step, w, h, p, fac1, fac2);
 }
-void hakf_launch_hessian(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride, int w, int h, int p, int nimg, int step)
+static void ifactors(int& f1, int& f2)
 {
-    float wv = 10.f / 3.f;                                                                        // akazed.cu:4177-4181
-    float fac1 = 1.f / (2.f * (wv + 2.f)), fac2 = wv * fac1;
-    const int f1 = (int)(fac1 * 65536 + 0.5f), f2 = (int)(fac2 * 65536 + 0.5f);
+    float fac1, fac2;                                                                             // akazed.cu:4177-4184
+    hak_deriv_factors(&fac1, &fac2);
+    f1 = (int)(fac1 * 65536 + 0.5f);
+    f2 = (int)(fac2 * 65536 + 0.5f);
+}
+void hakf_launch_hessian(hipStream_t st, const int* src, int* dxy, int* det, long stride, int w, int h, int p, int nimg, int step)
+{
+    int f1, f2;
+    ifactors(f1, f2);
     dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
-    kf_derivate<<<grid, 256, 0, st>>>(src, lx, ly, stride, w, h, p, step, f1, f2);
-    kf_hessian<<<grid, 256, 0, st>>>(lx, ly, det, stride, w, h, p, step, f1, f2);
+    kf_derivate<<<grid, 256, 0, st>>>(src, dxy, stride, w, h, p, step, f1, f2);
+    kf_hessian<<<grid, 256, 0, st>>>(dxy, det, stride, w, h, p, step, f1, f2);
+}
+void hakf_launch_det(hipStream_t st, const int* dxy, int* det, long stride, int w, int h, int p, int nimg, int step)
+{
+    int f1, f2;
+    ifactors(f1, f2);
+    dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
+    kf_hessian<<<grid, 256, 0, st>>>(dxy, det, stride, w, h, p, step, f1, f2);
 }
 
 // ---- akazed.cu:3476 gCalcExtremaMap (int): key = response << 32 | ~layer, candidates appended
 __global__ __launch_bounds__(256) void kf_extrema(const int* __restrict__ base, long stride, unsigned long long* maps, long map_stride,
                                                   unsigned long long* cand, long cand_cap, HakImgState* state, HakLayout L,
-                                                  const HakTables* __restrict__ tab, int octave, int s, int threshold)
+                                                  const HakTables* __restrict__ tab, int octave, int s, int threshold, long det_off)
 {
     const int img = blockIdx.z;
     const HakOct oc = L.oct[octave];
-    const int* det = base + (long)img * stride + L.det(octave, s);
+    const int* det = base + (long)img * stride + det_off;
     const int layer = octave * L.ms + s;
     const float border = tab->borders[layer];
     const int psz = (int)tab->borders[octave * L.ms];
@@ -461,12 +467,13 @@ __global__ __launch_bounds__(256) void kf_extrema(const int* __restrict__ base, 
         }
     }
 }
-void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold)
+void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold,
+                         long det_off)
 {
     const HakOct oc = L.oct[octave];
     dim3 grid((oc.w + 63) / 64, (oc.h + 15) / 16, b.nimg);
     kf_extrema<<<grid, 256, 0, st>>>(reinterpret_cast<const int*>(b.base), b.stride, b.maps, b.map_stride, b.cand, b.cand_cap, b.state, L,
-                                     tab, octave, s, threshold);
+                                     tab, octave, s, threshold, det_off);
 }
 
 // refine (akazed.cu:3600) + orientation (3649) + MLDB (3723): k_orient<int> / k_describe<int> in kernels_describe.hip

@@ -7,7 +7,8 @@
 // centre written out) -> det tile (+1 halo, in LDS, centre written out) -> 3x3 strict-maximum test
 // + threshold + border test -> atomicMax into the full-resolution key map and an entry in the
 // image's candidate list (the NMS then visits candidates instead of scanning the dense map).
-// HBM traffic: read smooth once (4 B/px), write Lx, Ly, det (12 B/px); nothing is re-read.
+// HBM traffic: read smooth once (4 B/px), write the interleaved {Lx, Ly} plane (8 B/px); nothing is re-read.  The
+// determinant stays in LDS (it is written out only for the stage tests): the refinement re-evaluates it (hak_det_at).
 //
 // The kernel is bytes-in-flight-bound when a block loads one tile and then computes with nothing
 // outstanding (rocprof: ~4 % VALU-active, waves waiting on memory), so a block is PERSISTENT over a
@@ -86,7 +87,7 @@ struct HakExtremaArgs {
 };
 
 template <typename V, int S, bool INTERIOR>
-__device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__ oy, V* __restrict__ od,
+__device__ __forceinline__ void hessian_tile(V* __restrict__ oxy, V* __restrict__ od,
                                              int w, int h, int p, int x0, int y0, V fac1, V fac2,
                                              V* __restrict__ sm, V* __restrict__ sx, V* __restrict__ sy, int lane, int wv,
                                              const HakExtremaArgs<V>& ex, int img, unsigned long long* cbuf, int* ccnt, const int ccap)
@@ -130,10 +131,10 @@ __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__
                 sx[r * DW + CM + lane] = vx;
                 sy[r * DW + CM + lane] = vy;
                 if (r >= S + HF_E && r < S + HF_E + TY) {
-                    V* rx = ox + (long)y * p + x0;
-                    V* ry = oy + (long)y * p + x0;
-                    rx[lane] = vx;
-                    ry[lane] = vy;
+                    using V2 = typename std::conditional<std::is_same<V, float>::value, float2, int2>::type;
+                    V2 pr;
+                    pr.x = vx; pr.y = vy;
+                    reinterpret_cast<V2*>(oxy + 2 * ((long)y * p + x0))[lane] = pr;      // interleaved {Lx, Ly}
                 }
             }
         }
@@ -186,7 +187,7 @@ __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__
                 const V dyy = hs_d(fac1, fac2, ylr + yll - yur - yul, ylc - yuc);
                 const V d = hs_det(dxx, dyy, dxy);                                // akazed.cu:1330
                 dt[r * EW + HF_E + lane] = d;
-                if (r >= HF_E && r < HF_E + TY) {
+                if (od != nullptr && r >= HF_E && r < HF_E + TY) {                 // (uniform) stage tests only
                     V* rd = od + (long)y * p + x0;
                     rd[lane] = d;
                 }
@@ -270,8 +271,8 @@ __device__ __forceinline__ void hessian_tile(V* __restrict__ ox, V* __restrict__
 
 // grid: (x tiles, y tile groups, images); a block walks `tiles_per_block` tiles downwards
 template <typename V, int S>
-__global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restrict__ src, V* __restrict__ lx,
-                                                       V* __restrict__ ly, V* __restrict__ det, long stride,
+__global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restrict__ src, V* __restrict__ dxy,
+                                                       V* __restrict__ det, long stride,
                                                        int w, int h, int p, V fac1, V fac2, int tiles_per_block,
                                                        int ntx, int nby, int nimg, HakExtremaArgs<V> ex, int ccap)
 {
@@ -282,9 +283,8 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
     int bx, by, img;                                              // XCD-aware block order (hak_internal.h)
     if (!hak_xcd_decode(ntx, nby, nimg, bx, by, img)) return;
     const V* s = src + (long)img * stride;
-    V* ox = lx + (long)img * stride;
-    V* oy = ly + (long)img * stride;
-    V* od = det + (long)img * stride;
+    V* oxy = dxy + (long)img * stride;
+    V* od = det ? det + (long)img * stride : nullptr;
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int x0 = bx * HF_TX;
@@ -319,8 +319,8 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
         hak_lds_barrier();
         if (ty + 1 < ty1) hess_fetch<V, S>(P, s, w, h, p, x0, y0 + G::TY, lane, wv);   // in flight during the compute below
         const bool interior = x0 - HALO >= 0 && x0 + HF_TX + HALO <= w && y0 - HALO >= 0 && y0 + G::TY + HALO <= h;
-        if (interior) hessian_tile<V, S, true>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
-        else hessian_tile<V, S, false>(ox, oy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
+        if (interior) hessian_tile<V, S, true>(oxy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
+        else hessian_tile<V, S, false>(oxy, od, w, h, p, x0, y0, fac1, fac2, sm, sx, sy, lane, wv, ex, img, cbuf, &ccnt, ccap);
     }
     if (ex.maps != nullptr) {
         __syncthreads();
@@ -328,12 +328,7 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
     }
 }
 
-static void deriv_factors(float& fac1, float& fac2)
-{
-    float wv = 10.f / 3.f;                                   // akazed.cu:2537-2539
-    fac1 = 1.f / (2.f * (wv + 2.f));
-    fac2 = wv * fac1;
-}
+static void deriv_factors(float& fac1, float& fac2) { hak_deriv_factors(&fac1, &fac2); }
 
 // process-wide mode (0 never / 1 by size / 2 always), refreshed from HAK_HESS_STREAM by every hak_create
 int hak_hessian_stream_enabled = 1;
@@ -342,7 +337,7 @@ int hak_hessian_stream_enabled = 1;
 int hak_hessian_cbuf_cap = HF_CBUF;
 
 template <typename V, int S>
-static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride,
+static void launch_fused(hipStream_t st, const V* src, V* dxy, V* det, long stride,
                          int w, int h, int p, int nimg, const HakExtremaArgs<V>& ex)
 {
     float f1, f2;
@@ -355,7 +350,7 @@ static void launch_fused(hipStream_t st, const V* src, V* lx, V* ly, V* det, lon
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
-    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, lx, ly, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex, hak_hessian_cbuf_cap);
+    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, dxy, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex, hak_hessian_cbuf_cap);
 }
 
 template <typename V>
@@ -373,8 +368,9 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
 
 
 // derivate + determinant (+ extrema when b != nullptr) of one level.  Returns true when the
-// extrema were handled here; false means the caller must run the stand-alone extrema kernel.
-bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+// extrema were handled here; false means the caller must run the stand-alone extrema kernel on `det`.
+// The fused kernels write `det` only when store_det is set; the dilation > 4 fallback always fills it.
+bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
@@ -382,41 +378,43 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* lx, float
     if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
-        if (hak_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
+        if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
             return true;
     }
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
+    float* od = store_det ? det : nullptr;
     switch (step) {
-    case 1: launch_fused<float, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 2: launch_fused<float, 2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 3: launch_fused<float, 3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 4: launch_fused<float, 4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 1: launch_fused<float, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 2: launch_fused<float, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 3: launch_fused<float, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 4: launch_fused<float, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
     default: break;
     }
-    hak_launch_derivate(st, src, lx, ly, stride, w, h, p, nimg, step);      // dilation > 4: two direct passes
-    hak_launch_hessian(st, lx, ly, det, stride, w, h, p, nimg, step);
+    hak_launch_derivate(st, src, dxy, stride, w, h, p, nimg, step);        // dilation > 4: two direct passes
+    hak_launch_hessian(st, dxy, det, stride, w, h, p, nimg, step);
     return false;
 }
 
 // the integer FAST path's level (fastakaze::hHessianDeterminant + hCalcExtremaMap, akazed.cu:4175-4195, 4260-4285):
 // same kernel on int32 planes.  Returns false for dilation > 4 (caller: kf_derivate / kf_hessian / kf_extrema).
-bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
     if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
-        if (hakf_launch_hessian_stream(st, src, lx, ly, det, stride, w, h, p, nimg, step, (int)(f1 * 65536 + 0.5f), (int)(f2 * 65536 + 0.5f),
-                                       b, L, htab, octave, sub, idthreshold))
+        if (hakf_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, (int)(f1 * 65536 + 0.5f),
+                                       (int)(f2 * 65536 + 0.5f), b, L, htab, octave, sub, idthreshold))
             return true;
     }
     const HakExtremaArgs<int> ex = extrema_args<int>(b, L, htab, octave, sub, idthreshold);
+    int* od = store_det ? det : nullptr;
     switch (step) {
-    case 1: launch_fused<int, 1>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 2: launch_fused<int, 2>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 3: launch_fused<int, 3>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
-    case 4: launch_fused<int, 4>(st, src, lx, ly, det, stride, w, h, p, nimg, ex); return true;
+    case 1: launch_fused<int, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 2: launch_fused<int, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 3: launch_fused<int, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 4: launch_fused<int, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
     default: return false;
     }
 }

@@ -10,8 +10,11 @@
 //     Lx, Ly  of row b = t - S      come from input rows b-S, b, b+S      (the ring's oldest / middle / newest),
 //     det     of row c = t - 2S     comes from Lx / Ly rows c-S, c, c+S,
 //     extrema of row e = t - 2S - 1 come from det rows e-1, e, e+1,
-// so the input is read once (4 B/px) and Lx, Ly, det are written once (12 B/px) with 16-byte accesses (non-temporal
-// stores: the three planes are next touched sparsely, by the NMS and the descriptor stage).  Horizontal
+// so the input is read once (4 B/px) and the derivatives are written once, INTERLEAVED as {Lx, Ly} pairs (8 B/px, two
+// 16-byte non-temporal stores per lane and row: the plane is next touched sparsely, by the descriptor stage, which then
+// fetches both derivatives of a sample with one 8-byte gather from one sector).  The determinant is NOT written (only when
+// a stage test asks for it): its consumers are the extrema test below and the refinement of the few keypoints, which
+// re-evaluates it from the derivative plane (hak_det_at).  Horizontal
 // neighbours at distance S are the adjacent lane's components: S DPP wave shifts per direction per row.  The rings
 // rotate statically (row loop unrolled by R); the strip's outer M columns and the 2S+1 warm-up rows above / below a
 // segment are recomputed by the neighbouring wave.
@@ -25,7 +28,6 @@
 // Requires w % 4 == 0 and 1 <= S <= 4; everything else takes the LDS tile kernel.
 #include "fed_common.h"
 #include <utility>
-#include <cstdlib>
 
 namespace {
 
@@ -34,13 +36,14 @@ template <int S> struct HsGeo {
     static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
     static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
-#ifndef HAK_HS_MINW3
-#define HAK_HS_MINW3 0
-#endif
-    // waves per SIMD the register allocator must make room for: S = 3 needs 187 VGPRs unconstrained (2 waves); capped at 168
-    // it spills ~26 dwords outside the row loop's critical path and runs 3 waves (A/B: see DESIGN.md)
-    static constexpr int MINW = (HAK_HS_MINW3 && S == 3) ? 3 : (S <= 2 ? 3 : 2);
+    // waves per SIMD the register allocator must make room for.  S = 3 needs ~187 VGPRs (2 waves); capping it at 168 for a
+    // third wave spills 26 dwords and measured 3 % SLOWER (A/B on one box), so S >= 3 stays at two waves
+    static constexpr int MINW = S <= 2 ? 3 : 2;
 };
+
+template <typename V> struct HsV2;
+template <> struct HsV2<float> { using T = float2; };
+template <> struct HsV2<int> { using T = int2; };
 
 #define HS_CBUF 256
 struct HsCand { unsigned long long* buf; int n; };      // staged candidates: this wave's HS_CBUF LDS entries; n: wave-uniform fill count
@@ -49,6 +52,7 @@ template <typename V, int S> struct HsState {
     using V4 = typename FedV<V>::V4;
     V4 A[HsGeo<S>::R], X[HsGeo<S>::R];                              // slot = iteration index mod R
     V4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
+    V4* XS;                                                     // one staging row for Lx (interleaved store below)
     V4 Dm, Dc, Dp;                                                  // det rows e-1, e, e+1 (rotated by moves)
     HsCand cb;                                                      // staged candidates
 };
@@ -109,8 +113,9 @@ __device__ __forceinline__ int hs_max3(int a, int b, int c) { return max(max(a, 
 #define HS_DY(ul, uc, ur, ll, lc, lr) hs_d(fac1, fac2, (lr) + (ll) - (ur) - (ul), (lc) - (uc))
 
 template <typename V> struct HsArgs {
-    const V* src; V* lx; V* ly; V* det;
-    V* obase; unsigned off_lx, off_ly, off_det;     // lx / ly / det as byte offsets from the lowest of the three (buffer stores)
+    const V* src; V* dxy; V* det;
+    V* obase; unsigned off_dxy, off_det;            // dxy / det as byte offsets from the lower of the two (buffer stores); off_det =
+                                                    // HAK_BUF_OOB: the determinant is not stored (the hardware drops the store)
     int w, h, p;
     V fac1, fac2;
     // extrema (maps == nullptr: determinant only)
@@ -200,10 +205,22 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         T.X[pmod(U, R)] = vx;
         T.Y[pmod(U, R) * 64 + lane] = vy;
         {
-            // unconditional buffer stores; rows outside the segment and margin lanes carry the out-of-range bit
-            const unsigned roff = b >= ybeg && b < yend ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB;
-            hak_buf_store_nt(orsrc, ovoff[0] + roff, vx);
-            hak_buf_store_nt(orsrc, ovoff[1] + roff, vy);
+            // Interleaved plane: pixel x of row b lives at 2 * (b * p + x).  Storing a lane's own four pixels would be two
+            // 16-byte pieces at a 32-byte lane stride -- every store instruction half-fills sixteen 128-byte lines (measured:
+            // +0.7 ms per 256 images against dense stores).  The row is therefore turned through LDS: Lx goes to a staging
+            // row (Ly sits in its ring slot already), lane j reads back the pixel PAIR 2j, 2j+1 of both (two conflict-free
+            // ds_read_b64) and stores {Lx, Ly, Lx, Ly} -- one dense kilobyte per instruction; a second pair of reads serves
+            // pixels 128 + 2j.  Same wave, LDS operations complete in order: no barrier.
+            // Unconditional buffer stores; rows outside the segment and pixel pairs the strip does not own carry the
+            // out-of-range bit.
+            using V2 = typename HsV2<V>::T;
+            T.XS[lane] = vx;
+            const V2* xs2 = reinterpret_cast<const V2*>(T.XS);
+            const V2* ys2 = reinterpret_cast<const V2*>(T.Y + pmod(U, R) * 64);
+            const V2 xa = xs2[lane], ya = ys2[lane], xb2 = xs2[64 + lane], yb2 = ys2[64 + lane];
+            const unsigned roff = b >= ybeg && b < yend ? (unsigned)(b * p) * 2u * (unsigned)sizeof(V) : HAK_BUF_OOB;
+            hak_buf_store_nt(orsrc, ovoff[0] + roff, mk4(xa.x, ya.x, xa.y, ya.y));
+            hak_buf_store_nt(orsrc, ovoff[2] + roff, mk4(xb2.x, yb2.x, xb2.y, yb2.y));
         }
         if (YEDGE) {
 #pragma unroll
@@ -243,7 +260,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         HS_DET(z, 2) __builtin_amdgcn_sched_barrier(0); HS_DET(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_DET
         T.Dm = T.Dc; T.Dc = T.Dp; T.Dp = d;
-        hak_buf_store_nt(orsrc, ovoff[2] + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), d);
+        hak_buf_store_nt(orsrc, ovoff[1] + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), d);
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
     if (a.maps != nullptr) {
@@ -290,7 +307,7 @@ __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsSta
 
 template <typename V, int S, bool XEDGE>
 __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const int lane, typename FedV<V>::V4* yring, unsigned long long* cbuf)
+                                         const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf)
 {
     using G = HsGeo<S>;
     using V4 = typename FedV<V>::V4;
@@ -308,9 +325,17 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     const __amdgpu_buffer_rsrc_t orsrc = hak_buf_rsrc(a.obase);
     // per-plane lane offsets (column + plane); lanes that own nothing carry the out-of-range marker
     const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
-    const unsigned ovoff[3] = {owns ? xb + a.off_lx : HAK_BUF_OOB, owns ? xb + a.off_ly : HAK_BUF_OOB, owns ? xb + a.off_det : HAK_BUF_OOB};
+    // [0], [2]: the interleaved derivative stores of pixel pairs 2 * lane and 128 + 2 * lane of the strip (ownership is a
+    // property of the PIXEL: margins and widths are multiples of 4, so both pixels of a pair share it); [1]: det (lane's own pixels)
+    const int sx = x0 - 4 * lane;                               // image column of the strip's pixel 0
+    auto pair_off = [&](int q) -> unsigned {
+        const int x = sx + q;
+        return q >= G::M && q < G::M + G::XV && x >= 0 && x < w ? (unsigned)x * 2u * (unsigned)sizeof(V) + a.off_dxy : HAK_BUF_OOB;
+    };
+    const unsigned ovoff[3] = {pair_off(2 * lane), owns && a.off_det != HAK_BUF_OOB ? xb + a.off_det : HAK_BUF_OOB, pair_off(128 + 2 * lane)};
     HsState<V, S> T;
     T.Y = yring;
+    T.XS = xstage;
     T.cb.buf = cbuf;
     T.cb.n = 0;
     const V zz = 0;
@@ -336,6 +361,7 @@ __global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V
 {
     using G = HsGeo<S>;
     __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
+    __shared__ typename FedV<V>::V4 xstage[4 * 64];                           // per-wave Lx staging row of the interleaved store
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
@@ -349,8 +375,8 @@ __global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
-    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, cbuf + wv * HS_CBUF);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
+    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
 }
 
 template <typename V, int S>
@@ -367,22 +393,20 @@ void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, in
 
 
 template <typename V>
-bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long stride, int w, int h, int p, int nimg, int step,
+bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_det, long stride, int w, int h, int p, int nimg, int step,
                        V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
 {
     if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
     HsArgs<V> a{};
-    V* lo = lx < ly ? lx : ly;
-    lo = det < lo ? det : lo;
+    V* lo = dxy;
+    if (store_det && det < lo) lo = det;
     {   // plane offset + plane size must stay below the out-of-range marker
-        const long room = (long)HAK_BUF_OOB / (long)sizeof(V) - (long)h * p;
-        if ((lx - lo) >= room || (ly - lo) >= room || (det - lo) >= room) return false;
+        const long room = (long)HAK_BUF_OOB / (long)sizeof(V) - 2L * h * p;
+        if ((dxy - lo) >= room || (store_det && (det - lo) >= room)) return false;
     }
-    a.obase = lo; a.off_lx = (unsigned)((lx - lo) * sizeof(V)); a.off_ly = (unsigned)((ly - lo) * sizeof(V)); a.off_det = (unsigned)((det - lo) * sizeof(V));
-    // timing experiments only (results become wrong): drop the det / the Lx, Ly stores in hardware (out-of-range offsets)
-    if (getenv("HAK_EXP_HS_NODET")) a.off_det = HAK_BUF_OOB;
-    if (getenv("HAK_EXP_HS_NOLXY")) { a.off_lx = HAK_BUF_OOB; a.off_ly = HAK_BUF_OOB; }
-    a.src = src; a.lx = lx; a.ly = ly; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
+    a.obase = lo; a.off_dxy = (unsigned)((dxy - lo) * sizeof(V));
+    a.off_det = store_det ? (unsigned)((det - lo) * sizeof(V)) : HAK_BUF_OOB;
+    a.src = src; a.dxy = dxy; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
     long map_stride = 0;
     if (b) {
         const int layer = octave * L->ms + sub;
@@ -402,16 +426,16 @@ bool launch_stream_any(hipStream_t st, const V* src, V* lx, V* ly, V* det, long 
 }   // namespace
 
 // return false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
-bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* lx, float* ly, float* det, long stride,
+bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
-    return launch_stream_any<float>(st, src, lx, ly, det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold);
+    return launch_stream_any<float>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold);
 }
 
-bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* lx, int* ly, int* det, long stride,
+bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
                                 const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
-    return launch_stream_any<int>(st, src, lx, ly, det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold);
+    return launch_stream_any<int>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold);
 }

@@ -275,13 +275,12 @@ void hak_launch_flow(hipStream_t st, const float* src, float* dst, long stride, 
 }
 
 // ------------------------------------------------- derivatives + determinant
-__global__ __launch_bounds__(256) void k_derivate(const float* __restrict__ src, float* __restrict__ lx,
-                                                  float* __restrict__ ly, long stride, int w, int h, int p,
+// unfused fallback for dilations > 4 and the debug / test planes: dxy = interleaved {Lx, Ly} (HakLayout)
+__global__ __launch_bounds__(256) void k_derivate(const float* __restrict__ src, float* __restrict__ dxy, long stride, int w, int h, int p,
                                                   int step, float fac1, float fac2)
 {
     const float* s = src + (long)blockIdx.z * stride;
-    float* ox = lx + (long)blockIdx.z * stride;
-    float* oy = ly + (long)blockIdx.z * stride;
+    float2* o = reinterpret_cast<float2*>(dxy + (long)blockIdx.z * stride);
     const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
     const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
     if (x >= w) return;
@@ -293,59 +292,61 @@ __global__ __launch_bounds__(256) void k_derivate(const float* __restrict__ src,
         float ul = r0[x0], uc = r0[x], ur = r0[x2];
         float cl = r1[x0], cr = r1[x2];
         float ll = r2[x0], lc = r2[x], lr = r2[x2];
-        ox[(long)y * p + x] = fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl);       // akazed.cu:1294
-        oy[(long)y * p + x] = fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc);       // akazed.cu:1295
+        o[(long)y * p + x] = make_float2(fac1 * (ur + lr - ul - ll) + fac2 * (cr - cl),        // akazed.cu:1294
+                                         fac1 * (lr + ll - ur - ul) + fac2 * (lc - uc));       // akazed.cu:1295
     }
 }
 
-__global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ lx, const float* __restrict__ ly,
-                                                 float* __restrict__ det, long stride, int w, int h, int p,
+__global__ __launch_bounds__(256) void k_hessian(const float* __restrict__ dxy, float* __restrict__ det, long stride, int w, int h, int p,
                                                  int step, float fac1, float fac2)
 {
-    const float* dx = lx + (long)blockIdx.z * stride;
-    const float* dy = ly + (long)blockIdx.z * stride;
+    const float* d = dxy + (long)blockIdx.z * stride;
     float* o = det + (long)blockIdx.z * stride;
     const int x = blockIdx.x * TILE_X + (threadIdx.x & 63);
     const int y0 = blockIdx.y * TILE_Y + (threadIdx.x >> 6);
     if (x >= w) return;
-    const int x0 = hak_refl(x - step, w), x2 = hak_refl(x + step, w);
-    for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
-        long o0 = (long)hak_refl(y - step, h) * p, o1 = (long)y * p, o2 = (long)hak_refl(y + step, h) * p;
-        float xul = dx[o0 + x0], xuc = dx[o0 + x], xur = dx[o0 + x2];
-        float xcl = dx[o1 + x0], xcr = dx[o1 + x2];
-        float xll = dx[o2 + x0], xlc = dx[o2 + x], xlr = dx[o2 + x2];
-        float yul = dy[o0 + x0], yuc = dy[o0 + x], yur = dy[o0 + x2];
-        float yll = dy[o2 + x0], ylc = dy[o2 + x], ylr = dy[o2 + x2];
-        float dxx = fac1 * (xur + xlr - xul - xll) + fac2 * (xcr - xcl);
-        float dxy = fac1 * (xlr + xll - xur - xul) + fac2 * (xlc - xuc);
-        float dyy = fac1 * (ylr + yll - yur - yul) + fac2 * (ylc - yuc);
-        o[o1 + x] = dxx * dyy - dxy * dxy;                                         // akazed.cu:1330
-    }
+    for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4)
+        o[(long)y * p + x] = hak_det_at<float>(d, x, y, step, w, h, p, fac1, fac2);             // akazed.cu:1318-1330
 }
 
-static void deriv_factors(float& fac1, float& fac2)
+void hak_deriv_factors(float* fac1, float* fac2)
 {
     float wv = 10.f / 3.f;                                   // akazed.cu:2537-2539
-    fac1 = 1.f / (2.f * (wv + 2.f));
-    fac2 = wv * fac1;
+    *fac1 = 1.f / (2.f * (wv + 2.f));
+    *fac2 = wv * *fac1;
 }
 
-void hak_launch_derivate(hipStream_t st, const float* src, float* lx, float* ly, long stride,
+void hak_launch_derivate(hipStream_t st, const float* src, float* dxy, long stride,
                          int w, int h, int p, int nimg, int step)
 {
     float f1, f2;
-    deriv_factors(f1, f2);
+    hak_deriv_factors(&f1, &f2);
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
-    k_derivate<<<grid, 256, 0, st>>>(src, lx, ly, stride, w, h, p, step, f1, f2);
+    k_derivate<<<grid, 256, 0, st>>>(src, dxy, stride, w, h, p, step, f1, f2);
 }
 
-void hak_launch_hessian(hipStream_t st, const float* lx, const float* ly, float* det, long stride,
+void hak_launch_hessian(hipStream_t st, const float* dxy, float* det, long stride,
                         int w, int h, int p, int nimg, int step)
 {
     float f1, f2;
-    deriv_factors(f1, f2);
+    hak_deriv_factors(&f1, &f2);
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
-    k_hessian<<<grid, 256, 0, st>>>(lx, ly, det, stride, w, h, p, step, f1, f2);
+    k_hessian<<<grid, 256, 0, st>>>(dxy, det, stride, w, h, p, step, f1, f2);
+}
+
+// interleaved {a, b} plane (pitch 2p) -> two dense planes (pitch p): stage tests and hak_debug_plane only
+__global__ __launch_bounds__(256) void k_deinterleave(const float2* __restrict__ ab, float* __restrict__ a, float* __restrict__ b,
+                                                      int w, int h, int p)
+{
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const float2 v = ab[(long)y * p + x];
+    a[(long)y * p + x] = v.x;
+    b[(long)y * p + x] = v.y;
+}
+void hak_launch_deinterleave(hipStream_t st, const float* ab, float* a, float* b, int w, int h, int p)
+{
+    k_deinterleave<<<dim3((w + 255) / 256, h), 256, 0, st>>>(reinterpret_cast<const float2*>(ab), a, b, w, h, p);
 }
 
 // ------------------------------------------------------------------ ingest

@@ -198,7 +198,7 @@ typedef struct hak_traffic {
     /* compulsory HBM bytes per image of each kernel class AS BUILT (after fusion): what its launches must move even with
        perfect reuse inside a launch -- the numerator of the per-class roofline fractions in bench.py */
     double fed_fused_bytes;  /* FED launches as enqueued by the last detect call: read L (+ g), write L' (+ smooth, + g) */
-    double hessian_bytes;    /* 16 B/px per level: read smooth, write Lx, Ly, det */
+    double hessian_bytes;    /* 12 B/px per level: read smooth, write the interleaved {Lx, Ly} plane (the determinant is not stored) */
     double prologue_bytes;   /* 16 B/px of octave 0: read image, write Lt(0,0) + gradient plane, re-read it for the histogram */
     double describe_bytes;   /* (872 + 5292) B sampled per keypoint (orientation + MLDB) x npts_hint */
     double nms_bytes;        /* 104 B record per keypoint x npts_hint */
