@@ -170,8 +170,6 @@ struct hak_ctx {
     double fed_fused_bytes = 0;     // compulsory HBM bytes per image of the FED launches as enqueued (read L [+ g], write L' [+ smooth, g])
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
     int fuse_head = 1;              // octave heads through the decimating k_fed_sf variant (env HAK_FUSE_HEAD=0 disables)
-    int fuse_lp = 1;                // the streaming Hessian takes its own sigma=1 low-pass of L(o, s-1) where k_fed_sf precedes it, so that the
-                                    // smooth plane is neither written nor re-read (env HAK_FUSE_LP=0 disables)
     int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
@@ -306,7 +304,6 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
     if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
     if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
-    if (const char* e = getenv("HAK_FUSE_LP")) c->fuse_lp = atoi(e);
     { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
     { const char* e = getenv("HAK_BASE_STREAM"); hak_base_stream_enabled = e ? atoi(e) : 1; }
     { const char* e = getenv("HAK_HESS_CBUF"); const int v = e ? atoi(e) : 256; hak_hessian_cbuf_cap = v < 1 ? 1 : (v > 256 ? 256 : v); }
@@ -443,7 +440,6 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             const int G = hak_fed_groups(n, c->max_fuse, oc.w);     // launches of this FED cycle
             const float* fsrc;          // input of the first FED launch
             bool fused_first = false;
-            bool lowpass_in_hessian = false;
             if (s == 0) {                                                         // akaze.cpp:369-392
                 // octave head: decimation + low-pass + conductivity + the first FED group in one streaming pass when covered
                 if (c->fuse_head && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
@@ -477,15 +473,12 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                        oc.h >= 8) {
                 const int ns0 = hak_fed_group_size(n, G, 0);
                 float* dst0 = (G % 2 == 1) ? Lt : tmp;
-                // when the streaming Hessian of this level takes its own low-pass of L(o, s-1), smooth never goes to HBM
-                const bool want_lp = c->fuse_lp && hak_hessian_lowpass_fused(oc.w, oc.h, oc.p, nimg, lp.sigma_size);
                 ProfScope ps(c, HAK_PROF_FED, st);
-                fused_first = hak_launch_fed_sf(st, fsrc, want_lp ? nullptr : smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1,
-                                                cfg.diffusivity, lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
+                fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
+                                                lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
                 if (fused_first) {
-                    c->fed_launches++;           // reads L, writes L' (+ smooth unless the Hessian low-passes itself, + g for later launches)
-                    c->fed_fused_bytes += ((G > 1 ? 16.0 : 12.0) - (want_lp ? 4.0 : 0.0)) * oc.w * oc.h;
-                    lowpass_in_hessian = want_lp;
+                    c->fed_launches++;           // reads L, writes smooth, L' (+ g for later launches)
+                    c->fed_fused_bytes += (G > 1 ? 16.0 : 12.0) * oc.w * oc.h;
                 }
             }
             if (s != 0 && !fused_first) {                                         // akaze.cpp:403-404 in one pass
@@ -512,8 +505,8 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
             }
             { ProfScope ps(c, HAK_PROF_HESSIAN, st);                              // akaze.cpp:423
-              if (!hak_launch_hessian_level(st, lowpass_in_hessian ? fsrc : smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
-                                            lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold, lowpass_in_hessian ? c->taps1 : nullptr))
+              if (!hak_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
+                                            lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
                   hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]); }
         }
         // akaze.cpp:431-433 hCalcExtremaMap: fused into the per-level Hessian kernel above
@@ -577,7 +570,6 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             const bool fused = (oc.w % 4) == 0;
             const int G = fused ? hak_fed_groups(n, c->max_fuse, oc.w) : n;
             const int* src;
-            const int* lsrc = nullptr;  // L(o, s-1) when the Hessian kernel low-passes it itself
             bool fused_first = false;
             if (s == 0) {                                                         // akaze.cpp:640-662
                 int* first = (G % 2 == 0) ? Lt : tmp;
@@ -593,12 +585,9 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             } else {                                                              // akaze.cpp:664-695
                 src = A + L.lt(o, s - 1);
                 // low-pass + conductivity + first FED group in one streaming pass when covered, else low-pass + flow in one tile pass
-                if (fused && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
-                    const bool want_lp = c->fuse_lp && hak_hessian_lowpass_fused(oc.w, oc.h, oc.p, nimg, lp.sigma_size);
-                    fused_first = hakf_launch_fed_sf(st, src, want_lp ? nullptr : smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc.w, oc.h, oc.p, nimg,
-                                                     c->itaps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0), c->state, o, G > 1);
-                    if (fused_first && want_lp) lsrc = src;
-                }
+                if (fused && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg))
+                    fused_first = hakf_launch_fed_sf(st, src, smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc.w, oc.h, oc.p, nimg, c->itaps1,
+                                                     cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0), c->state, o, G > 1);
                 if (!fused_first)
                     hakf_launch_smooth_flow(st, src, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->itaps1, cfg.diffusivity, c->state, o);
             }
@@ -612,8 +601,8 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 done += ns;
                 src = dst;
             }
-            if (!hakf_launch_hessian_level(st, lsrc ? lsrc : smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
-                                           lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold, lsrc ? c->itaps1 : nullptr)) {
+            if (!hakf_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
+                                           lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
                 hakf_launch_hessian(st, smooth, A + L.dxy(o, s), flow, S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
                 hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold, L.flow_off[o]);
             }

@@ -254,30 +254,18 @@ extern int hak_hessian_stream_enabled;
 extern int hak_hessian_cbuf_cap;       // tile kernel: staged candidates per block (env HAK_HESS_CBUF, tests only)
 // dxy: interleaved {Lx, Ly} plane (2 * h * p elements).  det: where the determinant goes -- the fused kernels write it only
 // when store_det is set (stage tests); the launch sequence passes a scratch plane that only the dilation > 4 fallback fills.
-// lp_taps != nullptr (streaming kernel only): `src` is L(o, s-1) and the sigma=1 low-pass of akaze.cpp:403 runs inside the
-// kernel (taps k0, k1, k2) -- the smooth plane then never goes to HBM.  hak_hessian_lowpass_fused() tells the launch
-// sequence beforehand whether a level will take that route (k_fed_sf then skips its smooth store).
-bool hak_hessian_stream_covers(int w, int h, int p, int step);
-static inline bool hak_hessian_lowpass_fused(int w, int h, int p, int nimg, int step)
-{
-    return hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg) && hak_hessian_stream_covers(w, h, p, step);
-}
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
-                               const float* lp_taps);
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
-                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold,
-                                const int* lp_taps);
+                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
 bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold,
-                               const int* lp_taps = nullptr);
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
-                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
-                              const float* lp_taps = nullptr);
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
 // register-streaming pass A of the octave-0 prologue (kernels_base_stream.hip); false: not covered / does not pay
 extern int hak_base_stream_enabled;

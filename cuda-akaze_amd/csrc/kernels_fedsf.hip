@@ -216,13 +216,11 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
     FsOut O;
     {
-        V* lo = SMO != nullptr ? SMO : GO;
+        V* lo = SMO;
         if (WRITE_G) lo = GO < lo ? GO : lo;
         O.r = hak_buf_rsrc(lo);
         const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
-        // SMO == nullptr: the Hessian kernel takes its own low-pass of L (k_hessian_stream LP), the smooth plane is not needed --
-        // the store keeps its place in the instruction stream and is dropped by the hardware
-        O.smo = owns && SMO != nullptr ? xb + (unsigned)((SMO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+        O.smo = owns ? xb + (unsigned)((SMO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
         O.go = WRITE_G && owns ? xb + (unsigned)((GO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
     }
     const int t0 = max(0, ybeg - NS - 4);                   // rp from t0, smooth from t0+2, g from t0+3, level k from t0+3+k
@@ -278,7 +276,7 @@ __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
     const V* L = src + (long)img * stride;
-    V* SMO = smooth ? smooth + (long)img * stride : nullptr;
+    V* SMO = smooth + (long)img * stride;
     V* GO = flow + (long)img * stride;
     V* D = dst + (long)img * stride;
     const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
@@ -326,7 +324,7 @@ bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, lon
 {
     if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
     // smooth and g are addressed as 32-bit byte offsets from the lower of them: plane offset + plane size < the marker
-    if ((write_g && smooth ? (flow < smooth ? smooth - flow : flow - smooth) : 0L) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
+    if ((write_g ? (flow < smooth ? smooth - flow : flow - smooth) : 0L) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
     switch (ns) {
     case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
     case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;

@@ -20,7 +20,6 @@
 // Same per-pixel expressions and reflect-101 index rule as the reference (akazed.cu:1284-1295,
 // 1326-1330, 1346-1373).
 #include "fed_common.h"
-#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 
@@ -373,18 +372,15 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
 // The fused kernels write `det` only when store_det is set; the dilation > 4 fallback always fills it.
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
-                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
-                              const float* lp_taps)
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
     // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
     if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
-        if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold,
-                                      lp_taps))
+        if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
             return true;
     }
-    if (lp_taps) { fprintf(stderr, "hip-akaze: fused low-pass requested for a level the streaming Hessian does not cover\n"); abort(); }
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     float* od = store_det ? det : nullptr;
     switch (step) {
@@ -403,17 +399,15 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, floa
 // same kernel on int32 planes.  Returns false for dilation > 4 (caller: kf_derivate / kf_hessian / kf_extrema).
 bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold,
-                               const int* lp_taps)
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
     if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
         if (hakf_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, (int)(f1 * 65536 + 0.5f),
-                                       (int)(f2 * 65536 + 0.5f), b, L, htab, octave, sub, idthreshold, lp_taps))
+                                       (int)(f2 * 65536 + 0.5f), b, L, htab, octave, sub, idthreshold))
             return true;
     }
-    if (lp_taps) { fprintf(stderr, "hip-akaze: fused low-pass requested for a level the streaming Hessian does not cover\n"); abort(); }
     const HakExtremaArgs<int> ex = extrema_args<int>(b, L, htab, octave, sub, idthreshold);
     int* od = store_det ? det : nullptr;
     switch (step) {

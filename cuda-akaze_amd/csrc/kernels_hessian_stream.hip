@@ -31,24 +31,15 @@
 
 namespace {
 
-template <int S, bool LP> struct HsGeo {
+template <int S> struct HsGeo {
     static constexpr int PD = 2;                                    // input rows in flight ahead of the current one
-    // ring slots = unroll factor.  Plain: 2S+1 live rows + the PD rows being loaded straight into their slots.  Behind the
-    // fused low-pass (LP) the loads go to a PD-slot queue of their own, whose phase must repeat with the unrolled body: the
-    // smallest multiple of PD that holds the 2S+1 live rows
-    static constexpr int R = LP ? 2 * S + 2 : 2 * S + 1 + PD;
-    static constexpr int M = S <= 2 ? 8 : 12;                       // strip margin: multiple of 4, >= 2S+3 (2 for the fused low-pass)
+    static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
+    static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
     // waves per SIMD the register allocator must make room for.  S = 3 needs ~187 VGPRs (2 waves); capping it at 168 for a
     // third wave spills 26 dwords and measured 3 % SLOWER (A/B on one box), so S >= 3 stays at two waves
     static constexpr int MINW = S <= 2 ? 3 : 2;
 };
-
-#ifndef HAK_HS_LP2_MINW
-#define HAK_HS_LP2_MINW 3
-#endif
-// S = 2 behind the fused low-pass needs ~190 VGPRs unconstrained: three waves (168, 40 dwords spilled) or two -- A/B in DESIGN.md
-template <int S, bool LP> struct HsMinW { static constexpr int v = (LP && S == 2) ? HAK_HS_LP2_MINW : HsGeo<S, false>::MINW; };
 
 template <typename V> struct HsV2;
 template <> struct HsV2<float> { using T = float2; };
@@ -57,17 +48,13 @@ template <> struct HsV2<int> { using T = int2; };
 #define HS_CBUF 256
 struct HsCand { unsigned long long* buf; int n; };      // staged candidates: this wave's HS_CBUF LDS entries; n: wave-uniform fill count
 
-template <typename V, int S, bool LP> struct HsState {
+template <typename V, int S> struct HsState {
     using V4 = typename FedV<V>::V4;
-    V4 A[HsGeo<S, LP>::R], X[HsGeo<S, LP>::R];                      // slot = iteration index mod R
+    V4 A[HsGeo<S>::R], X[HsGeo<S>::R];                              // slot = iteration index mod R
     V4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
     V4* XS;                                                     // one staging row for Lx (interleaved store below)
     V4 Dm, Dc, Dp;                                                  // det rows e-1, e, e+1 (rotated by moves)
     HsCand cb;                                                      // staged candidates
-    // fused sigma=1 low-pass (LP): prefetched rows of L and the last five row-pass rows (window rotated by moves: the row
-    // loop is fully unrolled, so the compiler renames them away except at the loop edge)
-    V4 Lq[HsGeo<S, LP>::PD];
-    V4 rp[5];
 };
 
 template <int I, typename V4> __device__ __forceinline__ auto hs_c(const V4& r)
@@ -131,7 +118,6 @@ template <typename V> struct HsArgs {
                                                     // HAK_BUF_OOB: the determinant is not stored (the hardware drops the store)
     int w, h, p;
     V fac1, fac2;
-    SfTaps<V> kk;                                   // sigma=1 Gaussian taps of the fused low-pass (LP kernels only)
     // extrema (maps == nullptr: determinant only)
     unsigned long long* maps; unsigned long long* cand; long cand_cap; HakImgState* st;
     int p0, octave, layer, psz; float border; V threshold;
@@ -176,59 +162,20 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
     }
 }
 
-// LP = false: `src` is the plane the derivatives are taken of (Lt(0,0), or a smooth plane written by an octave head).
-// LP = true:  `src` is L(o, s-1) and the sigma=1 low-pass of akaze.cpp:403 (hLowPass, akazed.cu:204-290) runs here, in front
-//             of the derivative stages, so that the smooth plane never goes to HBM (k_fed_sf then does not write it): the
-//             row pass of L row tt feeds a five-row window, its column pass yields smooth row tt-2, and everything behind
-//             runs two rows later (t = tt-2, ring phase U = UU-2).  Same expressions, order and reflect rule as k_fed_sf.
-template <typename V, int S, int UU, bool XEDGE, bool YEDGE, bool LP>
-__device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int tt, const HsArgs<V>& a, const int xl, const int x0,
+template <typename V, int S, int U, bool XEDGE, bool YEDGE>
+__device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
                                         const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
 {
     using V4 = typename FedV<V>::V4;
-    constexpr int R = HsGeo<S, LP>::R;
-    constexpr int U = LP ? UU - 2 : UU;
-    const int t = LP ? tt - 2 : tt;
+    constexpr int R = HsGeo<S>::R;
     const V fac1 = a.fac1, fac2 = a.fac2;
     const int w = a.w, h = a.h, p = a.p;
     const bool le = x0 == 0, re = x0 + 3 == w - 1;
-    if constexpr (!LP) {
-        // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
-        // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
-        // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
-        T.A[pmod(U + HsGeo<S, LP>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S, LP>::PD, h - 1) * p + xl));
-    } else {
-        constexpr int PD = HsGeo<S, LP>::PD;
-        const V4 c = T.Lq[pmod(UU, PD)];
-        T.Lq[pmod(UU, PD)] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(tt + PD, h - 1) * p + xl));
-        // row pass of the Gaussian on L row tt (akazed.cu:227-239); x neighbours at +-1, +-2 from the adjacent lanes
-        const V sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
-        V4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
-        V4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
-        if (XEDGE) {
-            l1.x = le ? c.y : l1.x;                         // column -1 -> 1
-            l2.x = le ? c.z : l2.x;                         // column -2 -> 2
-            l2.y = le ? c.y : l2.y;                         // column -1 -> 1
-            r1.w = re ? c.z : r1.w;                         // column w   -> w-2
-            r2.z = re ? c.z : r2.z;                         // column w   -> w-2
-            r2.w = re ? c.y : r2.w;                         // column w+1 -> w-3
-        }
-        const SfTaps<V> kk = a.kk;
-        const V4 rpn = mk4(sf_conv(c.x, l1.x, r1.x, l2.x, r2.x, kk), sf_conv(c.y, l1.y, r1.y, l2.y, r2.y, kk),
-                           sf_conv(c.z, l1.z, r1.z, l2.z, r2.z, kk), sf_conv(c.w, l1.w, r1.w, l2.w, r2.w, kk));
-        T.rp[0] = T.rp[1]; T.rp[1] = T.rp[2]; T.rp[2] = T.rp[3]; T.rp[3] = T.rp[4]; T.rp[4] = rpn;    // rows tt-4 .. tt
-        if (YEDGE) {                                        // reflect-101 in y (value selects, see kernels_fedsf.hip)
-            T.rp[0] = vsel4(tt == 2, T.rp[4], T.rp[0]);     // row -2 := row 2
-            T.rp[1] = vsel4(tt == 2, T.rp[3], T.rp[1]);     // row -1 := row 1
-            T.rp[4] = vsel4(tt == h, T.rp[2], T.rp[4]);     // row h   := row h-2
-            T.rp[4] = vsel4(tt == h + 1, T.rp[0], T.rp[4]); // row h+1 := row h-3
-        }
-        // column pass -> smooth row t = tt - 2 (akazed.cu:283-288) straight into its ring slot
-        const V4 cc = T.rp[2], u1 = T.rp[1], d1 = T.rp[3], u2 = T.rp[0], d2 = T.rp[4];
-        T.A[pmod(U, R)] = mk4(sf_conv(cc.x, u1.x, d1.x, u2.x, d2.x, kk), sf_conv(cc.y, u1.y, d1.y, u2.y, d2.y, kk),
-                              sf_conv(cc.z, u1.z, d1.z, u2.z, d2.z, kk), sf_conv(cc.w, u1.w, d1.w, u2.w, d2.w, kk));
-    }
+    // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
+    // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
+    // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
+    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S>::PD, h - 1) * p + xl));
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -350,25 +297,24 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int tt, cons
     }
 }
 
-template <typename V, int S, bool XEDGE, bool YEDGE, bool LP, int... U>
-__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S, LP>& T, const int tb, const HsArgs<V>& a,
+template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
+__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
                                          const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
 {
-    (hs_iter<V, S, U, XEDGE, YEDGE, LP>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff), ...);
+    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff), ...);
 }
 
-template <typename V, int S, bool XEDGE, bool LP>
+template <typename V, int S, bool XEDGE>
 __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
                                          const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf)
 {
-    using G = HsGeo<S, LP>;
+    using G = HsGeo<S>;
     using V4 = typename FedV<V>::V4;
     const int h = a.h, w = a.w;
     const int xl = min(max(x0, 0), a.p - 4);                    // keep every lane's loads inside the plane
-    constexpr int LD = LP ? 2 : 0;                              // the fused low-pass delays every stage by two rows
-    const int t0 = max(0, ybeg - 1 - 2 * S - LD);               // first input row
-    const int tend = yend + 2 * S + LD;                         // iteration that tests the segment's last row for extrema
+    const int t0 = max(0, ybeg - 1 - 2 * S);                    // first input row
+    const int tend = yend + 2 * S;                              // iteration that tests the segment's last row for extrema
     // per-component x range of the extrema test (akazed.cu:1351-1356), constant along the strip
     unsigned xok = 0;
 #pragma unroll
@@ -387,7 +333,7 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
         return q >= G::M && q < G::M + G::XV && x >= 0 && x < w ? (unsigned)x * 2u * (unsigned)sizeof(V) + a.off_dxy : HAK_BUF_OOB;
     };
     const unsigned ovoff[3] = {pair_off(2 * lane), owns && a.off_det != HAK_BUF_OOB ? xb + a.off_det : HAK_BUF_OOB, pair_off(128 + 2 * lane)};
-    HsState<V, S, LP> T;
+    HsState<V, S> T;
     T.Y = yring;
     T.XS = xstage;
     T.cb.buf = cbuf;
@@ -398,29 +344,22 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
 #pragma unroll
-    for (int i = 0; i < 5; i++) T.rp[i] = z4;
-#pragma unroll
-    for (int i = 0; i < G::PD; i++) {
-        const V4 row = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl));
-        if constexpr (LP) { T.Lq[i] = row; }
-        else { T.A[i] = row; T.Lq[i] = z4; }
-    }
+    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl));
     for (int tb = t0; tb <= tend; tb += G::R) {
-        // reflect injections fire while a ring is at rows 1..S (t <= 2S, two rows later behind the low-pass, whose own
-        // window needs them at row 2) or at the virtual rows past h-1
-        if (tb <= 2 * S + LD || tb + G::R - 1 >= h)
-            hs_group<V, S, XEDGE, true, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
+        // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
+        if (tb <= 2 * S || tb + G::R - 1 >= h)
+            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
         else
-            hs_group<V, S, XEDGE, false, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
+            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
     }
     if (a.maps != nullptr) hs_flush(T.cb, a, lane);
 }
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
-template <typename V, int S, bool LP>
-__global__ __launch_bounds__(256, (HsMinW<S, LP>::v)) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
+template <typename V, int S>
+__global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
 {
-    using G = HsGeo<S, LP>;
+    using G = HsGeo<S>;
     __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
     __shared__ typename FedV<V>::V4 xstage[4 * 64];                           // per-wave Lx staging row of the interleaved store
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
@@ -436,30 +375,28 @@ __global__ __launch_bounds__(256, (HsMinW<S, LP>::v)) void k_hessian_stream(HsAr
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
-    else hs_strip<V, S, false, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
+    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
 }
 
 template <typename V, int S>
-void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, int nimg, bool lowpass)
+void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, int nimg)
 {
-    using G = HsGeo<S, false>;                                  // (the strip geometry does not depend on LP)
+    using G = HsGeo<S>;
     const int gx = (a.w + G::XV - 1) / G::XV;
     // rows per wave: tall segments amortise the 4S+2 warm-up rows; shrink while the grid cannot fill the chip
     int ry = 128;
     while (ry > 16 && (long)gx * ((a.h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
     const int gy = (a.h + 4 * ry - 1) / (4 * ry);
-    if (lowpass) k_hessian_stream<V, S, true><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
-    else k_hessian_stream<V, S, false><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
+    k_hessian_stream<V, S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
 }
 
 
 template <typename V>
 bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_det, long stride, int w, int h, int p, int nimg, int step,
-                       V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold,
-                       const V* lp_taps)
+                       V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
 {
-    if (!hak_hessian_stream_covers(w, h, p, step)) return false;
+    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
     HsArgs<V> a{};
     V* lo = dxy;
     if (store_det && det < lo) lo = det;
@@ -470,8 +407,6 @@ bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_
     a.obase = lo; a.off_dxy = (unsigned)((dxy - lo) * sizeof(V));
     a.off_det = store_det ? (unsigned)((det - lo) * sizeof(V)) : HAK_BUF_OOB;
     a.src = src; a.dxy = dxy; a.det = det; a.w = w; a.h = h; a.p = p; a.fac1 = fac1; a.fac2 = fac2;
-    if (lp_taps) a.kk = SfTaps<V>{lp_taps[0], lp_taps[1], lp_taps[2]};
-    const bool lowpass = lp_taps != nullptr;
     long map_stride = 0;
     if (b) {
         const int layer = octave * L->ms + sub;
@@ -480,39 +415,27 @@ bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_
         a.psz = (int)htab->borders[octave * L->ms]; a.border = htab->borders[layer]; a.threshold = threshold;
     }
     switch (step) {
-    case 1: launch_stream<V, 1>(st, a, stride, map_stride, nimg, lowpass); break;
-    case 2: launch_stream<V, 2>(st, a, stride, map_stride, nimg, lowpass); break;
-    case 3: launch_stream<V, 3>(st, a, stride, map_stride, nimg, lowpass); break;
-    default: launch_stream<V, 4>(st, a, stride, map_stride, nimg, lowpass); break;
+    case 1: launch_stream<V, 1>(st, a, stride, map_stride, nimg); break;
+    case 2: launch_stream<V, 2>(st, a, stride, map_stride, nimg); break;
+    case 3: launch_stream<V, 3>(st, a, stride, map_stride, nimg); break;
+    default: launch_stream<V, 4>(st, a, stride, map_stride, nimg); break;
     }
     return true;
 }
 
 }   // namespace
 
-// the shapes this kernel covers (the launch sequence asks before it decides whether k_fed_sf still has to write smooth)
-bool hak_hessian_stream_covers(int w, int h, int p, int step)
-{
-    return step >= 1 && step <= 4 && (w & 3) == 0 && w >= 16 && h >= 2 * step + 6 &&
-           2L * h * p < (long)HAK_BUF_OOB / 4 - 2L * h * p;                    // interleaved plane + room for a det plane below the marker
-}
-
-// return false when this kernel does not cover the case (caller falls back to the LDS tile kernel).  lp_taps != nullptr:
-// `src` is L(o, s-1) and the sigma=1 low-pass runs inside the kernel (three taps k0, k1, k2)
+// return false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
-                               const float* lp_taps)
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
-    return launch_stream_any<float>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold,
-                                    lp_taps);
+    return launch_stream_any<float>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold);
 }
 
 bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
-                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold,
-                                const int* lp_taps)
+                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
-    return launch_stream_any<int>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold,
-                                  lp_taps);
+    return launch_stream_any<int>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold);
 }
