@@ -99,6 +99,28 @@ def gather_summary(pairs, keypoints, matches, device, use_dist):
     return summary.cpu().tolist()
 
 
+def pin_to_gpu_numa_node(local_rank, world):
+    """best effort: run this rank's host threads (launch loop, pinned result buffers, OpenMP oracle) on the cores of the NUMA node its
+    GPU hangs off, so that the PCIe traffic of the result download / image upload does not cross sockets (SURVEY 8e names the host
+    side as the 8-GPU bottleneck).  Returns the node number or None when the topology cannot be read."""
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node < 0:
+            return None
+        cpus = set()
+        for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        allowed = cpus & set(os.sched_getaffinity(0))
+        if world > 1 and len(allowed) >= 2:
+            os.sched_setaffinity(0, allowed)
+        return node
+    except Exception:
+        return None
+
+
 def fence(use_dist):
     torch.cuda.synchronize()
     if use_dist:
@@ -371,6 +393,7 @@ def main():
         print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
+    numa_node = pin_to_gpu_numa_node(local_rank, world)
     # HAK_BENCH_FORCE_DIST=1 exercises the RCCL code path (barrier / MAX all-reduce / summary all-gather) with one rank too
     use_dist = world > 1 or os.environ.get("HAK_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -569,7 +592,7 @@ def main():
                        "pairs_per_step_per_gpu": my_pairs if strong else B, "pairs_per_launch_sequence": B,
                        "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
                        "octave_streams": "serial" if args.serial else "concurrent", "step_pipeline": NCTX,
-                       "sharding": "independent pairs per rank, no data-path collective",
+                       "sharding": "independent pairs per rank, no data-path collective", "rank0_gpu_numa_node": numa_node,
                        "keypoints_per_image": round(summary[1] / max(1.0, 2.0 * summary[0]), 1),
                        "matches_per_pair": round(summary[2] / max(1.0, float(summary[0])), 1)},
             "verified": verified, "roofline": roof, "cpu_baseline": cpu, "configs": extra,

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -710,6 +711,10 @@ extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point*
     if (!d_pts1 || (!d_pts2 && n2 > 0)) return fail("null argument");
     if (n1 <= 0) return 0;
     if (n2 >= (1 << 20)) return fail("more than 2^20 - 1 train points");         // k_match packs distance << 20 | index
+    // one big pair goes through a process-wide scratch buffer (sliced search, kernels_match.hip): concurrent calls of this
+    // synchronous entry point take turns (the reference's cuMatch is not re-entrant at all)
+    static std::mutex match_mutex;
+    std::lock_guard<std::mutex> guard(match_mutex);
     hipStream_t st = c ? c->stream : nullptr;
     if (c) {
         ProfScope ps(c, HAK_PROF_MATCH);

@@ -72,19 +72,26 @@ __device__ __forceinline__ unsigned hamming_key(const unsigned int (&q)[16], con
 // distances, the smallest index -- the reference's "first strict minimum in ascending order" (akazed.cu:2176-2187) -- in
 // one v_min_u32 instead of compare + two selects.  Requires n2 < 2^20 (checked by the launcher).
 // NQ = 1 is used when NQ = 2 would leave the chip with fewer than ~2 blocks per CU (one big pair, e.g. 10k x 10k).
+// gkey != nullptr (one big pair, blockIdx.y = train slice): the block walks only tiles [slice * tiles_per_slice, ...) and
+// merges its class minima into gkey[query][class] with atomicMin -- the packed key makes the merge order-independent (smaller
+// distance first, then smaller index) -- and k_match_finish applies the accept rule; the chip then sees slices x query
+// blocks workgroups instead of n1 / 16.
 template <int NQ>
 __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_point* pts2_base,
                                                const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
-                                               int n1_host, int n2_host, long stride1, long stride2, int count_stride)
+                                               int n1_host, int n2_host, long stride1, long stride2, int count_stride,
+                                               unsigned* __restrict__ gkey, int tiles_per_slice)
 {
     constexpr int QB = MQ * NQ;                          // queries per block
     __shared__ unsigned skey[MC][QB];
     __shared__ unsigned int tile[MT][16];               // 16 KB: every train descriptor is fetched once per block
-    const int pair = blockIdx.y;
+    const int pair = gkey ? 0 : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
     hak_point* pts1 = pts1_base + (long)pair * stride1;
     const hak_point* pts2 = pts2_base + (long)pair * stride2;
+    const int jbeg = gkey ? (int)blockIdx.y * tiles_per_slice * MT : 0;
+    const int jend = gkey ? min(n2, jbeg + tiles_per_slice * MT) : n2;
     const int q = threadIdx.x & (MQ - 1), c = threadIdx.x >> 4;     // lane = q + 16*(c%4): 4 classes per wave
     for (int q0 = blockIdx.x * QB; q0 < n1; q0 += gridDim.x * QB) {
         unsigned int qd[NQ][16];
@@ -96,7 +103,7 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
             if (q0 + q + MQ * a < n1) load_desc(pts1 + q0 + q + MQ * a, qd[a]);
             best[a] = 0xFFFFFFFFu;
         }
-        for (int j0 = 0; j0 < n2; j0 += MT) {
+        for (int j0 = jbeg; j0 < jend; j0 += MT) {
             __syncthreads();                                        // previous tile's readers are done
             stage_train(pts2, j0, n2, tile, threadIdx.x);
             __syncthreads();
@@ -119,6 +126,12 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
 #pragma unroll
                 for (int a = 0; a < NQ; a++) best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + r)));
             }
+        }
+        if (gkey) {                                                 // (uniform) sliced search: merge, k_match_finish decides
+#pragma unroll
+            for (int a = 0; a < NQ; a++)
+                if (q0 + q + MQ * a < n1 && best[a] != 0xFFFFFFFFu) atomicMin(&gkey[(long)(q0 + q + MQ * a) * MC + c], best[a]);
+            continue;
         }
 #pragma unroll
         for (int a = 0; a < NQ; a++) skey[c][q + MQ * a] = best[a];
@@ -150,6 +163,39 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
             }
         }
         __syncthreads();
+    }
+}
+
+// accept rule of gHammingMatch (akazed.cu:2190-2223) on the merged class minima of the sliced search; one thread per query
+__global__ __launch_bounds__(256) void k_match_finish(hak_point* pts1, const hak_point* pts2, int n1, const unsigned* __restrict__ gkey)
+{
+    const int qi = blockIdx.x * 256 + threadIdx.x;
+    if (qi >= n1) return;
+    const uint4* k4 = reinterpret_cast<const uint4*>(gkey + (long)qi * MC);
+    unsigned k[MC];
+#pragma unroll
+    for (int t = 0; t < MC / 4; t++) { const uint4 v = k4[t]; k[4 * t] = v.x; k[4 * t + 1] = v.y; k[4 * t + 2] = v.z; k[4 * t + 3] = v.w; }
+    int bc = 0;
+#pragma unroll
+    for (int t = 1; t < MC; t++)
+        if ((k[t] >> 20) < (k[bc] >> 20)) bc = t;
+    const unsigned kmin = k[bc];
+    const int dmin = (int)(kmin >> 20);
+    int nflag = 0;
+#pragma unroll
+    for (int t = 0; t < MC; t++) nflag += (unsigned)dmin < (k[t] >> 20) ? 1 : 0;
+    hak_point* p1 = pts1 + qi;
+    const int bi = (int)(kmin & 0xFFFFFu);
+    if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {
+        p1->match = bi;
+        p1->distance = dmin;
+        p1->match_x = pts2[bi].x;
+        p1->match_y = pts2[bi].y;
+    } else {
+        p1->match = -1;
+        p1->distance = -1;
+        p1->match_x = -1.f;
+        p1->match_y = -1.f;
     }
 }
 
@@ -280,6 +326,11 @@ void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pt
                                            ratio_den, cross, max_dist, out, out_stride, out_count, 1);
 }
 
+// scratch of the sliced search (one big pair through hak_match, whose context may be NULL): one process-wide buffer per
+// call site is enough -- hak_match is synchronous -- and it only ever grows
+static unsigned* g_match_keys = nullptr;
+static long g_match_keys_cap = 0;
+
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs)
 {
@@ -291,7 +342,29 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     int gx = n1_dev ? (two ? 320 : 640) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
+    // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well
+    const int tiles = (n2_host + MT - 1) / MT;
+    if (!n1_dev && npairs == 1 && !two && gx < 2048 && tiles >= 4) {
+        int slices = (2048 + gx - 1) / gx;
+        if (slices > tiles / 2) slices = tiles / 2;
+        const int tps = (tiles + slices - 1) / slices;
+        slices = (tiles + tps - 1) / tps;
+        const long need = (long)n1_host * MC;
+        bool ok = true;
+        if (need > g_match_keys_cap) {
+            if (g_match_keys) (void)hipFree(g_match_keys);
+            g_match_keys = nullptr; g_match_keys_cap = 0;
+            ok = hipMalloc((void**)&g_match_keys, sizeof(unsigned) * (size_t)need) == hipSuccess;
+            if (ok) g_match_keys_cap = need;
+        }
+        if (ok && slices > 1) {
+            (void)hipMemsetAsync(g_match_keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
+            k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, g_match_keys, tps);
+            k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, g_match_keys);
+            return;
+        }
+    }
     dim3 grid(gx, npairs);
-    if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2);
-    else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2);
+    if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
+    else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
 }
