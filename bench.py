@@ -188,6 +188,28 @@ def verify_batch(want, pts, counts):
             "checker": "CPU oracle (oracle/akaze_oracle.c) on the same seeded pairs, all 104-byte fields"}
 
 
+def opencv_baseline(u8_pairs, cores):
+    """main.cpp:344-399's own CPU leg -- cv::AKAZE::create() defaults + BFMatcher(HAMMING) -- when OpenCV is importable
+    (it is not in this image; the oracle port below is what runs)"""
+    try:
+        import cv2
+    except ImportError:
+        return None
+    cv2.setNumThreads(cores)
+    det, bf = cv2.AKAZE_create(), cv2.BFMatcher(cv2.NORM_HAMMING)
+    times = []
+    for k in range(11):
+        a, b = u8_pairs[k % len(u8_pairs)]
+        t0 = time.perf_counter()
+        _, d1 = det.detectAndCompute(a, None)
+        _, d2 = det.detectAndCompute(b, None)
+        bf.match(d1, d2)
+        if k:
+            times.append(time.perf_counter() - t0)
+    return {"value": round(1.0 / statistics.median(times), 4), "unit": "pairs/s", "cores": cores,
+            "what": "cv2.AKAZE_create() defaults + BFMatcher(NORM_HAMMING), median of 10 pairs"}
+
+
 def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times, budget_s=25.0):
     """median pairs/s of the oracle over >= 10 pairs (after the warm-up pairs already run for the verification)"""
     times = list(first_times[1:])                 # the very first pair paid page-in and the OpenMP pool start-up
@@ -204,6 +226,7 @@ def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times,
     tot = statistics.median(t[0] + t[1] for t in times)
     return {"value": round(1.0 / tot, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
             "detect_ms_per_pair": round(det * 1e3, 2), "match_ms_per_pair": round(mat * 1e3, 2),
+            "opencv": opencv_baseline(u8_pairs, cores),
             "sample": f"median of {len(times)} synthetic {w}-px-wide pairs (detect+describe both images, then match), "
                       f"OpenMP oracle built {flags}; OpenCV's cv::AKAZE (main.cpp:344-399) is not installed in this image"}
 
