@@ -296,10 +296,10 @@ class Pipeline:
 
 
 def fit_batch(B, w, h, max_pts, nctx, floor=16):
-    # arena ~ 19 float planes per octave pyramid + key map + candidate list ~ 31 B/px x 4/3 per image and context
-    # (250 MB at 1080p): 128 pairs x 2 contexts = 127 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
+    # arena = 15 float planes per octave pyramid (x 4/3) + key map 8 B/px + candidate list ~ 11 B/px ~ 100 B/px per image and
+    # context (207 MB at 1080p): 128 pairs x 2 contexts = 106 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
     free_b = torch.cuda.mem_get_info()[0]
-    while B > floor and 2 * B * (w * h * 125 + 2 * max_pts * 104) * nctx > 0.8 * free_b:
+    while B > floor and 2 * B * (w * h * 100 + 2 * max_pts * 104) * nctx > 0.8 * free_b:
         B //= 2
     return B
 
