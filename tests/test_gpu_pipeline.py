@@ -310,7 +310,8 @@ def gpu_match(ah, torch, p1, p2):
     return out
 
 
-@pytest.mark.parametrize("n1,n2", [(1000, 1000), (37, 5), (5, 37), (16, 16), (300, 0), (1, 1), (2205, 2382)])
+@pytest.mark.parametrize("n1,n2", [(1000, 1000), (37, 5), (5, 37), (16, 16), (300, 0), (1, 1), (2205, 2382),
+                                   (300, 5000), (3000, 7777), (40, 1023), (40, 1025), (5000, 600)])   # sliced / unsliced train sets
 def test_match_vs_oracle(ah, okz, torch, synth, n1, n2):
     base = synth.random_descriptors(max(n2, 1), 7, ah.POINT_DTYPE)[:n2]
     q = synth.random_descriptors(n1, 8, ah.POINT_DTYPE, planted_from=base if n2 else None,
@@ -323,6 +324,31 @@ def test_match_vs_oracle(ah, okz, torch, synth, n1, n2):
         assert np.array_equal(got[f], want[f]), f
     if n2 >= 2 and n1 >= 100:
         assert (got["match"] >= 0).sum() > 0
+
+
+def test_match_ties_across_tiles_and_slices(ah, okz, torch, synth):
+    """the accept rule counts the residue classes that attain the minimum (akazed.cu:2206) and every class keeps its FIRST minimum:
+    a train set made of repeated descriptors puts equal distances into different LDS tiles, different classes and -- for the big
+    pair -- different train slices, whose packed keys are merged with atomicMin"""
+    rng = np.random.default_rng(5)
+    proto = synth.random_descriptors(48, 11, ah.POINT_DTYPE)
+    for n1, n2 in ((64, 4096), (4000, 6000)):
+        train = proto[rng.integers(0, len(proto), n2)].copy()
+        train["x"] = np.arange(n2, dtype=np.float32)
+        # every 97th train descriptor is unique (a single class attains its minimum: accepted), the rest are repeats
+        uniq = synth.random_descriptors(n2 // 97 + 1, 12, ah.POINT_DTYPE)
+        train["features"][::97] = uniq["features"][:len(train[::97])]
+        pick = rng.integers(0, n2, n1)
+        pick[::2] = rng.choice(np.arange(0, n2, 97), size=len(pick[::2]))     # every other query sits next to a unique train point
+        query = train[pick].copy()
+        flip = rng.integers(0, 486, n1)
+        query["features"][np.arange(n1), flip >> 3] ^= (1 << (flip & 7)).astype(np.uint8)
+        query["features"][:, 60] &= 0x3F
+        got = gpu_match(ah, torch, query, train)
+        want = okz.match(query.copy(), train)
+        for f in ("match", "distance", "match_x", "match_y"):
+            assert np.array_equal(got[f], want[f]), (n1, n2, f)
+        assert 0 < (got["match"] >= 0).sum() < n1               # both outcomes of the rule occur
 
 
 def test_match_10k_x_10k(ah, okz, torch, synth):
