@@ -606,11 +606,13 @@ def main():
     if rank == 0:
         total_pairs = (args.total_pairs if strong else world * B) * args.steps
         out = {
-            "metric": "pairs_per_sec_detect_describe_match_1080p", "value": round(total_pairs / elapsed, 2),
+            "metric": f"pairs_per_sec_detect_describe_match_{h}p", "value": round(total_pairs / elapsed, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"configs[1]: {w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
+            "config": {"workload": ("configs[1]: " if (w, h, args.octaves) == (1920, 1080, 4) else "configs[3] shape: " if (w, h) == (1280, 720) else
+                                    "configs[2]: " if (w, h, args.octaves) == (3840, 2160, 5) else "") +
+                                   f"{w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
                        "pairs_per_step_per_gpu": my_pairs if strong else B, "pairs_per_launch_sequence": B,
                        "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
