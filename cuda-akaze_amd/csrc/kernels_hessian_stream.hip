@@ -38,7 +38,7 @@ template <int S> struct HsGeo {
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
     // waves per SIMD the register allocator must make room for.  S = 3 needs ~187 VGPRs (2 waves); capping it at 168 for a
     // third wave spills 26 dwords and measured 3 % SLOWER (A/B on one box), so S >= 3 stays at two waves
-    static constexpr int MINW = S <= 2 ? 3 : 2;
+    static constexpr int MINW = S <= 3 ? 3 : 2;
 };
 
 template <typename V> struct HsV2;
@@ -123,29 +123,40 @@ template <typename V> struct HsArgs {
     int p0, octave, layer, psz; float border; V threshold;
 };
 
+// Arguments that only the (rare) candidate emission needs.  As kernel arguments they would sit in SGPRs for the whole row
+// loop -- the loop is short of scalar registers (10 v_readlane spill reloads per row at S = 3) -- so the block parks them in
+// LDS once and the emission path reads them back.
+struct HsCold { unsigned long long* maps; unsigned long long* cand; long cand_cap; HakImgState* st; int p0, octave, layer, pad; };
+// Pointers that come back from LDS are generic to the compiler: it would use FLAT atomics / stores for them, and a FLAT
+// operation in the row loop makes every later wait a full `vmcnt(0) lgkmcnt(0)` drain (measured: Hessian +12 %).  The casts
+// below tell it the truth -- these are global addresses.
+typedef unsigned long long __attribute__((address_space(1))) * hs_gu64p;
+typedef int __attribute__((address_space(1))) * hs_gi32p;
+
 // Candidate emission.  Reserving list slots needs an atomic WITH return, and waiting for it drains every outstanding
 // store and prefetch of the wave (s_waitcnt vmcnt(0)) -- with a candidate in roughly every third row that stalled the
 // stream for a full memory round trip again and again.  Candidates are therefore staged in a 256-entry per-wave LDS
 // buffer and flushed with ONE slot reservation when it runs full (and at the end of the segment); the key-map update is a
 // return-less atomic and stays inline.
 
-template <typename V>
-__device__ __forceinline__ void hs_flush(HsCand& cb, const HsArgs<V>& a, const int lane)
+__device__ __forceinline__ void hs_flush(HsCand& cb, const HsCold* cold, const int lane)
 {
     if (cb.n > 0) {
+        const HsCold a = *cold;
         int base = 0;
-        if (lane == 0) base = atomicAdd(&a.st->ncand, cb.n);
+        if (lane == 0) base = __hip_atomic_fetch_add((hs_gi32p)&a.st->ncand, cb.n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         base = __builtin_amdgcn_readfirstlane(base);
+        const hs_gu64p gcand = (hs_gu64p)a.cand;
         for (int i = lane; i < cb.n; i += 64) {
             const long slot = (long)base + i;
-            if (slot < a.cand_cap) a.cand[slot] = cb.buf[i];
+            if (slot < a.cand_cap) gcand[slot] = cb.buf[i];
         }
         cb.n = 0;
     }
 }
 
 template <typename V>
-__device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, const int e, const HsArgs<V>& a, const int lane,
+__device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, const int e, const HsCold& a, const int lane,
                                         HsCand& cb)
 {
     const unsigned long long m = __ballot(hit);
@@ -154,7 +165,7 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
         if (hit) {
             const int fx = x << a.octave, fy = e << a.octave;
             const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)a.layer);
-            atomicMax(&a.maps[(long)fy * a.p0 + fx], key);
+            (void)__hip_atomic_fetch_max((hs_gu64p)a.maps + ((long)fy * a.p0 + fx), key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             cb.buf[cb.n + __popcll(m & ((1ull << lane) - 1ull))] =
                 ((unsigned long long)a.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
         }
@@ -165,7 +176,8 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
 template <typename V, int S, int U, bool XEDGE, bool YEDGE>
 __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
-                                        const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
+                                        const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3], const int er0, const int er1,
+                                        const HsCold* cold)
 {
     using V4 = typename FedV<V>::V4;
     constexpr int R = HsGeo<S>::R;
@@ -263,14 +275,15 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
         hak_buf_store_nt(orsrc, ovoff[1] + (c >= ybeg && c < yend ? (unsigned)(c * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), d);
     }
     // ---- extrema of row e = t - 2S - 1 (akazed.cu:1346-1373)
-    if (a.maps != nullptr) {
+    {
         const int e = t - 2 * S - 1;
         const V thr = a.threshold;
         const V4 v = T.Dc;
-        // threshold first: almost no pixel passes it, so the wave almost always skips the neighbourhood test
+        // threshold first: almost no pixel passes it, so the wave almost always skips the neighbourhood test.  [er0, er1) = the
+        // rows of this segment that pass the reference's border test (akazed.cu:1351-1356), worked out once per strip; empty
+        // when the launch wants the determinant only
         const bool any = owns && (v.x > thr || v.y > thr || v.z > thr || v.w > thr);
-        if (e >= ybeg && e < yend && __ballot(any) != 0ull &&
-            e >= a.psz && (int)(e - a.border + 0.5f) - 1 >= 0 && (int)(e + a.border + 0.5f) + 1 < h) {
+        if (e >= er0 && e < er1 && __ballot(any) != 0ull) {
             const V4 up = T.Dm, dn = T.Dp;
             const V vl = wave_shr1(v.w), vr = wave_shl1(v.x);
             const V ul = wave_shr1(up.w), ur = wave_shl1(up.x);
@@ -287,11 +300,12 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
             const bool hz = owns && (xok & 4u) && v.z > mz;
             const bool hw = owns && (xok & 8u) && v.w > mw;
             if (__ballot(hx || hy || hz || hw) != 0ull) {
-                if (T.cb.n > HS_CBUF - 128) hs_flush(T.cb, a, lane);    // a row holds at most 128 strict 3x3 maxima per wave
-                hs_emit(hx, v.x, x0, e, a, lane, T.cb);
-                hs_emit(hy, v.y, x0 + 1, e, a, lane, T.cb);
-                hs_emit(hz, v.z, x0 + 2, e, a, lane, T.cb);
-                hs_emit(hw, v.w, x0 + 3, e, a, lane, T.cb);
+                if (T.cb.n > HS_CBUF - 128) hs_flush(T.cb, cold, lane);    // a row holds at most 128 strict 3x3 maxima per wave
+                const HsCold ca = *cold;                                   // one LDS read of the parked arguments per row with a hit
+                hs_emit(hx, v.x, x0, e, ca, lane, T.cb);
+                hs_emit(hy, v.y, x0 + 1, e, ca, lane, T.cb);
+                hs_emit(hz, v.z, x0 + 2, e, ca, lane, T.cb);
+                hs_emit(hw, v.w, x0 + 3, e, ca, lane, T.cb);
             }
         }
     }
@@ -300,14 +314,16 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
 template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
 __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3])
+                                         const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3],
+                                         const int er0, const int er1, const HsCold* cold)
 {
-    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff), ...);
+    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold), ...);
 }
 
 template <typename V, int S, bool XEDGE>
 __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
-                                         const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf)
+                                         const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf,
+                                         const HsCold* cold)
 {
     using G = HsGeo<S>;
     using V4 = typename FedV<V>::V4;
@@ -321,6 +337,14 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     for (int k = 0; k < 4; k++) {
         const int x = x0 + k;
         if (x >= a.psz && (int)(x - a.border + 0.5f) - 1 >= 0 && (int)(x + a.border + 0.5f) + 1 < w) xok |= 1u << k;
+    }
+    // rows of this segment whose extrema are wanted: the reference's border test is monotone in the row, so it is a range
+    int er0 = 0, er1 = 0;
+    if (a.maps != nullptr) {
+        auto row_ok = [&](int e) { return e >= a.psz && (int)(e - a.border + 0.5f) - 1 >= 0 && (int)(e + a.border + 0.5f) + 1 < h; };
+        er0 = ybeg; er1 = yend;
+        while (er0 < er1 && !row_ok(er0)) er0++;
+        while (er1 > er0 && !row_ok(er1 - 1)) er1--;
     }
     const __amdgpu_buffer_rsrc_t orsrc = hak_buf_rsrc(a.obase);
     // per-plane lane offsets (column + plane); lanes that own nothing carry the out-of-range marker
@@ -348,11 +372,11 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     for (int tb = t0; tb <= tend; tb += G::R) {
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
         if (tb <= 2 * S || tb + G::R - 1 >= h)
-            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
+            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
         else
-            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff);
+            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
     }
-    if (a.maps != nullptr) hs_flush(T.cb, a, lane);
+    if (a.maps != nullptr) hs_flush(T.cb, cold, lane);
 }
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
@@ -363,10 +387,15 @@ __global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V
     __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
     __shared__ typename FedV<V>::V4 xstage[4 * 64];                           // per-wave Lx staging row of the interleaved store
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
+    __shared__ HsCold cold;
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
     a.src += (long)img * stride; a.obase += (long)img * stride;
-    if (a.maps) { a.maps += (long)img * map_stride; a.cand += (long)img * a.cand_cap; a.st += img; }
+    if (a.maps) {
+        if (threadIdx.x == 0)
+            cold = HsCold{a.maps + (long)img * map_stride, a.cand + (long)img * a.cand_cap, a.cand_cap, a.st + img, a.p0, a.octave, a.layer, 0};
+        __syncthreads();                                        // (block-uniform; the only barrier of the kernel)
+    }
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int ybeg = (by * 4 + wv) * ry;
@@ -375,8 +404,8 @@ __global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
-    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
+    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
 }
 
 template <typename V, int S>
