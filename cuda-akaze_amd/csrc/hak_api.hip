@@ -283,6 +283,7 @@ static int build_plan(hak_ctx* c, int w, int h)
             c->htab.comp_packed[b * 16 + 2 * i] = (unsigned char)c->htab.comp1[b * 8 + i];
             c->htab.comp_packed[b * 16 + 2 * i + 1] = (unsigned char)c->htab.comp2[b * 8 + i];
         }
+    hak_describe_plan(&c->htab, cfg.descriptor_pattern_size);
     hak_gauss_taps(1.f, 2, c->taps1);
     int ksz = (int)(2 * ceilf((cfg.soffset - 0.8f) / 0.3f) + 3);                 // akaze.cpp:328
     c->base_R = ksz <= 5 ? 2 : ksz <= 7 ? 3 : ksz <= 9 ? 4 : 5;                   // akazed.cu:2345-2377
@@ -308,6 +309,8 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
     { const char* e = getenv("HAK_BASE_STREAM"); hak_base_stream_enabled = e ? atoi(e) : 1; }
     { const char* e = getenv("HAK_HESS_CBUF"); const int v = e ? atoi(e) : 256; hak_hessian_cbuf_cap = v < 1 ? 1 : (v > 256 ? 256 : v); }
+    { const char* e = getenv("HAK_DESC_ORDER"); const int v = e ? atoi(e) : 4; hak_desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    { const char* e = getenv("HAK_DESC_PLAN"); hak_desc_plan = e ? atoi(e) : 1; }
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
@@ -520,7 +523,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
       hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts); }
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
-      hak_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc); }
+      hak_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok); }
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     c->maps_dirty = false;
     return 0;
@@ -610,7 +613,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
         }
     }
     hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts, 1);
-    hakf_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc);
+    hakf_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok);
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     c->maps_dirty = false;
     return 0;

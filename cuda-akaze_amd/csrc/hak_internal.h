@@ -49,11 +49,22 @@ struct HakTables {
     float borders[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
     int sigma_size[HAK_MAX_OCTAVES * HAK_MAX_SCALES];
     float orient_w[36];                                // exp(-r2*0.08f)
+    int orient_ij[128];                                // k_orient's 109 disc samples in the reference's thread order: i | j << 8 (bytes)
+    float orient_gw[128];                              // ... and their weight orient_w[i*i + j*j]; slots 109.. unused (0)
     float fac1, fac2;                                  // dilated-Scharr factors (akazed.cu:2537-2539); FAST: ifac = (int)(fac * 65536 + 0.5f)
     int ifac1, ifac2;
     int comp1[488], comp2[488];                        // MLDB pair table (akazed.cu:65-159)
     unsigned char comp_packed[64 * 16];                // per descriptor byte: 8 x (idx1, idx2) as bytes
+    // MLDB sample plan of the configured descriptor_pattern_size (hak_describe_plan, kernels_describe.hip): which sample a
+    // lane takes in its n-th turn and where it goes depends on (lane, n) only, never on the keypoint.  [n * 64 + lane]:
+    //   dsc_pos : bits 0..7 l = x - size2 (signed), 8..15 k = y - size2 (signed), bit 16 sample exists
+    //   dsc_cell: byte g (2x2, 3x3, 4x4 grid) = accumulator row (0x7F none) | 0x80 when the lane's previous sample went to the
+    //             same row; bit 24 + g: last sample of this lane in that row
+    unsigned int dsc_pos[7 * 64];
+    unsigned int dsc_cell[7 * 64];
+    int dsc_plan_ok;                                   // 0: pattern too large or a lane revisits a row -> generic k_describe
 };
+void hak_describe_plan(HakTables* t, int patsize);
 
 // ---------------------------------------------------------------- device helpers
 // reflect-101 as the reference: left/top abs(i), right/bottom borderAdd (akazed.cu:162-170)
@@ -251,6 +262,7 @@ static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
     return strips * ((h + 31) / 32) * nimg >= 2048;
 }
 extern int hak_hessian_stream_enabled;
+extern int hak_desc_order, hak_desc_plan;   // describe: image group size of the block order, planned MLDB kernel (env HAK_DESC_ORDER / HAK_DESC_PLAN)
 extern int hak_hessian_cbuf_cap;       // tile kernel: staged candidates per block (env HAK_HESS_CBUF, tests only)
 // dxy: interleaved {Lx, Ly} plane (2 * h * p elements).  det: where the determinant goes -- the fused kernels write it only
 // when store_det is set (stage tests); the launch sequence passes a scratch plane that only the dilation > 4 fallback fills.
@@ -343,11 +355,11 @@ void hakf_launch_det(hipStream_t st, const int* dxy, int* det, long stride, int 
 void hakf_launch_extrema(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int octave, int s, int threshold,
                          long det_off);
 void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
-                          int patsize, int upright, int desc);
+                          int patsize, int upright, int desc, int planned);
 
 // descriptors (kernels_describe.hip)
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
-                         hak_point* points, int max_pts, int patsize, int upright, int desc);
+                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned);
 
 // bandwidth probes (kernels_probe.hip)
 int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy);

@@ -14,10 +14,11 @@
 //     ascending order; threads are combined as (a_t + a_{t+32}) followed by the
 //     shuffle-down tree 1,2,4,8,16 (akazed.cu:1957-1981)
 //
-// The stage is gather-latency-bound (1323 + 218 scattered loads per keypoint), so (a) all gathers
-// of a phase are issued before any is consumed, and (b) the per-thread accumulator table is built
-// in three rounds over a third-size LDS table (8.2 KB per keypoint), which triples the number of
-// keypoints a CU works on concurrently.
+// Both kernels issue every gather of a keypoint before any is consumed.  What bounds them (counters of the 256 x 1080p batch,
+// profiles/README.md): k_describe* the texture-address path -- TA stalled by the L1 for 81 % of the kernel, 939 L1 accesses and
+// 506 L2 requests per keypoint, two thirds of those L2 misses (random 64-byte sectors at 3.8 TB/s); cutting its VALU work by 40 %
+// and its LDS traffic by more (k_describe_runs against k_describe) moved it by 1 %.  k_orient was bound by LDS broadcast reads
+// until the bin sums were reorganised as a counting sort (0.95 -> 0.42 ms).
 #include "hak_internal.h"
 #include <type_traits>
 
@@ -64,6 +65,8 @@ __device__ __forceinline__ typename DscV2<V>::T dsc_ld2(const V* base, unsigned 
     return *reinterpret_cast<const typename DscV2<V>::T*>(reinterpret_cast<const char*>(base) + 2u * byte_off);
 }
 
+typedef float dsc_v2f __attribute__((ext_vector_type(2)));
+
 template <typename V>
 __device__ __forceinline__ void reduce_rows(const V* acc, V* vals, int nrows, int out_base, int lane)
 {
@@ -91,17 +94,31 @@ __device__ __forceinline__ void reduce_rows(const V* acc, V* vals, int nrows, in
 template <typename V>
 __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long stride, HakLayout L,
                                                const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
-                                               hak_point* points, int max_pts, int do_orient)
+                                               hak_point* points, int max_pts, int do_orient, int order)
 {
     constexpr bool FAST = std::is_same<V, int>::value;
-    __shared__ float4 samp[128];                // {dx, dy, bin (as int bits), -}: one 16-byte broadcast read per sample
+    // bin sums in sample order (D7) without every bin lane looking at every sample: the samples are counting-sorted by bin
+    // (stable: place = samples of lower bins + earlier samples of the same bin, both from 64-bit lane masks OR-ed into LDS per
+    // bin), then lane b adds its own run front to back.  The first version -- 42 bin lanes scanning all 109 samples through
+    // 16-byte LDS broadcast reads -- was bound by exactly those reads: 112 x 768 bytes per keypoint against the CU's
+    // 128 bytes/clk made up 0.6 of the kernel's 0.95 ms, whatever the VALU count.
+    __shared__ unsigned long long bmask[2][42];  // [turn][bin]: lanes of that turn whose sample falls into the bin
+    __shared__ int bstart[42], bfirst[42];      // samples in lower bins; samples of the bin in turn 0
+    __shared__ float2 sorted[112];
     __shared__ float resx[42], resy[42], re8x[42], re8y[42];
-    const int img = blockIdx.y;
+    int img = blockIdx.y, first = blockIdx.x;
+    if (order > 0) {                                                // images dealt in groups of `order`: image index fastest inside a group
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned grp = lin / ((unsigned)order * gridDim.x), b0 = grp * order;
+        const unsigned gs = min((unsigned)order, gridDim.y - b0), within = lin - grp * order * gridDim.x;
+        img = b0 + within % gs;
+        first = within / gs;
+    }
     const int lane = threadIdx.x;
     const int npts = state[img].num_pts;
     const V* arena = base + (long)img * stride;
     hak_point* pts = points + (long)img * max_pts;
-    for (int pi = blockIdx.x; pi < npts; pi += gridDim.x) {
+    for (int pi = first; pi < npts; pi += gridDim.x) {
         hak_point* pt = pts + pi;
         float ptx = pt->x, pty = pt->y;
         const float ptsize = pt->size;
@@ -149,56 +166,69 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
             const int step = (int)(ptsize + 0.5f);
             const int x = (int)(ptx + 0.5f) >> o;
             const int y = (int)(pty + 0.5f) >> o;
-            // the 208 sample threads of the reference, 64 at a time: issue every gather first
-            float gdx[4], gdy[4];
-            int gr2[4];
+            // the reference's 208 sample threads keep the 109 with r2 < 36; HakTables lists those in ascending thread order
+            // (offsets and Gaussian weight per slot), so two turns of 64 lanes cover them and a sample's slot is its place in
+            // the summation order (D7) -- no compaction step.  Slots 109..127 gather at the keypoint and get no bin.
+            float gdx[2], gdy[2], gw[2];
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const int tix = q * 64 + lane;
-                const int i = (tix & 15) - 6, j = (tix >> 4) - 6;
-                const int r2 = i * i + j * j;
-                gr2[q] = (tix < 208 && r2 < 36) ? r2 : -1;
+            for (int q = 0; q < 2; q++) {
+                const int ij = tab->orient_ij[q * 64 + lane];
+                gw[q] = tab->orient_gw[q * 64 + lane];
+                const int i = (int)(signed char)(ij & 0xFF), j = (int)(signed char)((ij >> 8) & 0xFF);
                 const int yy = min(max(y + step * j, 0), oc.h - 1), xx = min(max(x + step * i, 0), oc.w - 1);
                 const unsigned pos = (unsigned)(yy * oc.p + xx) * (unsigned)sizeof(V);
-                if (gr2[q] >= 0) {
-                    const auto d2 = dsc_ld2(dxyd, pos);
-                    gdx[q] = (float)d2.x;
-                    gdy[q] = (float)d2.y;
-                } else gdx[q] = gdy[q] = 0.f;
+                const auto d2 = dsc_ld2(dxyd, pos);
+                gdx[q] = (float)d2.x;
+                gdy[q] = (float)d2.y;
             }
-            // valid samples are compacted in ascending thread order through a ballot
-            int nvalid = 0;
+            int bin[2];
+            float sdx[2], sdy[2];
+            if (lane < 42) bmask[0][lane] = bmask[1][lane] = 0ull;  // (one wave per workgroup: its LDS operations complete in order)
 #pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const bool ok = gr2[q] >= 0;
-                const unsigned long long m = __ballot(ok);
-                if (ok) {
-                    const int slot = nvalid + __popcll(m & ((1ull << lane) - 1ull));
-                    const float gw = tab->orient_w[gr2[q]];
-                    const float dx = gw * gdx[q];
-                    const float dy = gw * gdy[q];
-                    const float ang = FAST ? dsc_fast_atan2(dy, dx) : hak_atan2f(dy, dx);   // akazed.cu:3685 / 1702
-                    int a = (int)(ang * (21 / HAK_PI_D)) + 21;
-                    a = a > 41 ? 41 : a;
-                    a = a < 0 ? 0 : a;
-                    samp[slot] = make_float4(dx, dy, __int_as_float(a), 0.f);
-                }
-                nvalid += __popcll(m);
+            for (int q = 0; q < 2; q++) {
+                sdx[q] = gw[q] * gdx[q];
+                sdy[q] = gw[q] * gdy[q];
+                const float ang = FAST ? dsc_fast_atan2(sdy[q], sdx[q]) : hak_atan2f(sdy[q], sdx[q]);   // akazed.cu:3685 / 1702
+                int a = (int)(ang * (21 / HAK_PI_D)) + 21;
+                a = a > 41 ? 41 : a;
+                a = a < 0 ? 0 : a;
+                bin[q] = q * 64 + lane < 109 ? a : -1;
+                if (bin[q] >= 0) atomicOr(&bmask[q][bin[q]], 1ull << lane);
             }
             hak_lds_barrier();
+            int cnt = 0, start;
             if (lane < 42) {
-                float rx = 0.f, ry = 0.f;
-#pragma unroll 8
-                for (int n = 0; n < nvalid; n++) {                  // ascending sample order (D7)
-                    // unconditional read + select: a branch on the bin made every iteration two dependent LDS round trips
-                    const float4 sv = samp[n];
-                    const bool mine = __float_as_int(sv.z) == lane;
-                    const float nx = rx + sv.x, ny = ry + sv.y;
-                    rx = mine ? nx : rx;
-                    ry = mine ? ny : ry;
+                const int c0 = __popcll(bmask[0][lane]);
+                cnt = c0 + __popcll(bmask[1][lane]);
+                bfirst[lane] = c0;
+            }
+            {
+                int incl = cnt;                                      // inclusive scan over the bin lanes
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const int up = __shfl_up(incl, d);
+                    incl += lane >= d ? up : 0;
                 }
-                resx[lane] = rx;
-                resy[lane] = ry;
+                start = incl - cnt;
+            }
+            if (lane < 42) bstart[lane] = start;
+            hak_lds_barrier();
+#pragma unroll
+            for (int q = 0; q < 2; q++)
+                if (bin[q] >= 0) {
+                    const int place = bstart[bin[q]] + (q ? bfirst[bin[q]] : 0) + __popcll(bmask[q][bin[q]] & ((1ull << lane) - 1ull));
+                    sorted[place] = make_float2(sdx[q], sdy[q]);
+                }
+            hak_lds_barrier();
+            if (lane < 42) {
+                dsc_v2f r = {0.f, 0.f};
+                for (int p = start; p < start + cnt; p++) {
+                    const float2 v = sorted[p];
+                    r.x += v.x;
+                    r.y += v.y;
+                }
+                resx[lane] = r.x;
+                resy[lane] = r.y;
             }
             hak_lds_barrier();
             if (lane < 42) {                                        // akazed.cu:1708-1717
@@ -226,6 +256,200 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
         }
         hak_lds_barrier();                      // the scratch is reused by the next keypoint of this block
     }
+}
+
+// ---- MLDB with the sample plan of HakTables (the default descriptor_pattern_size 10 and every other pattern whose plan
+// holds: <= 7 samples per lane, no lane coming back to an accumulator row it has left).  Same sums in the same order as
+// k_describe below, organised around what is fixed per (lane, n):
+//   * the sample's window offset and its three accumulator rows come from the plan (no division, no cell arithmetic);
+//   * a lane's samples of one row are consecutive turns, so its partial sum a_t = ((0 + v) + v') + ... is carried in
+//     registers and written to the LDS table ONCE (k_describe: a read-modify-write round trip per sample and row);
+//   * two rounds that coincide with the grids -- 2x2 + 3x3 (39 rows), 4x4 (48 rows) -- instead of three of 30 rows that cut
+//     through them: every (sample, grid) is looked at once, not once per round;
+//   * the table is cleared with 16-byte stores in linear order.  One wave per workgroup: its LDS operations complete in
+//     program order, so the clear, the column writes and the row reads need no barrier between them, only the wait for the
+//     read data.
+#define RUN_ROWS 30         // accumulator rows per round
+template <typename V>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_describe_runs(const V* __restrict__ base, long stride, HakLayout L,
+                                                      const HakTables* __restrict__ tab, const HakImgState* __restrict__ state,
+                                                      hak_point* points, int max_pts, int upright, int order)
+{
+    __shared__ __attribute__((aligned(16))) V acc[(RUN_ROWS * ACC_LD + 3) / 4 * 4];
+    __shared__ V vals[90];
+    int img = blockIdx.y, first = blockIdx.x;
+    if (order > 0) {                                                // images dealt in groups of `order`: image index fastest inside a group
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x;
+        const unsigned grp = lin / ((unsigned)order * gridDim.x), b0 = grp * order;
+        const unsigned gs = min((unsigned)order, gridDim.y - b0), within = lin - grp * order * gridDim.x;
+        img = b0 + within % gs;
+        first = within / gs;
+    }
+    const int lane = threadIdx.x;
+    const int npts = state[img].num_pts;
+    const V* arena = base + (long)img * stride;
+    hak_point* pts = points + (long)img * max_pts;
+    if (first >= npts) return;
+    const uint4 cmp = reinterpret_cast<const uint4*>(tab->comp_packed)[lane];
+    const unsigned int cw[4] = {cmp.x, cmp.y, cmp.z, cmp.w};
+
+    for (int pi = first; pi < npts; pi += gridDim.x) {
+        // the lane's sample offsets, loaded with the keypoint (before the gathers: a load issued between them would have to
+        // wait for them too, vmcnt counts in order); its accumulator rows are loaded behind the gathers, where they are used.
+        // Per keypoint, not per block: a block runs this loop once or twice, and hoisted copies cost a wave of occupancy.
+        unsigned posw[MAX_SMP], cellw[MAX_SMP];
+#pragma unroll
+        for (int n = 0; n < MAX_SMP; n++) posw[n] = tab->dsc_pos[n * 64 + lane];
+        hak_point* pt = pts + pi;
+        const float ptx = pt->x, pty = pt->y, ptsize = pt->size;
+        const int layer = __builtin_amdgcn_readfirstlane(pt->octave);
+        const int o = layer / L.ms, s = layer - o * L.ms;
+        const HakOct oc = L.oct[o];
+        const V* imd = arena + L.lt(o, s);
+        const V* dxyd = arena + L.dxy(o, s);
+        float angle = 0.f;
+        if (!upright) angle = pt->angle;                            // written by k_orient
+
+        V vim[MAX_SMP], vrx[MAX_SMP], vry[MAX_SMP];
+        {
+            const float iratio = 1.f / (1 << o);
+            const int scale = (int)(ptsize + 0.5f);
+            const float xf = ptx * iratio;
+            const float yf = pty * iratio;
+            float si, co;
+            hak_sincosf(angle, &si, &co);
+            V gdx[MAX_SMP], gdy[MAX_SMP];
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) {
+                // a turn without a sample (posw = 0) gathers at the keypoint itself; it belongs to no row, so its values
+                // end in a running sum that is never written
+                const int l = (int)(signed char)(posw[n] & 0xFF);
+                const int k = (int)(signed char)((posw[n] >> 8) & 0xFF);
+                int xp = (int)(xf + scale * (k * co - l * si) + 0.5f);  // akazed.cu:1921
+                int yp = (int)(yf + scale * (k * si + l * co) + 0.5f);  // akazed.cu:1922
+                xp = min(max(xp, 0), oc.w - 1);
+                yp = min(max(yp, 0), oc.h - 1);
+                const unsigned pos = (unsigned)(yp * oc.p + xp) * (unsigned)sizeof(V);
+                vim[n] = dsc_ld(imd, pos);
+                const auto d2 = dsc_ld2(dxyd, pos);
+                gdx[n] = d2.x;
+                gdy[n] = d2.y;
+            }
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) cellw[n] = tab->dsc_cell[n * 64 + lane];
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) {
+                vrx[n] = (V)(-gdx[n] * si + gdy[n] * co);           // akazed.cu:1931 / 3777
+                vry[n] = (V)(gdx[n] * co + gdy[n] * si);
+            }
+        }
+        // one grid in one round: the lane's running sums per row, written when the row's last sample has been added and the
+        // row belongs to the round's window [row0, row0 + nrows)
+        auto runs = [&](int g, int row0, int nrows) {
+            V rim = V(0), rrx = V(0), rry = V(0);
+#pragma unroll
+            for (int n = 0; n < MAX_SMP; n++) {
+                const unsigned e = (cellw[n] >> (8 * g)) & 0xFFu;
+                const bool cont = e & 0x80u;
+                rim = dsc_add(cont ? rim : V(0), vim[n]);
+                rrx = dsc_add(cont ? rrx : V(0), vrx[n]);
+                rry = dsc_add(cont ? rry : V(0), vry[n]);
+                const unsigned rr = (e & 0x7Fu) - (unsigned)row0;    // 0x7F (no row) lies beyond every window
+                if (((cellw[n] >> (24 + g)) & 1u) && rr < (unsigned)nrows) {
+                    V* a = acc + rr * ACC_LD + lane;
+                    a[0] = rim;
+                    a[ACC_LD] = rrx;
+                    a[2 * ACC_LD] = rry;
+                }
+            }
+        };
+        auto clear = [&](int nrows) {
+            float4* a4 = reinterpret_cast<float4*>(acc);
+            const int n4 = (nrows * ACC_LD + 3) / 4;
+#pragma unroll
+            for (int i = 0; i < ((RUN_ROWS * ACC_LD + 3) / 4 + 63) / 64; i++)
+                if (lane + 64 * i < n4) a4[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        };
+        // rows 0..11 2x2, 12..38 3x3, 39..86 4x4 (three per cell); a cell never straddles two rounds (30 and 60 are cell starts)
+        clear(RUN_ROWS);
+        runs(0, 0, RUN_ROWS);
+        runs(1, 0, RUN_ROWS);
+        reduce_rows(acc, vals, RUN_ROWS, 0, lane);
+        clear(RUN_ROWS);
+        runs(1, RUN_ROWS, RUN_ROWS);
+        runs(2, RUN_ROWS, RUN_ROWS);
+        reduce_rows(acc, vals, RUN_ROWS, RUN_ROWS, lane);
+        clear(87 - 2 * RUN_ROWS);
+        runs(2, 2 * RUN_ROWS, 87 - 2 * RUN_ROWS);
+        reduce_rows(acc, vals, 87 - 2 * RUN_ROWS, 2 * RUN_ROWS, lane);
+        hak_lds_barrier();
+        if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
+            unsigned int desc_r = 0;
+            const int nb = lane == 60 ? 6 : 8;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const unsigned int pr = (cw[i >> 1] >> (16 * (i & 1))) & 0xFFFFu;
+                const int idx1 = pr & 0xFF, idx2 = pr >> 8;
+                if (i < nb) desc_r |= (vals[idx1] > vals[idx2] ? 1u : 0u) << i;
+            }
+            pt->features[lane] = (unsigned char)desc_r;
+        }
+        if (lane == 0) pt->angle = angle;
+        hak_lds_barrier();
+    }
+}
+
+// the plan of k_describe_runs for one pattern size and k_orient's sample list (host side, at context creation)
+void hak_describe_plan(HakTables* t, int patsize)
+{
+    int ns = 0;
+    for (int tix = 0; tix < 208; tix++) {                           // akazed.cu:1676-1690: 13 x 16 threads, disc r2 < 36
+        const int i = (tix & 15) - 6, j = (tix >> 4) - 6, r2 = i * i + j * j;
+        if (r2 >= 36) continue;
+        t->orient_ij[ns] = (i & 0xFF) | ((j & 0xFF) << 8);
+        t->orient_gw[ns] = t->orient_w[r2];
+        ns++;
+    }
+    for (; ns < 128; ns++) { t->orient_ij[ns] = 0; t->orient_gw[ns] = 0.f; }
+
+    const int size2 = patsize;
+    const int size3 = (int)ceilf(2.0f * patsize / 3.0f);            // akazed.cu:2682
+    const int size4 = (int)ceilf(0.5f * patsize);                   // akazed.cu:2683
+    const int winsize = std::max(3 * size3, 4 * size4);
+    const int nsmp = winsize * winsize;
+    t->dsc_plan_ok = 0;
+    if (nsmp > MAX_SMP * 64 || size2 > 127 || winsize - size2 > 127) return;
+    bool ok = true;
+    for (int lane = 0; lane < 64 && ok; lane++) {
+        int rows[MAX_SMP][3];
+        for (int n = 0; n < MAX_SMP; n++) {
+            const int i = lane + 64 * n;
+            const int y = i / winsize, x = i - winsize * y;
+            const int m = std::max(x, y);
+            const bool have = i < nsmp;
+            const int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));
+            const int x4 = (x < 2 * size4 ? (x < size4 ? 0 : 1) : (x < 3 * size4 ? 2 : 3));
+            const int y4 = (y < 2 * size4 ? (y < size4 ? 0 : 1) : (y < 3 * size4 ? 2 : 3));
+            rows[n][0] = have && m < 2 * size2 ? 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)) : 0x7F;
+            rows[n][1] = have && m < 3 * size3 ? 3 * (4 + y3 * 3 + x3) : 0x7F;
+            rows[n][2] = have && m < 4 * size4 ? 39 + 3 * (y4 * 4 + x4) : 0x7F;
+            t->dsc_pos[n * 64 + lane] = have ? ((unsigned)((x - size2) & 0xFF) | ((unsigned)((y - size2) & 0xFF) << 8) | (1u << 16)) : 0u;
+        }
+        for (int n = 0; n < MAX_SMP; n++) {
+            unsigned w = 0;
+            for (int g = 0; g < 3; g++) {
+                const int r = rows[n][g];
+                const bool cont = r != 0x7F && n > 0 && rows[n - 1][g] == r;
+                const bool last = r != 0x7F && !(n + 1 < MAX_SMP && rows[n + 1][g] == r);
+                w |= ((unsigned)r | (cont ? 0x80u : 0u)) << (8 * g);
+                w |= last ? (1u << (24 + g)) : 0u;
+                if (r != 0x7F && !cont)                              // a row the lane has already left?
+                    for (int q = 0; q + 1 < n; q++) ok = ok && rows[q][g] != r;
+            }
+            t->dsc_cell[n * 64 + lane] = w;
+        }
+    }
+    t->dsc_plan_ok = ok ? 1 : 0;
 }
 
 template <typename V>
@@ -392,22 +616,40 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
     (void)FAST;
 }
 
+// Block order of k_orient / k_describe_runs: keypoint index fastest within one image (0), or the images dealt in groups of G
+// with the image index fastest inside a group (G > 0).  Measured on 256 x 1080p (describe class, ms): G = 0: 4.11, 2: 3.97,
+// 4: 3.99, 8: 4.12, 16: 4.30, 32: 4.51, 256: 5.74 -- a few images side by side spread the gathers over more L2 channels, many
+// lose the L2 / Infinity-Cache sharing between neighbouring keypoints.  hak_create sets both from HAK_DESC_ORDER /
+// HAK_DESC_PLAN (A/B runs and the alternatives test; results do not depend on either).
+int hak_desc_order = 4;
+int hak_desc_plan = 1;
+static int desc_order() { return hak_desc_order; }
+static bool use_plan(int planned) { return planned && hak_desc_plan; }
+
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
-                         hak_point* points, int max_pts, int patsize, int upright, int desc)
+                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned)
 {
-    int gx = max_pts < 4096 ? max_pts : 4096;
+    // blocks per image: k_describe_runs is fastest with one keypoint per block (2.91 ms at 4096, 3.07 at 1024: 256 x 1080p, 2181
+    // keypoints per image), the short k_orient with fewer, looping blocks (0.42 -> 0.38 ms: half of 4096 would find nothing to do)
+    const int gx = max_pts < 4096 ? max_pts : 4096, gxo = max_pts < 1024 ? max_pts : 1024;
+    const dim3 grido(gxo, b.nimg);
     dim3 grid(gx, b.nimg);
-    if (desc && !upright) k_orient<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, 1);
-    if (desc) k_describe<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
+    if (desc && !upright) k_orient<float><<<grido, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, 1, 0);
+    if (desc && use_plan(planned)) k_describe_runs<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, upright, desc_order());
+    else if (desc) k_describe<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }
 
 // FAST path: k_orient<int> always runs (it carries the sub-pixel refinement of akazed.cu:3600)
 void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, hak_point* points, int max_pts,
-                          int patsize, int upright, int desc)
+                          int patsize, int upright, int desc, int planned)
 {
-    int gx = max_pts < 4096 ? max_pts : 4096;
+    // blocks per image: k_describe_runs is fastest with one keypoint per block (2.91 ms at 4096, 3.07 at 1024: 256 x 1080p, 2181
+    // keypoints per image), the short k_orient with fewer, looping blocks (0.42 -> 0.38 ms: half of 4096 would find nothing to do)
+    const int gx = max_pts < 4096 ? max_pts : 4096, gxo = max_pts < 1024 ? max_pts : 1024;
+    const dim3 grido(gxo, b.nimg);
     dim3 grid(gx, b.nimg);
     const int* base = reinterpret_cast<const int*>(b.base);
-    k_orient<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, desc && !upright);
-    if (desc) k_describe<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
+    k_orient<int><<<grido, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, desc && !upright, 0);
+    if (desc && use_plan(planned)) k_describe_runs<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, upright, desc_order());
+    else if (desc) k_describe<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }

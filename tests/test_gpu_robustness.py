@@ -230,7 +230,9 @@ def _alt_oracle(okz, synth, ah, u8, w, h, mp):
                                  {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0", "HAK_FED_MAX_FUSE": "2"},
                                  # tile Hessian with a 4-entry candidate staging buffer: nearly every row with a candidate takes the
                                  # overflow path of the reservation (direct global slots) next to staged ones
-                                 {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "4"}, {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "1"}],
+                                 {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "4"}, {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "1"},
+                                 # MLDB: the generic kernel instead of the planned one; block orders of the keypoint kernels
+                                 {"HAK_DESC_PLAN": "0"}, {"HAK_DESC_ORDER": "0"}, {"HAK_DESC_ORDER": "3", "HAK_DESC_PLAN": "0"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_alternatives_are_bit_identical(ah, okz, torch, synth, env):
     """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
