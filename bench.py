@@ -52,7 +52,7 @@ CLASS_KERNELS = {
     "hessian": ("k_hessian_stream", "k_hessian_fused"),
     "prologue": ("k_base_stream", "k_base_a", "kf_base", "k_grad_hist_plane", "k_kcontrast2"),
     "describe": ("k_describe", "k_orient"),
-    "nms": ("k_nms_cand", "k_row_scan", "k_emit", "k_clear_cand_maps"),
+    "nms": ("k_nms_cand", "k_row_scan", "k_emit", "k_refine", "k_clear_cand_maps"),
     "match": ("k_match",),
 }
 CLASS_SOURCES = {

@@ -48,9 +48,31 @@ def table(dirs):
               f"{g('SQ_INSTS_VALU') / w:9.0f} {g('SQ_INSTS_LDS') / w:8.0f} {g('SQ_INSTS_VMEM_RD') / w:8.1f} {g('SQ_INSTS_VMEM_WR') / w:8.1f} {w:9.0f}")
 
 
+def cache_table(dirs):
+    """TCP / TCC / TA counters per kernel (tools/refresh_profiles.sh): L1 accesses, L2 requests and hit rates, the share of the
+    kernel during which the texture-address unit is held up by the L1.  GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles,
+    TA_ADDR_STALLED_BY_TC_CYCLES_sum the 256 CUs' -- hence the 32."""
+    tot, n = load(dirs)
+    avg = {k: {c: tot[k][c] / n[k][c] for c in tot[k]} for k in tot}
+    print(f"{'kernel':44s} {'disp':>4s} {'L1 acc M':>9s} {'L2 req M':>9s} {'L1 hit%':>7s} {'L2 hit%':>7s} {'L2 miss MB':>10s} {'TA stalled%':>11s} {'TLB miss k':>10s}")
+    for k, v in sorted(avg.items(), key=lambda kv: -kv[1].get("TCP_TOTAL_CACHE_ACCESSES_sum", 0)):
+        g = lambda c: v.get(c, 0.0)
+        acc, req = g("TCP_TOTAL_CACHE_ACCESSES_sum"), g("TCP_TCC_READ_REQ_sum")
+        if acc < 1e6:
+            continue
+        hit, miss = g("TCC_HIT_sum"), g("TCC_MISS_sum")
+        gui = g("GRBM_GUI_ACTIVE")
+        print(f"{k[:44]:44s} {max(n[k].values()):4d} {acc / 1e6:9.1f} {req / 1e6:9.1f} {100 * (1 - req / acc) if acc else 0:7.1f} "
+              f"{100 * hit / (hit + miss) if hit + miss else 0:7.1f} {miss * 64 / 1e6:10.0f} "
+              f"{100 * g('TA_ADDR_STALLED_BY_TC_CYCLES_sum') / 32 / gui if gui else 0:11.1f} {g('TCP_UTCL1_TRANSLATION_MISS_sum') / 1e3:10.1f}")
+
+
 def main():
     if sys.argv[1] == "--table":
         table(sys.argv[2:])
+        return
+    if sys.argv[1] == "--cache":
+        cache_table(sys.argv[2:])
         return
     d = sys.argv[1]
     filt = sys.argv[2] if len(sys.argv) > 2 else ""

@@ -22,6 +22,13 @@ timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIV
 timeout 300 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_IDX_ACTIVE SQ_BUSY_CYCLES SQ_WAVES \
     --output-format csv -d $OUT/sqB -- $P > $OUT/sqB.log 2>&1
 python3 $R/tools/pmc_summary.py --table $OUT/sqA $OUT/sqB > $OUT/sq_counters.txt 2>&1
+# cache-path counters of the gather kernels (TCP / TCC / TA): at most 4 counters of one block per pass
+timeout 150 rocprofv3 --pmc TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_PENDING_STALL_CYCLES_sum \
+    --output-format csv -d $OUT/cA -- $P > $OUT/cA.log 2>&1
+timeout 150 rocprofv3 --pmc TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_TAG_STALL_sum --output-format csv -d $OUT/cB -- $P > $OUT/cB.log 2>&1
+timeout 150 rocprofv3 --pmc TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE --output-format csv -d $OUT/cC -- $P > $OUT/cC.log 2>&1
+python3 $R/tools/pmc_summary.py --cache $OUT/cA $OUT/cB $OUT/cC > $OUT/cache_counters.txt 2>&1
+rm -rf $OUT/cA $OUT/cB $OUT/cC
 find $OUT -name "*kernel_stats.csv" | head
 tail -1 $OUT/bench.json | cut -c1-400
 cat $OUT/pmc_traffic.log | cut -c1-600
