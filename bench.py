@@ -580,7 +580,15 @@ def main():
                 "classes": classes, "other_classes_ms": round(other_ms, 4),
                 "serial_ms_per_step": round(sum(cls_ms.values()), 3),
                 "end_to_end": {"all_stage_bytes_per_image_unfused_model": round(tr.all_stage_bytes),
-                               "unfused_model_GBs": round(tr.all_stage_bytes * 2.0 * total_pairs_timed / elapsed / 1e9, 1)},
+                               "unfused_model_GBs": round(tr.all_stage_bytes * 2.0 * total_pairs_timed / elapsed / 1e9, 1),
+                               # the whole job against the roofline: counter bytes of EVERY class (PMC passes) x the images of the
+                               # timed region / its wall time -- what the pipelined run actually pulls from HBM, all ranks together
+                               **({} if len(pmc) < 6 else (lambda bpi: {
+                                   "pmc_bytes_per_image": round(bpi),
+                                   "pmc_traffic_GBs": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9, 1),
+                                   "pmc_frac_peak": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
+                                   "pmc_frac_copy": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (copy_gbs * world), 4)})(
+                                       sum(pmc.values()) / nim))},
                 "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r02_*_serial_kernel_stats.csv"}
 
     # ---- the oracle legs: verification of the timed batch, then the CPU baseline (rank 0)

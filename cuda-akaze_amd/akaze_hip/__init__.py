@@ -100,6 +100,7 @@ SYMBOLS = {
     "hak_fed_tau": (C.c_int, [C.c_float, C.c_int, C.c_float, C.c_int, _fp, C.c_int]),
     "hak_gauss_taps": (None, [C.c_float, C.c_int, _fp]),
     "hak_compare_indices": (None, [_ip, _ip]),
+    "hak_describe_plan_query": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "hak_query_schedule": (C.c_int, [_vp, _ip, _ip, _fp, _fp]),
     "hak_query_geometry": (C.c_int, [_vp, _ip]),
     "hak_debug_plane": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
@@ -173,6 +174,14 @@ def compare_indices():
     b = np.zeros(488, np.int32)
     lib.hak_compare_indices(a.ctypes.data_as(_ip), b.ctypes.data_as(_ip))
     return a, b
+
+
+def describe_plan(pattern_size):
+    """(planned, pos[7][64], cell[7][64]) of hak_describe_plan_query"""
+    pos = np.zeros((7, 64), np.uint32)
+    cell = np.zeros((7, 64), np.uint32)
+    ok = lib.hak_describe_plan_query(pattern_size, pos.ctypes.data_as(C.POINTER(C.c_uint)), cell.ctypes.data_as(C.POINTER(C.c_uint)))
+    return bool(ok), pos, cell
 
 
 # ------------------------------------------------------ reference-shaped API

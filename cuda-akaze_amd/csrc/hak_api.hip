@@ -102,6 +102,19 @@ extern "C" void hak_gauss_taps(float var, int radius, float* taps)
     for (int i = 0; i <= radius; i++) taps[i] *= ksum;
 }
 
+extern "C" int hak_describe_plan_query(int pattern_size, unsigned int* pos, unsigned int* cell)
+{
+    static HakTables t;                                     // (too large for the stack of a small thread; host-only scratch)
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lock(mu);
+    if (pattern_size < 1) return 0;
+    memset(&t, 0, sizeof(t));
+    hak_describe_plan(&t, pattern_size);
+    if (pos) memcpy(pos, t.dsc_pos, sizeof(t.dsc_pos));
+    if (cell) memcpy(cell, t.dsc_cell, sizeof(t.dsc_cell));
+    return t.dsc_plan_ok;
+}
+
 extern "C" void hak_compare_indices(int* idx1, int* idx2)
 {
     // akazed.cu:65-159: per grid (2x2 cells 0-3, 3x3 cells 4-12, 4x4 cells 13-28), channel-major, pairs j<i

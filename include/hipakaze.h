@@ -177,6 +177,13 @@ int hak_fed_tau(float T, int M, float tau_max, int reordering, float* tau, int c
 void hak_gauss_taps(float var, int radius, float* taps);
 /* akazed.cu:65-159 setCompareIndices (486 pairs, arrays of >= 488 ints) */
 void hak_compare_indices(int* idx1, int* idx2);
+/* The MLDB kernel's per-lane sample plan for one descriptor_pattern_size (akazed.cu:1905-1955 restated per (lane, turn): sample
+ * i = lane + 64 * turn of the (winsize x winsize) window, its offset from the window centre and its accumulator row in the 2x2 /
+ * 3x3 / 4x4 grid).  pos / cell: 7 * 64 words each, [turn * 64 + lane], or NULL.  pos: bits 0..7 x - size2 (signed), 8..15
+ * y - size2 (signed), bit 16 the sample exists.  cell: byte g = row of grid g (0x7F none) | 0x80 when the lane's previous sample
+ * went to the same row; bit 24 + g: the lane's last sample in that row.  Returns 1 when the planned kernel serves this size (at
+ * most 7 samples per lane and no lane returning to a row it has left), 0 when the generic kernel does. */
+int hak_describe_plan_query(int pattern_size, unsigned int* pos, unsigned int* cell);
 /* schedule the context was built with: per (octave, sublevel) the number of FED
  * steps, sigma_size, size, border; returns effective number of octaves. */
 int hak_query_schedule(const hak_ctx* ctx, int* nsteps, int* sigma_size, float* sizes, float* borders);

@@ -77,3 +77,64 @@ def test_reference_shaped_api_surface(ah):
         assert hasattr(ah.Akazer, m)
     assert (ah.PM_G1, ah.PM_G2, ah.WEICKERT, ah.CHARBONNIER) == (0, 1, 2, 3)
     assert ah.iAlignUp(1920, 128) == 1920 and ah.iAlignUp(1281, 128) == 1408
+
+
+def _mldb_rows(patsize):
+    """accumulator row of every window sample in the three grids, straight from the reference's loops (akazed.cu:1905-1955):
+    rows 0..11 = 2x2 cells, 12..38 = 3x3, 39..86 = 4x4, three rows (value, dx', dy') per cell"""
+    s2, s3, s4 = patsize, -(-2 * patsize // 3), -(-patsize // 2)
+    win = max(3 * s3, 4 * s4)
+    rows = {}
+    for i in range(win * win):
+        y, x = divmod(i, win)
+        m = max(x, y)
+        r2 = 3 * ((0 if y < s2 else 2) + (0 if x < s2 else 1)) if m < 2 * s2 else None
+        r3 = 3 * (4 + min(y // s3, 2) * 3 + min(x // s3, 2)) if m < 3 * s3 else None
+        r4 = 39 + 3 * (min(y // s4, 3) * 4 + min(x // s4, 3)) if m < 4 * s4 else None
+        rows[i] = (x - s2, y - s2, (r2, r3, r4))
+    return win, rows
+
+
+@pytest.mark.parametrize("patsize", [4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_describe_plan_restates_the_reference_loops(ah, patsize):
+    """hak_describe_plan_query (the table k_describe_runs works from; host code, no GPU): every sample lands in the lane and
+    turn the reference's `i = tx; i += 64` loop gives it, with the reference's window offset and grid rows; a lane's samples of
+    one row are consecutive turns (that is what lets the kernel carry the row's partial sum in registers); sizes without
+    that property, or with more than 7 samples per lane, report 0 and take the generic kernel"""
+    ok, pos, cell = ah.describe_plan(patsize)
+    win, rows = _mldb_rows(patsize)
+    nsmp = win * win
+    fits = nsmp <= 7 * 64
+    revisits = False
+    for lane in range(64):
+        for g in range(3):
+            seq = [rows[lane + 64 * n][2][g] if lane + 64 * n < nsmp else None for n in range(7)]
+            seen, prev = set(), None
+            for r in seq:
+                if r is not None and r != prev and r in seen:
+                    revisits = True
+                if r is not None:
+                    seen.add(r)
+                prev = r
+    assert ok == (fits and not revisits)
+    assert ok == (patsize in (4, 5, 6, 7, 9, 10))                           # the default size 10 is planned
+    if not ok:                              # (the tables are only filled in for a size the planned kernel serves)
+        return
+    for n in range(7):
+        for lane in range(64):
+            i = lane + 64 * n
+            pw, cw = int(pos[n, lane]), int(cell[n, lane])
+            if i >= nsmp:
+                assert pw == 0 and (cw & 0xFFFFFF) == 0x7F7F7F and (cw >> 24) == 0
+                continue
+            l, k, rr = rows[i]
+            assert (pw >> 16) & 1
+            sb = lambda v: v - 256 if v > 127 else v
+            assert sb(pw & 0xFF) == l and sb((pw >> 8) & 0xFF) == k
+            for g in range(3):
+                b = (cw >> (8 * g)) & 0xFF
+                assert (b & 0x7F) == (0x7F if rr[g] is None else rr[g])
+                prev = rows[i - 64][2][g] if n > 0 else None
+                nxt = rows[i + 64][2][g] if n < 6 and i + 64 < nsmp else None
+                assert bool(b & 0x80) == (rr[g] is not None and prev == rr[g])
+                assert bool((cw >> (24 + g)) & 1) == (rr[g] is not None and nxt != rr[g])
