@@ -1,5 +1,6 @@
 // hak_internal.h -- shared declarations of libhipakaze (gfx950 only).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/hipakaze.h"
@@ -260,6 +261,18 @@ static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
     if (mode != 1) return mode != 0;
     const long strips = (w + 239) / 240;
     return strips * ((h + 31) / 32) * nimg >= 2048;
+}
+// Rows per wave of the register-streaming kernels.  A block's four waves take four consecutive row segments of a strip, so the
+// number of segments is a multiple of four (no block with idle waves) and the segments are equally tall (no short last one);
+// about 256 rows each amortise the warm-up rows (NS + 4 .. 4S + 2 per segment); more, shorter segments while the grid cannot
+// fill the chip.  1080 rows: 4 x 270, 2160: 8 x 270, 540: 4 x 135, 720: 4 x 180.  Measured on 256 x 1080p (FED / Hessian class,
+// ms): 9 segments of 128 rows, the ninth 56 rows tall in a block of its own (the rule this replaces): 9.70 / 9.14; 8 x 135:
+// 9.16 / 8.32; 4 x 270: 9.08 / 8.31; 12 x 90: 9.43 / 8.49; 16 x 68: 9.63 / 8.84.
+static inline int hak_stream_rows(int h, long strips_times_images, int min_rows)
+{
+    int nseg = 4 * ((h + 512) / 1024 > 1 ? (h + 512) / 1024 : 1);
+    while (strips_times_images * nseg < 4096 && (h + 2 * nseg - 1) / (2 * nseg) >= min_rows) nseg *= 2;
+    return (h + nseg - 1) / nseg;
 }
 extern int hak_hessian_stream_enabled;
 extern int hak_desc_order, hak_desc_plan;   // describe: image group size of the block order, planned MLDB kernel (env HAK_DESC_ORDER / HAK_DESC_PLAN)

@@ -287,9 +287,7 @@ bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img
     for (int i = 0; i < 5; i++) tp.b[i] = i <= R ? taps_base[i] : V(0);
     const int gx = (w + BS_XV - 1) / BS_XV;
     // rows per wave: ~128-row segments of equal height amortise the 2R warm-up rows; shrink while the grid cannot fill the chip
-    int nseg = (h + 127) / 128;
-    while ((long)gx * nseg * nimg < 4096 && (h + nseg - 1) / nseg > 16) nseg *= 2;
-    const int ry = (h + nseg - 1) / nseg;
+    const int ry = hak_stream_rows(h, (long)gx * nimg, 16);
     const int gy = ((h + ry - 1) / ry + 3) / 4;
     const unsigned grid = hak_xcd_grid(gx, gy, nimg);
     switch (R) {

@@ -228,8 +228,7 @@ static void launch_multi(hipStream_t st, const V* src, const V* flow, V* dst, lo
     const int xv = 256 - 2 * hx;
     const int gx = (w + xv - 1) / xv;
     // rows per wave: tall strips amortise the 2*NS warm-up rows; shrink while the grid cannot fill the chip
-    int ry = 128;
-    while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    const int ry = hak_stream_rows(h, (long)gx * nimg, 8);
     const int gy = (h + 4 * ry - 1) / (4 * ry);
     k_fed_multi<V, NS><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(src, flow, dst, stride, w, h, p, fac, ry, xv, hx, gx, gy, nimg);
 }

@@ -304,8 +304,7 @@ void launch_fs(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long st
     }
     const int gx = (w + FS_XV - 1) / FS_XV;
     // rows per wave: tall segments amortise the NS+4 warm-up rows; shrink while the grid cannot fill the chip
-    int ry = 128;
-    while (ry > 8 && (long)gx * ((h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    const int ry = hak_stream_rows(h, (long)gx * nimg, 8);
     const int gy = (h + 4 * ry - 1) / (4 * ry);
     const unsigned grid = hak_xcd_grid(gx, gy, nimg);
     if (sp > 0) {

@@ -414,8 +414,7 @@ void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, in
     using G = HsGeo<S>;
     const int gx = (a.w + G::XV - 1) / G::XV;
     // rows per wave: tall segments amortise the 4S+2 warm-up rows; shrink while the grid cannot fill the chip
-    int ry = 128;
-    while (ry > 16 && (long)gx * ((a.h + ry - 1) / ry) * nimg < 4096) ry >>= 1;
+    const int ry = hak_stream_rows(a.h, (long)gx * nimg, 16);
     const int gy = (a.h + 4 * ry - 1) / (4 * ry);
     k_hessian_stream<V, S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
 }
