@@ -272,7 +272,8 @@ static inline int hak_stream_rows(int h, long strips_times_images, int min_rows)
 {
     int nseg = 4 * ((h + 512) / 1024 > 1 ? (h + 512) / 1024 : 1);
     while (strips_times_images * nseg < 4096 && (h + 2 * nseg - 1) / (2 * nseg) >= min_rows) nseg *= 2;
-    return (h + nseg - 1) / nseg;
+    const int ry = (h + nseg - 1) / nseg;
+    return ry > min_rows ? ry : min_rows;                    // (small images: fewer, not shorter, segments)
 }
 extern int hak_hessian_stream_enabled;
 extern int hak_desc_order, hak_desc_plan;   // describe: image group size of the block order, planned MLDB kernel (env HAK_DESC_ORDER / HAK_DESC_PLAN)
