@@ -11,9 +11,10 @@
 // Mapping: a 256-thread block owns 32 queries x 16 residue classes.  Thread
 // (q, c) keeps the 64-byte descriptors of two queries in 32 VGPRs and walks class c with
 // 16 x (v_xor, v_bcnt) per distance; the train descriptors are staged through LDS
-// in tiles of 256 (coalesced, once per block) and read back with broadcast
+// in tiles of 128 (coalesced, once per block, the next tile's loads in flight during the compares) and read back with broadcast
 // ds_read_b128, each read serving two distances; classes are merged through LDS.
 #include "hak_internal.h"
+#include <cstddef>
 
 #define MQ 16      // queries per block
 #define MC 16      // residue classes (X2 of akazed.cu:7)
@@ -27,20 +28,31 @@ __device__ __forceinline__ void load_desc(const hak_point* p, unsigned int d[16]
     d[15] = f[15] & 0xFFu;                      // byte 60 only; bytes 61..63 are struct padding
 }
 
-#define MT 256     // train descriptors staged per LDS tile (16 per residue class)
+#define MT 128     // train descriptors staged per LDS tile (16 per residue class)
 
 // 64-byte descriptors of train records [j0, j0 + MT) -> LDS, byte 60 masked (bytes 61..63 are struct padding).
-// Cooperative and coalesced: thread t copies dword (t & 15) of records t >> 4, (t >> 4) + 16, ...
-__device__ __forceinline__ void stage_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (*tile)[16], int tid)
+// Cooperative and coalesced: thread t copies dword (t & 15) of records t >> 4, (t >> 4) + 16, ...  In two halves -- the
+// global loads into registers, the LDS writes -- so that the loads of tile i+1 are in flight while tile i is being compared
+// (as one step between two barriers, every tile exposed a full memory round trip to all eight waves of the block).
+__device__ __forceinline__ void fetch_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (&pre)[MT / 16], int tid)
 {
     const int d = tid & 15;
-#pragma unroll 4
-    for (int r = tid >> 4; r < MT; r += 16) {
-        const int j = j0 + r;
+    // byte offsets in 32 bits from the (wave-uniform) set base: one offset VGPR per load instead of a 64-bit address each
+    // (n2 < 2^20 records of 104 bytes, checked by the launcher)
+    const unsigned off0 = (unsigned)(j0 + (tid >> 4)) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) + 4u * d;
+    const unsigned msk = d == 15 ? 0xFFu : 0xFFFFFFFFu;
+#pragma unroll
+    for (int k = 0; k < MT / 16; k++) {
+        const int j = j0 + (tid >> 4) + 16 * k;
         unsigned int v = 0;
-        if (j < n2) v = reinterpret_cast<const unsigned int*>(pts2[j].features)[d];
-        tile[r][d] = d == 15 ? (v & 0xFFu) : v;
+        if (j < n2) v = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(pts2) + (off0 + 16u * k * (unsigned)sizeof(hak_point)));
+        pre[k] = v & msk;
     }
+}
+__device__ __forceinline__ void put_train(const unsigned int (&pre)[MT / 16], unsigned int (*tile)[16], int tid)
+{
+#pragma unroll
+    for (int k = 0; k < MT / 16; k++) tile[(tid >> 4) + 16 * k][tid & 15] = pre[k];
 }
 
 // v_bcnt_u32_b32 computes popcount(x) + acc in ONE instruction; left to itself the compiler takes sixteen plain popcounts
@@ -77,7 +89,7 @@ __device__ __forceinline__ unsigned hamming_key(const unsigned int (&q)[16], con
 // distance first, then smaller index) -- and k_match_finish applies the accept rule; the chip then sees slices x query
 // blocks workgroups instead of n1 / 16.
 template <int NQ>
-__global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_point* pts2_base,
+__global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const hak_point* pts2_base,
                                                const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                int n1_host, int n2_host, long stride1, long stride2, int count_stride,
                                                unsigned* __restrict__ gkey, int tiles_per_slice)
@@ -103,10 +115,13 @@ __global__ __launch_bounds__(256) void k_match(hak_point* pts1_base, const hak_p
             if (q0 + q + MQ * a < n1) load_desc(pts1 + q0 + q + MQ * a, qd[a]);
             best[a] = 0xFFFFFFFFu;
         }
+        unsigned int pre[MT / 16];
+        if (jbeg < jend) fetch_train(pts2, jbeg, n2, pre, threadIdx.x);
         for (int j0 = jbeg; j0 < jend; j0 += MT) {
             __syncthreads();                                        // previous tile's readers are done
-            stage_train(pts2, j0, n2, tile, threadIdx.x);
+            put_train(pre, tile, threadIdx.x);
             __syncthreads();
+            if (j0 + MT < jend) fetch_train(pts2, j0 + MT, n2, pre, threadIdx.x);   // next tile: lands during the compares below
             const int jn = min(MT, n2 - j0);
             int r = c;                                              // j = j0 + r keeps the residue class: MT % MC == 0
             for (; r + MC < jn; r += 2 * MC) {
