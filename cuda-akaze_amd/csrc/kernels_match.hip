@@ -30,29 +30,29 @@ __device__ __forceinline__ void load_desc(const hak_point* p, unsigned int d[16]
 
 #define MT 128     // train descriptors staged per LDS tile (16 per residue class)
 
-// 64-byte descriptors of train records [j0, j0 + MT) -> LDS, byte 60 masked (bytes 61..63 are struct padding).
-// Cooperative and coalesced: thread t copies dword (t & 15) of records t >> 4, (t >> 4) + 16, ...  In two halves -- the
-// global loads into registers, the LDS writes -- so that the loads of tile i+1 are in flight while tile i is being compared
-// (as one step between two barriers, every tile exposed a full memory round trip to all eight waves of the block).
-__device__ __forceinline__ void fetch_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (&pre)[MT / 16], int tid)
+// Train descriptors go through LDS per WAVE: a wave owns four residue classes (c0 .. c0+3) for all of the block's queries, so
+// it stages exactly the descriptors it compares -- records j0 + c + 16 k, k < MT / 16 -- into its own 2 KB and no block barrier
+// is needed (LDS executes a wave's operations in order: the writes of tile i+1 follow the reads of tile i).  In two halves --
+// global loads into registers, LDS writes -- so that the loads of tile i+1 are in flight while tile i is compared.  Lane l
+// copies dword l & 15 of class c0 + (l >> 4); byte 60 masked (bytes 61..63 are struct padding).
+__device__ __forceinline__ void fetch_train(const hak_point* __restrict__ pts2, int j0, int n2, unsigned int (&pre)[MT / 16], int c, int d)
 {
-    const int d = tid & 15;
     // byte offsets in 32 bits from the (wave-uniform) set base: one offset VGPR per load instead of a 64-bit address each
     // (n2 < 2^20 records of 104 bytes, checked by the launcher)
-    const unsigned off0 = (unsigned)(j0 + (tid >> 4)) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) + 4u * d;
+    const unsigned off0 = (unsigned)(j0 + c) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) + 4u * d;
     const unsigned msk = d == 15 ? 0xFFu : 0xFFFFFFFFu;
 #pragma unroll
     for (int k = 0; k < MT / 16; k++) {
-        const int j = j0 + (tid >> 4) + 16 * k;
         unsigned int v = 0;
-        if (j < n2) v = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(pts2) + (off0 + 16u * k * (unsigned)sizeof(hak_point)));
+        if (j0 + c + 16 * k < n2) v = *reinterpret_cast<const unsigned int*>(reinterpret_cast<const char*>(pts2) + (off0 + 16u * k * (unsigned)sizeof(hak_point)));
         pre[k] = v & msk;
     }
 }
-__device__ __forceinline__ void put_train(const unsigned int (&pre)[MT / 16], unsigned int (*tile)[16], int tid)
+// wt: this wave's tile [MT / 16][4 classes][16 dwords]
+__device__ __forceinline__ void put_train(const unsigned int (&pre)[MT / 16], unsigned int* wt, int lane)
 {
 #pragma unroll
-    for (int k = 0; k < MT / 16; k++) tile[(tid >> 4) + 16 * k][tid & 15] = pre[k];
+    for (int k = 0; k < MT / 16; k++) wt[k * 64 + lane] = pre[k];
 }
 
 // v_bcnt_u32_b32 computes popcount(x) + acc in ONE instruction; left to itself the compiler takes sixteen plain popcounts
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 {
     constexpr int QB = MQ * NQ;                          // queries per block
     __shared__ unsigned skey[MC][QB];
-    __shared__ unsigned int tile[MT][16];               // 16 KB: every train descriptor is fetched once per block
+    __shared__ __attribute__((aligned(16))) unsigned int tile[MT * 16];   // four per-wave tiles of MT / 16 x 4 classes x 16 dwords
     const int pair = gkey ? 0 : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
@@ -105,6 +105,8 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
     const int jbeg = gkey ? (int)blockIdx.y * tiles_per_slice * MT : 0;
     const int jend = gkey ? min(n2, jbeg + tiles_per_slice * MT) : n2;
     const int q = threadIdx.x & (MQ - 1), c = threadIdx.x >> 4;     // lane = q + 16*(c%4): 4 classes per wave
+    const int lane = threadIdx.x & 63;
+    unsigned int* wt = tile + (threadIdx.x >> 6) * (MT * 4);         // this wave's tile
     for (int q0 = blockIdx.x * QB; q0 < n1; q0 += gridDim.x * QB) {
         unsigned int qd[NQ][16];
         unsigned best[NQ];
@@ -116,30 +118,29 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
             best[a] = 0xFFFFFFFFu;
         }
         unsigned int pre[MT / 16];
-        if (jbeg < jend) fetch_train(pts2, jbeg, n2, pre, threadIdx.x);
+        if (jbeg < jend) fetch_train(pts2, jbeg, n2, pre, c, lane & 15);
         for (int j0 = jbeg; j0 < jend; j0 += MT) {
-            __syncthreads();                                        // previous tile's readers are done
-            put_train(pre, tile, threadIdx.x);
-            __syncthreads();
-            if (j0 + MT < jend) fetch_train(pts2, j0 + MT, n2, pre, threadIdx.x);   // next tile: lands during the compares below
+            put_train(pre, wt, lane);
+            if (j0 + MT < jend) fetch_train(pts2, j0 + MT, n2, pre, c, lane & 15);   // next tile: lands during the compares below
             const int jn = min(MT, n2 - j0);
-            int r = c;                                              // j = j0 + r keeps the residue class: MT % MC == 0
-            for (; r + MC < jn; r += 2 * MC) {
-                const uint4* t4 = reinterpret_cast<const uint4*>(tile[r]);
-                const uint4* u4 = reinterpret_cast<const uint4*>(tile[r + MC]);
+            const unsigned int* mine = wt + (lane >> 4) * 16;       // this lane's class within the wave's tile
+            int k = 0;                                              // j = j0 + c + 16 k keeps the residue class: MT % MC == 0
+            for (; c + MC * (k + 1) < jn; k += 2) {
+                const uint4* t4 = reinterpret_cast<const uint4*>(mine + k * 64);
+                const uint4* u4 = reinterpret_cast<const uint4*>(mine + (k + 1) * 64);
                 const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];   // 16 lanes read the same 16 bytes: LDS broadcast
                 const uint4 u0 = u4[0], u1 = u4[1], u2 = u4[2], u3 = u4[3];
 #pragma unroll
                 for (int a = 0; a < NQ; a++) {
-                    best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + r)));
-                    best[a] = min(best[a], hamming_key(qd[a], u0, u1, u2, u3, (unsigned)(j0 + r + MC)));
+                    best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + c + MC * k)));
+                    best[a] = min(best[a], hamming_key(qd[a], u0, u1, u2, u3, (unsigned)(j0 + c + MC * (k + 1))));
                 }
             }
-            if (r < jn) {
-                const uint4* t4 = reinterpret_cast<const uint4*>(tile[r]);
+            if (c + MC * k < jn) {
+                const uint4* t4 = reinterpret_cast<const uint4*>(mine + k * 64);
                 const uint4 t0 = t4[0], t1 = t4[1], t2 = t4[2], t3 = t4[3];
 #pragma unroll
-                for (int a = 0; a < NQ; a++) best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + r)));
+                for (int a = 0; a < NQ; a++) best[a] = min(best[a], hamming_key(qd[a], t0, t1, t2, t3, (unsigned)(j0 + c + MC * k)));
             }
         }
         if (gkey) {                                                 // (uniform) sliced search: merge, k_match_finish decides
