@@ -297,7 +297,8 @@ class Pipeline:
 
 def fit_batch(B, w, h, max_pts, nctx, floor=16):
     # arena = 15 float planes per octave pyramid (x 4/3) + key map 8 B/px + candidate list ~ 11 B/px ~ 100 B/px per image and
-    # context (207 MB at 1080p): 128 pairs x 2 contexts = 106 GB of the 288 GB.  Batch size is a batching choice, not part of the workload.
+    # context (207 MB at 1080p): 192 pairs x 2 contexts = 159 GB of the 288 GB.  Batch size is a batching choice, not part of the workload
+    # (measured, pairs/s: 96: 5665, 128: 5654, 144: 5752, 192: 5792).
     free_b = torch.cuda.mem_get_info()[0]
     while B > floor and 2 * B * (w * h * 100 + 2 * max_pts * 104) * nctx > 0.8 * free_b:
         B //= 2
@@ -388,7 +389,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=128, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
+    ap.add_argument("--pairs", type=int, default=192, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong scaling: this many pairs per step over ALL ranks (rank r takes shard_pairs), in batches of --pairs")
     ap.add_argument("--width", type=int, default=1920)
@@ -520,9 +521,10 @@ def main():
         ah.check(ah.lib.hak_prof_reset(det.ctx))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
+        rl_pairs = min(chunks[0], 128)      # the per-class table is quoted per 256 images (profiles/) whatever the batch
         for _ in range(nprof):
-            pipe.enqueue(0, d_imgs, chunks[0])
-            pipe.download(0, chunks[0])
+            pipe.enqueue(0, d_imgs, rl_pairs)
+            pipe.download(0, rl_pairs)
         cls_ms, cls_n = {}, {}
         for name, k in ah.PROF.items():
             m2, n2 = C.c_double(), C.c_int()
@@ -531,7 +533,7 @@ def main():
         ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
         ah.check(ah.lib.hak_set_concurrency(det.ctx, 0 if args.serial else 1))
         tr = det.traffic(int(round(nkp / max(1, 2 * last_pairs))))
-        nim = 2 * chunks[0]
+        nim = 2 * rl_pairs
         gb = C.c_double()
         ah.check(ah.lib.hak_op_copy_probe(2 << 30, 10, C.byref(gb)))           # 2 GiB source + 2 GiB destination, far beyond the caches
         copy_gbs = gb.value
