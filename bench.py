@@ -521,7 +521,7 @@ def main():
         ah.check(ah.lib.hak_prof_reset(det.ctx))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
-        rl_pairs = min(chunks[0], 128)      # the per-class table is quoted per 256 images (profiles/) whatever the batch
+        rl_pairs = chunks[0]                # the per-class legs run the launch sequence of the timed region (192 pairs by default)
         for _ in range(nprof):
             pipe.enqueue(0, d_imgs, rl_pairs)
             pipe.download(0, rl_pairs)

@@ -5,7 +5,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/bench.py --pairs 128 --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-verify --no-roofline "$@" > $OUT/log.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --output-format csv -d $OUT -o t -- python3 $R/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-verify --no-roofline "$@" > $OUT/log.txt 2>&1
 python3 - $OUT <<'P'
 import csv, glob, sys
 f = glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True)[0]

@@ -48,7 +48,7 @@ def main():
         fed_launches=launches,
         fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
         fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows,
-        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "128")))
+        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "192")))
     # per kernel class (bench.py CLASS_KERNELS): bytes per launch sequence + the hash of the sources the pass ran on, so that
     # bench.py refuses the figure once a kernel of the class has changed.  FETCH_SIZE is doubled only for the classes whose
     # loads are 16 B/lane streams (the case MI355X_MICROARCH.md calibrates); 4-byte gathers (describe / orient, NMS,
