@@ -264,8 +264,9 @@ __global__ __launch_bounds__(64) void k_orient(const V* __restrict__ base, long 
 //   * the sample's window offset and its three accumulator rows come from the plan (no division, no cell arithmetic);
 //   * a lane's samples of one row are consecutive turns, so its partial sum a_t = ((0 + v) + v') + ... is carried in
 //     registers and written to the LDS table ONCE (k_describe: a read-modify-write round trip per sample and row);
-//   * two rounds that coincide with the grids -- 2x2 + 3x3 (39 rows), 4x4 (48 rows) -- instead of three of 30 rows that cut
-//     through them: every (sample, grid) is looked at once, not once per round;
+//   * three rounds of 30 rows over an 8 KB table, as in k_describe, but a round only walks the grids that can own its rows
+//     (2x2 + 3x3, 3x3 + 4x4, 4x4: five passes over the seven samples instead of nine).  Two rounds that coincide with the grids
+//     (39 + 48 rows, every (sample, grid) looked at once) need 12.8 KB: 12 instead of 16 keypoints per CU and 3 % slower;
 //   * the table is cleared with 16-byte stores in linear order.  One wave per workgroup: its LDS operations complete in
 //     program order, so the clear, the column writes and the row reads need no barrier between them, only the wait for the
 //     read data.
