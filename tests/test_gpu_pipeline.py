@@ -170,11 +170,11 @@ def test_batch_equals_single(ah, torch, synth, B):
 
 
 def test_large_batch_launch_shapes_equal_single(ah, okz, torch, synth):
-    """the benchmark's regime: a batch big enough that every streaming kernel runs its full 120-128-row segments (a single
-    image makes the launchers shrink the segments until the grid fills the chip: 8 strips x 9 segments x images >= 4096
-    needs 57 images) -- both paths, 64 x 1080p, against the oracle run live on the same two scenes (and against the
-    single-image GPU results)"""
-    w, h, mp, B = 1920, 1080, 10000, 64
+    """the benchmark's regime: a batch big enough that every streaming kernel runs its full-height row segments (hak_stream_rows:
+    four segments of 270 rows per strip at 1080p; fewer images make the launchers cut shorter segments until the grid fills the
+    chip: 8 strips x 4 segments x images >= 4096 needs 128 images) -- both paths, 128 x 1080p, against the oracle run live on
+    the same two scenes (and against the single-image GPU results)"""
+    w, h, mp, B = 1920, 1080, 10000, 128
     p = ah.iAlignUp(w, 128)
     u8s = [synth.scene(w, h, 40 + i) for i in range(2)]
     singles = [gpu_detect(ah, torch, synth, u, max_pts=mp) for u in u8s]
