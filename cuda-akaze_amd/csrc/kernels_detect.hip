@@ -100,7 +100,11 @@ __global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __re
                 for (int u = 0; u < 8; u++) {
                     const int dj = dj0 + u;
                     const bool in = dj <= isz && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
-                    rn[u] = in ? row[2 * dj] : 0u;
+                    // akazed.cu:1581-1593: the reference's read cursor is not advanced by the `continue` of the centre, so on
+                    // the centre row every dj > 0 looks at column x + dj - 1 (dj == 1 at the centre itself) while the disc test
+                    // and the tie rule keep using dj -- followed literally
+                    const int col = dj - (int)(di == 0 && dj > 0);
+                    rn[u] = in ? row[2 * col] : 0u;
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {

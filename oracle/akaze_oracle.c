@@ -406,14 +406,21 @@ int okz_nms(OkzPoint* points, int max_pts, const float* response_map, const floa
             int isz = (int)(fsz + 0.5f);
             int sqsz = (int)(fsz * fsz);
             int to_nms = 0;
-            for (int i = -isz; i <= isz && !to_nms; i++)
+            for (int i = -isz; i <= isz && !to_nms; i++) {
+                /* :1578 the read cursor restarts at column ix - isz on every row and advances at the END of the
+                 * j loop body (:1593) -- which the `continue` of the centre (:1581-1584) skips.  So on row i == 0
+                 * every j > 0 reads column ix + j - 1 (j == 1 re-reads the centre itself), while the disc test
+                 * and the tie rule still use j.  Followed literally (deviation table: Q1). */
+                int col = ix - isz;
                 for (int j = -isz; j <= isz; j++) {
-                    if (i == 0 && j == 0) continue;
-                    float rn = response_map[(size_t)(iy + i) * p + (ix + j)];
-                    if (i * i + j * j < sqsz && (rn > -1e6f &&
+                    if (i == 0 && j == 0) continue;                                            /* :1581 */
+                    float rn = response_map[(size_t)(iy + i) * p + col];
+                    if (i * i + j * j < sqsz && (rn > -1e6f &&                                 /* :1585-1586 */
                         (rn > response_map[idx] || (rn == response_map[idx] && i <= 0 && j <= 0))))
                         to_nms = 1;
+                    col++;                                                                     /* :1593 */
                 }
+            }
             if (!to_nms) {
                 if (n < max_pts) {
                     OkzPoint* pt = points + n;

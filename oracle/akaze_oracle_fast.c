@@ -289,12 +289,17 @@ static int fkz_nms(FkPoint* pts, int max_pts, const int* rmap, const float* smap
             if (lmap[idx] < 0) continue;
             float fsz = smap[idx];
             int isz = (int)(fsz + 0.5f), sqsz = (int)(fsz * fsz), to_nms = 0;
-            for (int i = -isz; i <= isz && !to_nms; i++)
+            for (int i = -isz; i <= isz && !to_nms; i++) {
+                /* :3562-3577 same cursor as the float kernel: `continue` at the centre skips `new_idx++`, so on
+                 * row i == 0 every j > 0 reads column ix + j - 1 (Q1) */
+                int col = ix - isz;
                 for (int j = -isz; j <= isz; j++) {
-                    if (i == 0 && j == 0) continue;
-                    int rn = rmap[(size_t)(iy + i) * p + (ix + j)];
+                    if (i == 0 && j == 0) continue;                                            /* :3565 */
+                    int rn = rmap[(size_t)(iy + i) * p + col];
                     if (i * i + j * j < sqsz && rn > -1000000 && (rn > rmap[idx] || (rn == rmap[idx] && i <= 0 && j <= 0))) to_nms = 1;
+                    col++;                                                                     /* :3577 */
                 }
+            }
             if (!to_nms) {
                 if (n < max_pts) {
                     FkPoint* pt = pts + n;

@@ -65,9 +65,9 @@ def _counts(text, label):
 
 def test_demo_prints_the_oracle_counts(demo_run):
     out, _ = demo_run
-    assert _counts(out, "Number of features1:") == [3544, 3733]          # float path, then FAST path
-    assert _counts(out, "Number of features2:") == [4695, 4996]
-    assert _counts(out, "Number of accepted matches:")[0] == 2400
+    assert _counts(out, "Number of features1:") == [3634, 3815]          # float path, then FAST path
+    assert _counts(out, "Number of features2:") == [4831, 5137]
+    assert _counts(out, "Number of accepted matches:")[0] == 2468
     assert "Image size = (1280,960)" in out
 
 

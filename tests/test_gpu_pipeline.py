@@ -102,7 +102,7 @@ def test_reference_images_and_match(ah, torch, synth, golden):
     m = res[0][2].h_data[:res[0][2].num_pts]
     for f in ("match", "distance", "match_x", "match_y"):
         assert np.array_equal(m[f], golden.lr["pts1"][f]), f
-    assert (m["match"] >= 0).sum() == 2400
+    assert (m["match"] >= 0).sum() == 2468
     for _, det, data in res:
         ah.freeAkazeData(data)
         det.close()
