@@ -2,7 +2,10 @@
 """bench.py -- detect + describe + match throughput of the HIP AKAZE path on MI355X.
 
 Contract (one JSON line on rank 0):
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+N > 1: one rank per GPU.  Started by torch.distributed.run (the driver's way: WORLD_SIZE is set) the process is a rank; started
+plainly (`python bench.py --gpus 8`) it launches the N ranks itself as a child process tree and relays rank 0's line and the
+exit code; it exits 2 when the node has fewer devices than ranks were asked for.
 
 Workload = BASELINE.json configs[1]: 1920x1080 grayscale pairs, 4 octaves x 4 sublevels, PM_G2, MLDB,
 max 10000 points (main.cpp:156-166).  One "step" = one pass of the hot path over one batch of
@@ -71,6 +74,29 @@ def class_source_hash(klass):
         with open(os.path.join(ROOT, "cuda-akaze_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
+
+
+def launcher_command(argv, ngpus, port):
+    """the command `bench.py --gpus N` starts when it was not itself started by a launcher: one rank per GPU of this node over
+    RCCL, rendezvous on 127.0.0.1 (the container hostname may not resolve)"""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start N ranks as a fresh child process tree and
+    relay rank 0's JSON line and the exit code.  This parent never touches a GPU (device_count() does not initialise HIP here), so
+    the children own the devices.  Fails loudly when the node has fewer devices than ranks were asked for."""
+    import subprocess
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        print(f"bench.py: {args.gpus} ranks requested, {ndev} device{'s' if ndev != 1 else ''} visible on this node", file=sys.stderr)
+        sys.exit(2)
+    port = int(os.environ.get("MASTER_PORT", "0")) or 29500 + (os.getpid() % 2000)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL across processes)
+    proc = subprocess.run(launcher_command(argv, args.gpus, port), env=env)
+    sys.exit(proc.returncode)
 
 
 def shard_pairs(total_pairs, world, rank):
@@ -408,13 +434,19 @@ def main():
     ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
+    ap.add_argument("--launch", action="store_true",
+                    help="go through the rank launcher even for --gpus 1 (N > 1 without a launcher always does)")
     args = ap.parse_args()
 
+    if (args.gpus > 1 or args.launch) and "WORLD_SIZE" not in os.environ:
+        self_launch(args, sys.argv[1:])                     # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
+        sys.exit(2)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     numa_node = pin_to_gpu_numa_node(local_rank, world)
@@ -471,20 +503,26 @@ def main():
     upload_rate = None
     if (args.upload or world > 1) and my_pairs:
         h_u8 = torch.from_numpy(np.stack([u8_pairs[(i // 2) % NDIST][i % 2] for i in range(nimg)])).pin_memory()
-        d_u8 = torch.empty_like(h_u8, device="cuda")
+        # every pipeline context ingests into its OWN image batch: with two batches in flight the other context may still be
+        # reading its images while this one's are rewritten (real frames change from step to step)
+        d_u8s = [torch.empty_like(h_u8, device="cuda") for _ in range(NCTX)]
+        d_imgs_k = [d_imgs] + [torch.empty_like(d_imgs) for _ in range(NCTX - 1)]
 
         def up(k):
-            d_u8.copy_(h_u8, non_blocking=True)
+            d_u8s[k].copy_(h_u8, non_blocking=True)
             torch.cuda.current_stream().synchronize()
-            ah.check(ah.lib.hak_ingest_u8(pipe.dets[k].ctx, d_u8.data_ptr(), h * w, w, d_imgs.data_ptr(), h * p, p, w, h, nimg))
-        pipe.run(step_jobs * 2, pre=up)
+            ah.check(ah.lib.hak_ingest_u8(pipe.dets[k].ctx, d_u8s[k].data_ptr(), h * w, w, d_imgs_k[k].data_ptr(), h * p, p, w, h, nimg))
+
+        def up_jobs(n):                                      # job i runs on context i % NCTX (Pipeline.run)
+            return [(d_imgs_k[i % NCTX], c) for i, c in enumerate(chunks * n)]
+        pipe.run(up_jobs(2), pre=up)
         fence(use_dist)
         tu = time.perf_counter()
-        pipe.run(step_jobs * args.steps, pre=up)
+        pipe.run(up_jobs(args.steps), pre=up)
         fence(use_dist)
         el_u = max_over_ranks(time.perf_counter() - tu, "cuda", use_dist)
         upload_rate = (args.total_pairs if strong else world * B) * args.steps / el_u
-        del h_u8, d_u8
+        del h_u8, d_u8s, d_imgs_k
 
     # ---- optional: the integer FAST path on the same pairs (secondary figure, never `value`)
     fast_rate = None
@@ -617,7 +655,8 @@ def main():
         total_pairs = (args.total_pairs if strong else world * B) * args.steps
         out = {
             "metric": f"pairs_per_sec_detect_describe_match_{h}p", "value": round(total_pairs / elapsed, 2),
-            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: " if (w, h, args.octaves) == (1920, 1080, 4) else "configs[3] shape: " if (w, h) == (1280, 720) else

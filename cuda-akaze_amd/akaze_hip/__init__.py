@@ -117,6 +117,13 @@ SYMBOLS = {
     "hak_op_rcp_check": (C.c_int, [C.c_uint, C.c_uint, C.POINTER(C.c_ulonglong)]),
     "hak_op_smooth_flow": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float]),
     "hak_op_hessian": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "hak_debug_set_plane": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "hak_op_tail_begin": (C.c_int, [_vp]),
+    "hak_op_tail_level": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "hak_op_tail_det_level": (C.c_int, [_vp, C.c_int, C.c_int, _vp]),
+    "hak_op_tail_seed": (C.c_int, [_vp, _vp, _vp]),
+    "hak_op_tail_finish": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, _ip]),
+    "hak_op_orient_describe": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "hak_op_copy_probe": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_double)]),
     "hak_op_gather_probe": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
@@ -275,6 +282,61 @@ class Akazer:
         out = np.zeros((whp[1], whp[0]), np.float32)
         check(lib.hak_debug_plane(self.ctx, img, kind, octave, sublevel, out.ctypes.data))
         return out
+
+    def set_plane(self, kind, octave, sublevel, plane, img=0):
+        """hak_debug_set_plane: dense (h, w) float32 -> plane (0 Lt, 2 Lx, 3 Ly) of the level"""
+        plane = np.ascontiguousarray(plane, np.float32)
+        w, h, _ = self.geometry()[octave]
+        assert plane.shape == (h, w), (plane.shape, (h, w))
+        check(lib.hak_debug_set_plane(self.ctx, img, kind, octave, sublevel, plane.ctypes.data))
+
+    # -- detector tail / descriptors on hand-made inputs (hipakaze.h hak_op_tail_*; tests/test_gpu_literal.py)
+    def tail_begin(self):
+        check(lib.hak_op_tail_begin(self.ctx))
+
+    def tail_level(self, octave, sublevel, lplane):
+        lplane = np.ascontiguousarray(lplane, np.float32)
+        check(lib.hak_op_tail_level(self.ctx, octave, sublevel, lplane.ctypes.data))
+
+    def tail_det_level(self, octave, sublevel, det):
+        det = np.ascontiguousarray(det, np.float32)
+        check(lib.hak_op_tail_det_level(self.ctx, octave, sublevel, det.ctypes.data))
+
+    def tail_seed(self, response, layer):
+        """response: (h, w) float32 (or int32 for the FAST path's map), layer: (h, w) int32, < 0 = no candidate"""
+        response = np.ascontiguousarray(response)
+        assert response.dtype.itemsize == 4
+        layer = np.ascontiguousarray(layer, np.int32)
+        check(lib.hak_op_tail_seed(self.ctx, response.ctypes.data, layer.ctypes.data))
+
+    def tail_finish(self, max_pts=1000, refine=False, fast=False):
+        """NMS + emit (+ refine) -> host records in raster order"""
+        data = AkazeData()
+        initAkazeData(data, max_pts, True, True)
+        try:
+            n = C.c_int(0)
+            check(lib.hak_op_tail_finish(self.ctx, data.d_data, max_pts, int(refine), int(fast), C.byref(n)))
+            k = min(n.value, max_pts)
+            if k:
+                check(lib.hak_memcpy_d2h(data.h_data.ctypes.data, data.d_data, k * POINT_DTYPE.itemsize))
+            return data.h_data[:k].copy(), n.value
+        finally:
+            freeAkazeData(data)
+
+    def orient_describe(self, points, desc=1):
+        """orientation + MLDB (desc=1) or MLDB with the records' own angles (desc=2) on host records; returns them updated"""
+        points = np.ascontiguousarray(points)
+        assert points.dtype == POINT_DTYPE and len(points) >= 1
+        data = AkazeData()
+        initAkazeData(data, len(points), False, True)
+        try:
+            check(lib.hak_memcpy_h2d(data.d_data, points.ctypes.data, points.nbytes))
+            check(lib.hak_op_orient_describe(self.ctx, data.d_data, len(points), int(desc)))
+            out = np.zeros(len(points), POINT_DTYPE)
+            check(lib.hak_memcpy_d2h(out.ctypes.data, data.d_data, out.nbytes))
+            return out
+        finally:
+            freeAkazeData(data)
 
     def kcontrast(self, img=0):
         v = C.c_float()

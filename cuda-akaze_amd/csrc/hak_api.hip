@@ -188,11 +188,26 @@ struct hak_ctx {
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
+    unsigned* match_keys = nullptr; // sliced 1-NN search of one big pair (hak_launch_match): grows on demand, on this context's device
+    long match_keys_cap = 0;
+    HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
+    hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
     bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
     bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
 };
 
 static inline int align_up(int a, int b) { return (a + b - 1) / b * b; }
+
+HakKnobs hak_knobs_from_env()
+{
+    HakKnobs k;
+    if (const char* e = getenv("HAK_HESS_STREAM")) k.hess_stream = atoi(e);
+    if (const char* e = getenv("HAK_BASE_STREAM")) k.base_stream = atoi(e);
+    if (const char* e = getenv("HAK_HESS_CBUF")) { const int v = atoi(e); k.hess_cbuf = v < 1 ? 1 : (v > 256 ? 256 : v); }
+    if (const char* e = getenv("HAK_DESC_ORDER")) { const int v = atoi(e); k.desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
+    if (const char* e = getenv("HAK_DESC_PLAN")) k.desc_plan = atoi(e);
+    return k;
+}
 
 struct ProfScope {
     hak_ctx* c; int k; hipEvent_t stop = nullptr; hipStream_t s;
@@ -319,11 +334,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
     if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
     if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
-    { const char* e = getenv("HAK_HESS_STREAM"); hak_hessian_stream_enabled = e ? atoi(e) : 1; }
-    { const char* e = getenv("HAK_BASE_STREAM"); hak_base_stream_enabled = e ? atoi(e) : 1; }
-    { const char* e = getenv("HAK_HESS_CBUF"); const int v = e ? atoi(e) : 256; hak_hessian_cbuf_cap = v < 1 ? 1 : (v > 256 ? 256 : v); }
-    { const char* e = getenv("HAK_DESC_ORDER"); const int v = e ? atoi(e) : 4; hak_desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
-    { const char* e = getenv("HAK_DESC_PLAN"); hak_desc_plan = e ? atoi(e) : 1; }
+    c->knobs = hak_knobs_from_env();
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
         c->max_fuse = v < 1 ? 1 : (v > HAK_FED_MAX_FUSE ? HAK_FED_MAX_FUSE : v);
@@ -350,6 +361,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     // the key map must be all zero at the start of every call; calls restore that themselves (k_clear_cand_maps)
     if (e == hipSuccess) e = hipMemset(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * B);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     for (int o = 0; o < L.noct && e == hipSuccess; o++) {
         if (o > 0) e = hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready[o], hipEventDisableTiming);
@@ -370,8 +382,9 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
 extern "C" void hak_destroy(hak_ctx* c)
 {
     if (!c) return;
-    // only the context's own streams: a caller-provided stream (hak_set_stream) may already have been destroyed by its
-    // owner; callers that used one must synchronise it themselves before destroying the context
+    // work may still be queued on a caller-provided stream (hak_set_stream), which may itself be gone by now: wait for the
+    // event recorded after the context's last enqueue instead of touching that stream
+    if (c->ev_last) { (void)hipEventSynchronize(c->ev_last); (void)hipEventDestroy(c->ev_last); }
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (int o = 0; o < HAK_MAX_OCTAVES; o++) {
@@ -381,7 +394,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt};
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt, c->match_keys};
     for (void* b : bufs) (void)hipFree(b);
     if (c->h_num) (void)hipHostFree(c->h_num);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -411,6 +424,22 @@ extern "C" int hak_sync(hak_ctx* c)
 }
 
 // ------------------------------------------------------- the launch sequence
+// The key map must be all zero when a launch sequence starts; every sequence restores that itself (k_clear_cand_maps).  If a
+// call fails between writing the map and cleaning it up, the flag stays set and the next call clears the map in full -- eagerly
+// on the context's stream and never inside a stream capture, so a replayed graph cannot miss (or needlessly carry) the clear.
+static void maps_guard_begin(hak_ctx* c)
+{
+    if (c->maps_dirty)
+        (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)c->L.oct[0].plane * c->cfg.batch, c->stream);
+    c->maps_dirty = true;
+}
+static int maps_guard_end(hak_ctx* c, int rc)
+{
+    if (!rc) c->maps_dirty = false;
+    if (c->ev_last) (void)hipEventRecord(c->ev_last, c->stream);
+    return rc;
+}
+
 static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
                           hak_point* d_points, int* d_num_pts, int desc, int max_pts)
 {
@@ -420,14 +449,12 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     hipStream_t st = main_st;
     float* A = c->arena;
     const long S = L.arena;
-    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
+    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
     c->last_fast = false;
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
 
-    hak_launch_reset_state(st, c->state, nimg);        // (the key map is all zero here: hak_create / k_clear_cand_maps)
-    if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
-    c->maps_dirty = true;
+    hak_launch_reset_state(st, c->state, nimg);        // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
 
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
@@ -444,7 +471,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
                 { ProfScope ps(c, HAK_PROF_CONTRAST, st);                          // akaze.cpp:329-332 in two passes over img
                   hak_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp /* free until the FED cycle of (0,1) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
-                                        c->taps_base, c->base_R, c->state, cfg.per, L.noct); }
+                                        c->taps_base, c->base_R, c->state, cfg.per, L.noct, c->knobs); }
                 if (c->concurrent) (void)hipEventRecord(c->ev_ready[0], st);       // Lt(0,0) + contrast factors ready
                 { ProfScope ps(c, HAK_PROF_HESSIAN, st);
                   // (the determinant goes to HBM only in the dilation > 4 fallback: `flow` is free here and at every later call)
@@ -538,7 +565,6 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
       hak_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok); }
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
-    c->maps_dirty = false;
     return 0;
 }
 
@@ -552,12 +578,10 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     hipStream_t st = c->stream;
     int* A = reinterpret_cast<int*>(c->arena);
     const long S = L.arena;
-    HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap};
+    HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
     const int idthreshold = 65;                                                   // akaze.cpp:559
     c->last_fast = true;
-    hakf_launch_reset(st, c->state, nimg);              // (the key map is all zero here: hak_create / k_clear_cand_maps)
-    if (c->maps_dirty) (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * c->cfg.batch, st);
-    c->maps_dirty = true;
+    hakf_launch_reset(st, c->state, nimg);              // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
         int* smooth = A + L.smooth_off[o];
@@ -569,7 +593,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             if (o == 0 && s == 0) {                                               // akaze.cpp:589-623
                 // one fused pass + a histogram pass over the gradient plane it leaves in det(0,0) (free until the Hessian below)
                 if (!hakf_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp, S, oc.w, oc.h, oc.p, nimg, c->itaps1,
-                                            c->itaps_base, c->base_R, c->state, cfg.per, L.noct)) {
+                                            c->itaps_base, c->base_R, c->state, cfg.per, L.noct, c->knobs)) {
                     hakf_launch_conv_u8(st, d_images, image_stride, pitch, smooth, S, oc.w, oc.h, oc.p, nimg, c->itaps1, 2);
                     hakf_launch_contrast(st, smooth, S, oc.w, oc.h, oc.p, nimg, c->state, cfg.per, L.noct);
                     hakf_launch_conv_u8(st, d_images, image_stride, pitch, Lt, S, oc.w, oc.h, oc.p, nimg, c->itaps_base, c->base_R);
@@ -628,7 +652,6 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts, 1);
     hakf_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok);
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
-    c->maps_dirty = false;
     return 0;
 }
 
@@ -638,7 +661,8 @@ extern "C" int hak_fast_detect_and_compute_batch(hak_ctx* c, const unsigned char
     if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
     if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    return enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts);
+    maps_guard_begin(c);
+    return maps_guard_end(c, enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts));
 }
 
 extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_image, int pitch, hak_point* d_points, int max_pts,
@@ -647,7 +671,8 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
     if (max_pts < 1) return fail("max_pts < 1");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    if (enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts)) return 1;
+    maps_guard_begin(c);
+    if (maps_guard_end(c, enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts))) return 1;
     HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *num_pts = c->h_num[0];
@@ -657,8 +682,16 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
 }
 
 // enqueue one detect+describe sequence: replay the captured graph when the arguments repeat, else capture it
+static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts);
 static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
                       hak_point* d_points, int* d_num_pts, int desc, int max_pts)
+{
+    maps_guard_begin(c);
+    return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts));
+}
+static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts)
 {
     if (!c->use_graph || c->prof_on)
         return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
@@ -727,14 +760,12 @@ extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point*
     if (!d_pts1 || (!d_pts2 && n2 > 0)) return fail("null argument");
     if (n1 <= 0) return 0;
     if (n2 >= (1 << 20)) return fail("more than 2^20 - 1 train points");         // k_match packs distance << 20 | index
-    // one big pair goes through a process-wide scratch buffer (sliced search, kernels_match.hip): concurrent calls of this
-    // synchronous entry point take turns (the reference's cuMatch is not re-entrant at all)
-    static std::mutex match_mutex;
-    std::lock_guard<std::mutex> guard(match_mutex);
+    // one big pair takes the sliced search (kernels_match.hip), whose scratch belongs to the context (its device) or, without
+    // one, is a stream-ordered allocation on the current device -- no process-wide buffer, no lock
     hipStream_t st = c ? c->stream : nullptr;
     if (c) {
         ProfScope ps(c, HAK_PROF_MATCH);
-        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1);
+        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, &c->match_keys, &c->match_keys_cap);
     } else {
         hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1);
     }
@@ -1134,6 +1165,121 @@ extern "C" int hak_op_hessian(const float* s, float* lx, float* ly, float* det, 
     const hipError_t e = hipDeviceSynchronize();
     (void)hipFree(dxy);
     if (e != hipSuccess) return fail(std::string("hak_op_hessian: ") + hipGetErrorString(e));
+    return 0;
+}
+
+// ---- detector tail / descriptors on hand-made inputs (include/hipakaze.h; tests/test_gpu_literal.py)
+static HakBatch tail_batch(hak_ctx* c)
+{
+    return HakBatch{c->arena, c->L.arena, 1, c->state, c->maps, c->L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
+}
+static int tail_level_ok(hak_ctx* c, int o, int s, const void* h)
+{
+    if (!c || !h) return fail("null argument");
+    if (o < 0 || o >= c->L.noct || s < 0 || s >= c->L.ms) return fail("bad level");
+    return 0;
+}
+
+extern "C" int hak_debug_set_plane(hak_ctx* c, int img, int kind, int o, int s, const float* h_src)
+{
+    if (tail_level_ok(c, o, s, h_src)) return 1;
+    if (img < 0 || img >= c->cfg.batch) return fail("bad image index");
+    const HakLayout& L = c->L;
+    const HakOct oc = L.oct[o];
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float* arena = c->arena + (long)img * L.arena;
+    if (kind == HAK_PLANE_LT) {
+        HIP_TRY(hipMemcpy2D(arena + L.lt(o, s), sizeof(float) * oc.p, h_src, sizeof(float) * oc.w, sizeof(float) * oc.w, oc.h, hipMemcpyHostToDevice));
+        return 0;
+    }
+    if (kind != HAK_PLANE_LX && kind != HAK_PLANE_LY) return fail("only the Lt, Lx and Ly planes can be set");
+    // element (y, x) of the interleaved plane = {Lx, Ly} at 2 * (y * p + x): a strided 2-D copy of single floats
+    float* dst = arena + L.dxy(o, s) + (kind == HAK_PLANE_LY ? 1 : 0);
+    for (int y = 0; y < oc.h; y++)
+        HIP_TRY(hipMemcpy2D(dst + 2L * y * oc.p, 2 * sizeof(float), h_src + (long)y * oc.w, sizeof(float), sizeof(float), oc.w, hipMemcpyHostToDevice));
+    return 0;
+}
+
+extern "C" int hak_op_tail_begin(hak_ctx* c)
+{
+    if (!c) return fail("null context");
+    c->last_fast = false;
+    maps_guard_begin(c);                                            // (stays set until hak_op_tail_finish has cleaned the map)
+    hak_launch_reset_state(c->stream, c->state, 1);
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int hak_op_tail_level(hak_ctx* c, int o, int s, const float* h_src)
+{
+    if (tail_level_ok(c, o, s, h_src)) return 1;
+    const HakLayout& L = c->L;
+    const HakOct oc = L.oct[o];
+    float* A = c->arena;
+    float* smooth = A + L.smooth_off[o];
+    HIP_TRY(hipMemcpy2D(smooth, sizeof(float) * oc.p, h_src, sizeof(float) * oc.w, sizeof(float) * oc.w, oc.h, hipMemcpyHostToDevice));
+    HakBatch b = tail_batch(c);
+    const int step = c->plan[(size_t)o * L.ms + s].sigma_size;
+    if (!hak_launch_hessian_level(c->stream, smooth, A + L.dxy(o, s), A + L.flow_off[o], false, L.arena, oc.w, oc.h, oc.p, 1, step, &b, &L,
+                                  &c->htab, o, s, c->cfg.dthreshold))
+        hak_launch_extrema_level(c->stream, b, L, c->dtab, o, s, c->cfg.dthreshold, L.flow_off[o]);
+    if (hipGetLastError() != hipSuccess) return fail("tail level launch failed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int hak_op_tail_det_level(hak_ctx* c, int o, int s, const float* h_det)
+{
+    if (tail_level_ok(c, o, s, h_det)) return 1;
+    const HakLayout& L = c->L;
+    const HakOct oc = L.oct[o];
+    HIP_TRY(hipMemcpy2D(c->arena + L.flow_off[o], sizeof(float) * oc.p, h_det, sizeof(float) * oc.w, sizeof(float) * oc.w, oc.h,
+                        hipMemcpyHostToDevice));
+    hak_launch_extrema_level(c->stream, tail_batch(c), L, c->dtab, o, s, c->cfg.dthreshold, L.flow_off[o]);
+    if (hipGetLastError() != hipSuccess) return fail("extrema launch failed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int hak_op_tail_seed(hak_ctx* c, const unsigned int* h_resp_bits, const int* h_layer)
+{
+    if (!c || !h_resp_bits || !h_layer) return fail("null argument");
+    const size_t n = (size_t)c->L.oct[0].w * c->L.oct[0].h;
+    unsigned* d_r = nullptr;
+    int* d_l = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_r, sizeof(unsigned) * n));
+    int rc = 0;
+    if (hipMalloc((void**)&d_l, sizeof(int) * n) != hipSuccess) rc = fail("seed scratch");
+    if (!rc && (hipMemcpy(d_r, h_resp_bits, sizeof(unsigned) * n, hipMemcpyHostToDevice) != hipSuccess ||
+                hipMemcpy(d_l, h_layer, sizeof(int) * n, hipMemcpyHostToDevice) != hipSuccess)) rc = fail("seed upload");
+    if (!rc) {
+        hak_launch_seed_maps(c->stream, tail_batch(c), c->L, d_r, d_l);
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("seed kernel");
+    }
+    (void)hipFree(d_r); (void)hipFree(d_l);
+    return rc;
+}
+
+extern "C" int hak_op_tail_finish(hak_ctx* c, hak_point* d_points, int max_pts, int refine, int fast, int* num_pts)
+{
+    if (!c || !d_points || !num_pts || max_pts < 1) return fail("bad argument");
+    hak_launch_nms_emit(c->stream, tail_batch(c), c->L, c->dtab, c->psz, d_points, max_pts, c->d_num, fast ? 1 : 0, refine ? 1 : 0);
+    int rc = hipGetLastError() != hipSuccess ? fail("tail finish launch failed") : 0;
+    if (!rc && hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail("count download");
+    if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("sync");
+    if (!rc) *num_pts = c->h_num[0];
+    return maps_guard_end(c, rc);
+}
+
+extern "C" int hak_op_orient_describe(hak_ctx* c, hak_point* d_points, int n, int desc)
+{
+    if (!c || !d_points || n < 1) return fail("bad argument");
+    HIP_TRY(hipMemcpy(&c->state[0].num_pts, &n, sizeof(int), hipMemcpyHostToDevice));
+    // desc == 2: the MLDB kernel alone, rotated by the angles the records already hold
+    hak_launch_describe(c->stream, tail_batch(c), c->L, c->dtab, d_points, n, c->cfg.descriptor_pattern_size, c->cfg.upright, desc ? 1 : 0,
+                        c->htab.dsc_plan_ok, desc == 2 ? 0 : 1);
+    if (hipGetLastError() != hipSuccess) return fail("describe launch failed");
+    HIP_TRY(hipStreamSynchronize(c->stream));
     return 0;
 }
 

@@ -227,6 +227,17 @@ __host__ __device__ __forceinline__ float hak_expf(float x)
 // ---------------------------------------------------------------- launchers
 // (defined in the kernel files; all asynchronous on `st`; nimg = batch images,
 //  base = arena of image 0, stride = floats between image arenas)
+// Kernel-selection knobs of one context (hak_create reads them from the environment once; tests and A/B runs set them
+// there).  They never change results, only which of two bit-identical kernels runs.
+struct HakKnobs {
+    int hess_stream = 1;          // HAK_HESS_STREAM: register-streaming Hessian kernel 0 never / 1 by the size rule / 2 always where it applies
+    int base_stream = 1;          // HAK_BASE_STREAM: same for pass A of the octave-0 prologue
+    int hess_cbuf = 256;          // HAK_HESS_CBUF: staged candidates per block of the tile kernel (1..256; tests drive the overflow path)
+    int desc_order = 4;           // HAK_DESC_ORDER: image group size of the describe kernels' block order
+    int desc_plan = 1;            // HAK_DESC_PLAN: planned MLDB kernel (k_describe_runs) on / off
+};
+HakKnobs hak_knobs_from_env();    // defaults overridden by the HAK_* variables (hak_api.hip)
+
 struct HakBatch {
     float* base;                  // arena of image 0
     long stride;                  // floats between consecutive image arenas
@@ -238,6 +249,7 @@ struct HakBatch {
     int* rowcount;                // [nimg][h0]
     unsigned long long* cand;     // [nimg][cand_cap] extrema candidates: layer<<32 | y<<16 | x (full-res)
     long cand_cap;
+    const HakKnobs* knobs = nullptr;   // the owning context's; nullptr (stage operators): hak_knobs_from_env()
 };
 
 // scale space (kernels_scalespace.hip)
@@ -275,9 +287,6 @@ static inline int hak_stream_rows(int h, long strips_times_images, int min_rows)
     const int ry = (h + nseg - 1) / nseg;
     return ry > min_rows ? ry : min_rows;                    // (small images: fewer, not shorter, segments)
 }
-extern int hak_hessian_stream_enabled;
-extern int hak_desc_order, hak_desc_plan;   // describe: image group size of the block order, planned MLDB kernel (env HAK_DESC_ORDER / HAK_DESC_PLAN)
-extern int hak_hessian_cbuf_cap;       // tile kernel: staged candidates per block (env HAK_HESS_CBUF, tests only)
 // dxy: interleaved {Lx, Ly} plane (2 * h * p elements).  det: where the determinant goes -- the fused kernels write it only
 // when store_det is set (stage tests); the launch sequence passes a scratch plane that only the dilation > 4 fallback fills.
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
@@ -294,14 +303,13 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, floa
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
 // register-streaming pass A of the octave-0 prologue (kernels_base_stream.hip); false: not covered / does not pay
-extern int hak_base_stream_enabled;
 bool hak_launch_base_stream(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad, long stride, int w, int h,
-                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state);
+                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state, int mode);
 bool hakf_launch_base_stream(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad, long stride, int w,
-                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state);
+                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state, int mode);
 bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad_scratch, long stride,
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
-                           HakImgState* state, float per, int noct);
+                           HakImgState* state, float per, int noct, const HakKnobs& knobs);
 // sigma=1 low-pass + conductivity fused (kernels_smoothflow.hip)
 void hakf_launch_smooth_flow(hipStream_t st, const int* src, int* smooth, int* flow, long stride,
                              int w, int h, int p, int nimg, const int* itaps, int diffusivity,
@@ -313,7 +321,7 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
 #define HAK_FED_MAX_FUSE 4
 bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,
                             int w, int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state,
-                            float per, int noct);
+                            float per, int noct, const HakKnobs& knobs);
 int hak_launch_rcp_check(unsigned lo, unsigned hi, unsigned long long* d_bad);
 bool hak_launch_fed_sf_head(hipStream_t st, const float* src, HakOct so, float* smooth, float* flow, float* dst, long stride,
                             HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
@@ -350,7 +358,8 @@ void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout
 void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d_num, long max_pts, int nimg, hak_point* h_points,
                          int* h_num);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
-                         hak_point* points, int max_pts, int* num_out, int fast = 0);
+                         hak_point* points, int max_pts, int* num_out, int fast = 0, int refine = 1);
+void hak_launch_seed_maps(hipStream_t st, const HakBatch& b, const HakLayout& L, const unsigned* d_resp_bits, const int* d_layer);
 
 // integer FAST path (kernels_fast.hip); planes are int32 in the same arena layout
 void hakf_launch_reset(hipStream_t st, HakImgState* state, int nimg);
@@ -372,8 +381,9 @@ void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L,
                           int patsize, int upright, int desc, int planned);
 
 // descriptors (kernels_describe.hip)
+// orient = 0 (stage tests): skip k_orient and describe with the angles the records hold
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
-                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned);
+                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned, int orient = 1);
 
 // bandwidth probes (kernels_probe.hip)
 int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy);
@@ -381,7 +391,8 @@ int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, dou
 
 // matcher (kernels_match.hip)
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
-                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs);
+                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs,
+                      unsigned** scratch = nullptr, long* cap = nullptr);
 void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
                      int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride);
 void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,

@@ -276,7 +276,7 @@ __global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
 // that the histogram pass reads 4 B/px instead of recomputing sigma=1 + Scharr from the image.
 bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad_scratch, long stride,
                            int w, int h, int p, int nimg, const float* taps1, const float* taps_base, int R,
-                           HakImgState* state, float per, int noct)
+                           HakImgState* state, float per, int noct, const HakKnobs& knobs)
 {
     if (R < 2 || R > 5) return false;
     BsTaps t;
@@ -287,7 +287,7 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
     const unsigned grid = hak_xcd_grid(ntx, nby, nimg);
-    if (hak_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, taps1, taps_base, R, state)) {
+    if (hak_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, taps1, taps_base, R, state, knobs.base_stream)) {
         // pass A done by the streaming kernel
     } else
     switch (R) {

@@ -16,7 +16,6 @@
 // stage then indexes plainly.  w % 4 == 0, R <= 4 (a deeper halo than one lane needs the tile kernel).
 #include "fed_common.h"
 
-int hak_base_stream_enabled = 1;        // HAK_BASE_STREAM: 0 never, 1 by the size rule, 2 always where the kernel applies
 
 namespace {
 
@@ -274,13 +273,13 @@ __global__ __launch_bounds__(256) void k_base_stream(const typename BsT<V>::In* 
 
 template <typename V>
 bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img_stride, int sp, V* lt, V* grad, long stride, int w, int h,
-                        int p, int nimg, const V* taps1, const V* taps_base, int R, HakImgState* state)
+                        int p, int nimg, const V* taps1, const V* taps_base, int R, HakImgState* state, int mode)
 {
     using In = typename BsT<V>::In;
     constexpr long LA = 4;                                  // elements per aligned lane load: 4 floats / 4 bytes
     if (!grad || R < 2 || R > 4 || (w & 3) || w < 16 || h < 16) return false;
     if ((sp % LA) || (img_stride % LA) || (reinterpret_cast<uintptr_t>(img) % (LA * sizeof(In)))) return false;
-    if (!hak_stream_pays(hak_base_stream_enabled, w, h, nimg)) return false;
+    if (!hak_stream_pays(mode, w, h, nimg)) return false;
     if ((lt < grad ? grad - lt : lt - grad) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;   // plane offset + plane size < marker
     BsmTaps<V> tp;
     tp.a = SfTaps<V>{taps1[0], taps1[1], taps1[2]};
@@ -301,12 +300,12 @@ bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img
 } // namespace
 
 bool hak_launch_base_stream(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad, long stride, int w, int h,
-                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state)
+                            int p, int nimg, const float* taps1, const float* taps_base, int R, HakImgState* state, int mode)
 {
-    return launch_base_stream<float>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, taps1, taps_base, R, state);
+    return launch_base_stream<float>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, taps1, taps_base, R, state, mode);
 }
 bool hakf_launch_base_stream(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad, long stride, int w,
-                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state)
+                             int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state, int mode)
 {
-    return launch_base_stream<int>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, itaps1, itaps_base, R, state);
+    return launch_base_stream<int>(st, img, img_stride, sp, lt, grad, stride, w, h, p, nimg, itaps1, itaps_base, R, state, mode);
 }

@@ -620,23 +620,22 @@ __global__ __launch_bounds__(64) void k_describe(const V* __restrict__ base, lon
 // Block order of k_orient / k_describe_runs: keypoint index fastest within one image (0), or the images dealt in groups of G
 // with the image index fastest inside a group (G > 0).  Measured on 256 x 1080p (describe class, ms): G = 0: 4.11, 2: 3.97,
 // 4: 3.99, 8: 4.12, 16: 4.30, 32: 4.51, 256: 5.74 -- a few images side by side spread the gathers over more L2 channels, many
-// lose the L2 / Infinity-Cache sharing between neighbouring keypoints.  hak_create sets both from HAK_DESC_ORDER /
+// lose the L2 / Infinity-Cache sharing between neighbouring keypoints.  HakKnobs::desc_order / desc_plan, from HAK_DESC_ORDER /
 // HAK_DESC_PLAN (A/B runs and the alternatives test; results do not depend on either).
-int hak_desc_order = 4;
-int hak_desc_plan = 1;
-static int desc_order() { return hak_desc_order; }
-static bool use_plan(int planned) { return planned && hak_desc_plan; }
+static HakKnobs knobs_of(const HakBatch& b) { return b.knobs ? *b.knobs : hak_knobs_from_env(); }
 
 void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab,
-                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned)
+                         hak_point* points, int max_pts, int patsize, int upright, int desc, int planned, int orient)
 {
     // blocks per image: k_describe_runs is fastest with one keypoint per block (2.91 ms at 4096, 3.07 at 1024: 256 x 1080p, 2181
     // keypoints per image), the short k_orient with fewer, looping blocks (0.42 -> 0.38 ms: half of 4096 would find nothing to do)
     const int gx = max_pts < 4096 ? max_pts : 4096, gxo = max_pts < 1024 ? max_pts : 1024;
     const dim3 grido(gxo, b.nimg);
     dim3 grid(gx, b.nimg);
-    if (desc && !upright) k_orient<float><<<grido, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, 1, 0);
-    if (desc && use_plan(planned)) k_describe_runs<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, upright, desc_order());
+    const HakKnobs kn = knobs_of(b);
+    const int order = kn.desc_order < 0 ? 0 : (kn.desc_order > 255 ? 255 : kn.desc_order);
+    if (desc && !upright && orient) k_orient<float><<<grido, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, 1, 0);
+    if (desc && (planned && kn.desc_plan)) k_describe_runs<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, upright, order);
     else if (desc) k_describe<float><<<grid, 64, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }
 
@@ -649,8 +648,10 @@ void hakf_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L,
     const int gx = max_pts < 4096 ? max_pts : 4096, gxo = max_pts < 1024 ? max_pts : 1024;
     const dim3 grido(gxo, b.nimg);
     dim3 grid(gx, b.nimg);
+    const HakKnobs kn = knobs_of(b);
+    const int order = kn.desc_order < 0 ? 0 : (kn.desc_order > 255 ? 255 : kn.desc_order);
     const int* base = reinterpret_cast<const int*>(b.base);
     k_orient<int><<<grido, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, desc && !upright, 0);
-    if (desc && use_plan(planned)) k_describe_runs<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, upright, desc_order());
+    if (desc && (planned && kn.desc_plan)) k_describe_runs<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, upright, order);
     else if (desc) k_describe<int><<<grid, 64, 0, st>>>(base, b.stride, L, tab, b.state, points, max_pts, patsize, upright, desc);
 }

@@ -276,8 +276,28 @@ __global__ __launch_bounds__(256) void k_clear_cand_maps(unsigned long long* __r
     }
 }
 
+// hand-made full-resolution maps -> key map + candidate list, with the extrema kernels' own key and list format
+// (hak_op_tail_seed: the NMS micro-fixtures)
+__global__ __launch_bounds__(256) void k_seed_maps(const unsigned* __restrict__ resp_bits, const int* __restrict__ layer, int w, int h, int p,
+                                                   unsigned long long* map, unsigned long long* cand, long cand_cap, HakImgState* state)
+{
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const int l = layer[(long)y * w + x];
+    if (l < 0) return;
+    atomicMax(&map[(long)y * p + x], ((unsigned long long)resp_bits[(long)y * w + x] << 32) | (0xFFFFFFFFu - (unsigned)l));
+    const long slot = atomicAdd(&state->ncand, 1);
+    if (slot < cand_cap) cand[slot] = ((unsigned long long)l << 32) | ((unsigned)y << 16) | (unsigned)x;
+}
+
+void hak_launch_seed_maps(hipStream_t st, const HakBatch& b, const HakLayout& L, const unsigned* d_resp_bits, const int* d_layer)
+{
+    const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
+    k_seed_maps<<<dim3((w + 63) / 64, (h + 3) / 4), 256, 0, st>>>(d_resp_bits, d_layer, w, h, p, b.maps, b.cand, b.cand_cap, b.state);
+}
+
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
-                         hak_point* points, int max_pts, int* num_out, int fast)
+                         hak_point* points, int max_pts, int* num_out, int fast, int refine)
 {
     const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
     const int words = (w + 63) / 64;
@@ -289,7 +309,7 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
     dim3 g3((h + 3) / 4, 1, b.nimg);
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
-    if (!fast)                                                      // (the FAST path refines on its int planes: k_orient<int>)
+    if (!fast && refine)                                            // (the FAST path refines on its int planes: k_orient<int>)
         k_refine<<<dim3((max_pts + 15) / 16, b.nimg), 256, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts);
     k_clear_cand_maps<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, p);
 }

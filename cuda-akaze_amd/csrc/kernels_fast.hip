@@ -299,14 +299,14 @@ __global__ __launch_bounds__(256) void kf_grad_hist_plane(const int* __restrict_
 // (caller: hakf_launch_conv_u8 x2 + hakf_launch_contrast)
 bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,
                             int w, int h, int p, int nimg, const int* itaps1, const int* itaps_base, int R, HakImgState* state,
-                            float per, int noct)
+                            float per, int noct, const HakKnobs& knobs)
 {
     if (R < 2 || R > 5) return false;
     FkTaps t1, tb;
     for (int i = 0; i < 8; i++) { t1.k[i] = i <= 2 ? itaps1[i] : 0; tb.k[i] = i <= R ? itaps_base[i] : 0; }
     const int nbx = (w + FB_TX - 1) / FB_TX, nby = (h + FB_TY - 1) / FB_TY;
     const unsigned grid = hak_xcd_grid(nbx, nby, nimg);
-    if (hakf_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, itaps1, itaps_base, R, state)) {
+    if (hakf_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, itaps1, itaps_base, R, state, knobs.base_stream)) {
         // pass A done by the streaming kernel
     } else
     switch (R) {

@@ -330,15 +330,13 @@ __global__ __launch_bounds__(64 * HF_NW) void k_hessian_fused(const V* __restric
 
 static void deriv_factors(float& fac1, float& fac2) { hak_deriv_factors(&fac1, &fac2); }
 
-// process-wide mode (0 never / 1 by size / 2 always), refreshed from HAK_HESS_STREAM by every hak_create
-int hak_hessian_stream_enabled = 1;
-// staged candidates per block actually used (1..HF_CBUF); HAK_HESS_CBUF shrinks it so that the tests can drive the
-// overflow path of the staging buffer with ordinary images
-int hak_hessian_cbuf_cap = HF_CBUF;
+// HakKnobs::hess_stream: 0 never / 1 by size / 2 always.  HakKnobs::hess_cbuf: staged candidates per block actually used
+// (1..HF_CBUF); HAK_HESS_CBUF shrinks it so that the tests can drive the overflow path of the staging buffer with ordinary images.
+static HakKnobs knobs_of(const HakBatch* b) { return (b && b->knobs) ? *b->knobs : hak_knobs_from_env(); }
 
 template <typename V, int S>
 static void launch_fused(hipStream_t st, const V* src, V* dxy, V* det, long stride,
-                         int w, int h, int p, int nimg, const HakExtremaArgs<V>& ex)
+                         int w, int h, int p, int nimg, const HakExtremaArgs<V>& ex, int cbuf_cap)
 {
     float f1, f2;
     deriv_factors(f1, f2);
@@ -350,7 +348,7 @@ static void launch_fused(hipStream_t st, const V* src, V* dxy, V* det, long stri
     int tpb = 8;
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
-    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, dxy, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex, hak_hessian_cbuf_cap);
+    k_hessian_fused<V, S><<<hak_xcd_grid(ntx, nby, nimg), 64 * HF_NW, 0, st>>>(src, dxy, det, stride, w, h, p, v1, v2, tpb, ntx, nby, nimg, ex, cbuf_cap < 1 ? 1 : (cbuf_cap > HF_CBUF ? HF_CBUF : cbuf_cap));
 }
 
 template <typename V>
@@ -375,7 +373,8 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, floa
                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
 {
     // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
-    if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
+    const HakKnobs kn = knobs_of(b);
+    if (hak_stream_pays(kn.hess_stream, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
         if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
@@ -384,10 +383,10 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, floa
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     float* od = store_det ? det : nullptr;
     switch (step) {
-    case 1: launch_fused<float, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 2: launch_fused<float, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 3: launch_fused<float, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 4: launch_fused<float, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 1: launch_fused<float, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 2: launch_fused<float, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 3: launch_fused<float, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 4: launch_fused<float, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
     default: break;
     }
     hak_launch_derivate(st, src, dxy, stride, w, h, p, nimg, step);        // dilation > 4: two direct passes
@@ -401,7 +400,8 @@ bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* de
                                int w, int h, int p, int nimg, int step,
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
-    if (hak_stream_pays(hak_hessian_stream_enabled, w, h, nimg)) {
+    const HakKnobs kn = knobs_of(b);
+    if (hak_stream_pays(kn.hess_stream, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
         if (hakf_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, (int)(f1 * 65536 + 0.5f),
@@ -411,10 +411,10 @@ bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* de
     const HakExtremaArgs<int> ex = extrema_args<int>(b, L, htab, octave, sub, idthreshold);
     int* od = store_det ? det : nullptr;
     switch (step) {
-    case 1: launch_fused<int, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 2: launch_fused<int, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 3: launch_fused<int, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
-    case 4: launch_fused<int, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex); return true;
+    case 1: launch_fused<int, 1>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 2: launch_fused<int, 2>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 3: launch_fused<int, 3>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
+    case 4: launch_fused<int, 4>(st, src, dxy, od, stride, w, h, p, nimg, ex, kn.hess_cbuf); return true;
     default: return false;
     }
 }

@@ -342,13 +342,12 @@ void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pt
                                            ratio_den, cross, max_dist, out, out_stride, out_count, 1);
 }
 
-// scratch of the sliced search (one big pair through hak_match, whose context may be NULL): one process-wide buffer per
-// call site is enough -- hak_match is synchronous -- and it only ever grows
-static unsigned* g_match_keys = nullptr;
-static long g_match_keys_cap = 0;
-
+// Scratch of the sliced search (one big pair through hak_match): owned by the calling context (`scratch` / `cap` point at its
+// members; the buffer lives on the context's device and only ever grows).  Without a context (cuMatch is a free function in
+// the reference, so hak_match accepts ctx == NULL) the buffer is a stream-ordered allocation on the device that is current
+// for this call, released after the finish kernel -- never a process-wide pointer that could belong to another device.
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
-                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs)
+                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, unsigned** scratch, long* cap)
 {
     // two queries per thread halve the LDS traffic per distance but also the number of blocks: only when the grid still
     // covers the chip a few times (batched pairs); one big pair (10k x 10k) keeps one query per thread
@@ -366,18 +365,28 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
         const int tps = (tiles + slices - 1) / slices;
         slices = (tiles + tps - 1) / tps;
         const long need = (long)n1_host * MC;
-        bool ok = true;
-        if (need > g_match_keys_cap) {
-            if (g_match_keys) (void)hipFree(g_match_keys);
-            g_match_keys = nullptr; g_match_keys_cap = 0;
-            ok = hipMalloc((void**)&g_match_keys, sizeof(unsigned) * (size_t)need) == hipSuccess;
-            if (ok) g_match_keys_cap = need;
-        }
-        if (ok && slices > 1) {
-            (void)hipMemsetAsync(g_match_keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
-            k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, g_match_keys, tps);
-            k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, g_match_keys);
-            return;
+        if (slices > 1) {
+            unsigned* keys = nullptr;
+            bool transient = false;
+            if (scratch && cap) {
+                if (need > *cap) {                                  // (earlier launches that used the old buffer are ahead of us on `st`)
+                    if (*scratch) { (void)hipStreamSynchronize(st); (void)hipFree(*scratch); }
+                    *scratch = nullptr; *cap = 0;
+                    if (hipMalloc((void**)scratch, sizeof(unsigned) * (size_t)need) == hipSuccess) *cap = need;
+                    else (void)hipGetLastError();
+                }
+                keys = *scratch;
+            } else {
+                transient = hipMallocAsync((void**)&keys, sizeof(unsigned) * (size_t)need, st) == hipSuccess;
+                if (!transient) { keys = nullptr; (void)hipGetLastError(); }
+            }
+            if (keys) {
+                (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
+                k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
+                k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, keys);
+                if (transient) (void)hipFreeAsync(keys, st);
+                return;
+            }
         }
     }
     dim3 grid(gx, npairs);

@@ -239,6 +239,27 @@ int hak_op_smooth_flow(const float* d_src, float* d_smooth, float* d_flow, int w
                        int diffusivity, float kcontrast);                                               /* hLowPass(var 1) + hFlow, akaze.cpp:403-404 */
 int hak_op_hessian(const float* d_src, float* d_lx, float* d_ly, float* d_det, int w, int h, int p, int step); /* hHessianDeterminant 2531 */
 
+/* ---- detector-tail and descriptor stages on hand-made inputs (tests/test_gpu_literal.py: micro-fixtures whose expected
+ * output is derived by hand from the cited reference statements).  They drive the SAME launchers as the launch sequence, on
+ * image 0 of the context, and synchronise before returning.  A sequence is begin -> {level | det_level | seed}* -> finish.
+ *   hak_debug_set_plane   write plane (HAK_PLANE_LT / LX / LY) of (octave, sublevel) from a dense w x h host array
+ *   hak_op_tail_begin     reset the per-image state (candidate list, counters); the key map is already clear
+ *   hak_op_tail_level     hHessianDeterminant 2531 + gCalcExtremaMap 1334 of one level from a dense host L-plane, through the
+ *                         fused kernel the context would pick (knobs as in hak_create), threshold = cfg.dthreshold
+ *   hak_op_tail_det_level gCalcExtremaMap 1334 alone (the stand-alone kernel of the dilation > 4 fallback) on a dense host
+ *                         determinant plane
+ *   hak_op_tail_seed      hand-made full-resolution maps: response words (float or int bits) and layer ids (< 0: empty)
+ *   hak_op_tail_finish    gNmsRNaive 1554 (+ gRefine 1615 when `refine`) -> d_points in raster order; *num_pts = survivors
+ *   hak_op_orient_describe gCalcOrient 1665 + gDescribe2 1869 on the first n records of d_points, reading the planes the
+ *                         arena holds now (desc: 0 none, 1 both, 2 descriptor only with the records' own angles) */
+int hak_debug_set_plane(hak_ctx* ctx, int img, int kind, int octave, int sublevel, const float* h_src);
+int hak_op_tail_begin(hak_ctx* ctx);
+int hak_op_tail_level(hak_ctx* ctx, int octave, int sublevel, const float* h_src);
+int hak_op_tail_det_level(hak_ctx* ctx, int octave, int sublevel, const float* h_det);
+int hak_op_tail_seed(hak_ctx* ctx, const unsigned int* h_response_bits, const int* h_layer);
+int hak_op_tail_finish(hak_ctx* ctx, hak_point* d_points, int max_pts, int refine, int fast, int* num_pts);
+int hak_op_orient_describe(hak_ctx* ctx, hak_point* d_points, int n, int desc);
+
 /* ---- bandwidth ceilings of the box (SURVEY 8d "copy-kernel ceiling"; not on the hot path).
  * hak_op_copy_probe: float4 copy of `bytes` with the streaming kernels' access shape (16 B/lane, nt stores), `iters`
  * times; *gbytes_per_s = (read + write bytes) / average kernel time.

@@ -3,7 +3,8 @@
  * (Akazer::fastDetectAndCompute, namespace fastakaze): the float pipeline in int32 with 16.16
  * fixed-point weights, uint8 input in [0,255].
  *
- * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  Each function cites the reference file:line it
+ * TEST INFRASTRUCTURE ONLY (see oracle/README.md).  The stage functions are exported so that the literal micro-fixture
+ * tests (tests/test_reference_literal_cpu.py) can drive them one by one.  Each function cites the reference file:line it
  * follows.  Same deterministic choices D2-D10 as akaze_oracle.c; additionally:
  *   F1  32-bit products wrap (two's complement) exactly as the device's v_mul_lo_u32 does; the
  *       reference's `int * int` can overflow for large tau (stepfac * step, akazed.cu:3465).
@@ -256,7 +257,7 @@ void fkz_hessian(const int* src, int* dxo, int* dyo, int* det, int step, int w, 
 }
 
 /* akazed.cu:3476-3515 gCalcExtremaMap (int), sublevels ascending (D5) */
-static void fkz_extrema(const int* dets, int* rmap, float* smap, int* lmap, const float* params, int octave,
+void fkz_extrema(const int* dets, int* rmap, float* smap, int* lmap, const float* params, int octave,
                         int ms, int threshold, int w, int h, int p, int opitch)
 {
     int psz = (int)params[0];
@@ -280,7 +281,7 @@ static void fkz_extrema(const int* dets, int* rmap, float* smap, int* lmap, cons
 }
 
 /* akazed.cu:3538-3598 gNmsRNaive (int), raster order (D6), response filled (D8) */
-static int fkz_nms(FkPoint* pts, int max_pts, const int* rmap, const float* smap, const int* lmap, int psz, int w, int h, int p)
+int fkz_nms(FkPoint* pts, int max_pts, const int* rmap, const float* smap, const int* lmap, int psz, int w, int h, int p)
 {
     int n = 0;
     for (int iy = psz; iy + psz < h; iy++)
@@ -313,7 +314,7 @@ static int fkz_nms(FkPoint* pts, int max_pts, const int* rmap, const float* smap
 }
 
 /* akazed.cu:3600-3646 gRefine (int det, float offsets) */
-static void fkz_refine(FkPoint* pt, const int* det, int o, int p)
+void fkz_refine(FkPoint* pt, const int* det, int o, int p)
 {
     int y = (int)pt->y >> o, x = (int)pt->x >> o;
     size_t idx = (size_t)y * p + x;
@@ -347,7 +348,7 @@ static inline float fast_atan2(float y, float x)                       /* akazed
 }
 
 /* akazed.cu:3649-3718 gCalcOrient (int planes; per-sample angle by dFastAtan2) */
-static void fkz_orient(FkPoint* pt, const int* dxd, const int* dyd, int o, int w, int h, int p, const float* wtab)
+void fkz_orient(FkPoint* pt, const int* dxd, const int* dyd, int o, int w, int h, int p, const float* wtab)
 {
     float resx[42], resy[42], re8x[42], re8y[42];
     for (int t = 0; t < 42; t++) { resx[t] = 0.f; resy[t] = 0.f; }
@@ -374,7 +375,7 @@ static void fkz_orient(FkPoint* pt, const int* dxd, const int* dyd, int o, int w
 }
 
 /* akazed.cu:3723-3850 gDescribe2 (int accumulators: sums are exact and order-free) */
-static void fkz_describe(FkPoint* pt, const int* imd, const int* dxd, const int* dyd, int o, int w, int h, int p,
+void fkz_describe(FkPoint* pt, const int* imd, const int* dxd, const int* dyd, int o, int w, int h, int p,
                          int patsize, const int* idx1, const int* idx2)
 {
     int acc[90];

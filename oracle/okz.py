@@ -192,6 +192,70 @@ def hessian(src, w, step):
     return lx, ly, det
 
 
+# ---- detector tail and descriptor stages on hand-made inputs (tests/test_reference_literal_cpu.py)
+def _pitched(a, dtype=np.float32):
+    a = np.ascontiguousarray(a, dtype)
+    assert a.ndim == 2
+    return a
+
+
+def extrema_map(dets, w, params, octave, threshold, maps, opitch, fast=False):
+    """okz_extrema_map / fkz_extrema (gCalcExtremaMap akazed.cu:1334 / 3476).  dets: (ms, h, p) planes of one octave;
+    params = borders[ms] + sizes[ms]; maps = (response (H, P), size (H, P), layer (H, P)) updated in place."""
+    ms, h, p = dets.shape
+    resp, size, layer = maps
+    prm = np.ascontiguousarray(params, np.float32)
+    if fast:
+        assert dets.dtype == np.int32 and resp.dtype == np.int32
+        lib().fkz_extrema(dets.ctypes.data_as(C.c_void_p), resp.ctypes.data_as(C.c_void_p), _f(size), layer.ctypes.data_as(_ip), _f(prm),
+                          C.c_int(octave), C.c_int(ms), C.c_int(int(threshold)), C.c_int(w), C.c_int(h), C.c_int(p), C.c_int(opitch))
+    else:
+        assert dets.dtype == np.float32 and resp.dtype == np.float32
+        lib().okz_extrema_map(_f(dets.reshape(-1)), _f(resp.reshape(-1)), _f(size.reshape(-1)), layer.ctypes.data_as(_ip), _f(prm),
+                              C.c_int(octave), C.c_int(ms), C.c_float(threshold), C.c_int(w), C.c_int(h), C.c_int(p), C.c_int(opitch))
+
+
+def nms(resp, size, layer, w, psz, max_pts=10000, fast=False):
+    """okz_nms / fkz_nms (gNmsRNaive akazed.cu:1554 / 3538) on full-resolution maps (H, P); returns (points, total)"""
+    h, p = resp.shape
+    pts = np.zeros(max_pts, POINT_DTYPE)
+    fn = lib().fkz_nms if fast else lib().okz_nms
+    assert resp.dtype == (np.int32 if fast else np.float32) and size.dtype == np.float32 and layer.dtype == np.int32
+    n = fn(pts.ctypes.data_as(C.c_void_p), C.c_int(max_pts), resp.ctypes.data_as(C.c_void_p), _f(size.reshape(-1)),
+           layer.ctypes.data_as(_ip), C.c_int(psz), C.c_int(w), C.c_int(h), C.c_int(p))
+    return pts[:min(n, max_pts)].copy(), n
+
+
+def refine_point(pt, det, o, fast=False):
+    """okz_refine_point / fkz_refine (gRefine akazed.cu:1615 / 3600) on one record; det: (h, p) plane of its level"""
+    rec = np.array([pt], POINT_DTYPE)
+    h, p = det.shape
+    fn = lib().fkz_refine if fast else lib().okz_refine_point
+    fn(rec.ctypes.data_as(C.c_void_p), det.ctypes.data_as(C.c_void_p), C.c_int(o), C.c_int(p))
+    return rec[0]
+
+
+def orient_point(pt, lx, ly, o, w, fast=False):
+    """okz_orient_point / fkz_orient (gCalcOrient akazed.cu:1665 / 3649); lx, ly: (h, p) planes of the point's level"""
+    rec = np.array([pt], POINT_DTYPE)
+    h, p = lx.shape
+    fn = lib().fkz_orient if fast else lib().okz_orient_point
+    fn(rec.ctypes.data_as(C.c_void_p), lx.ctypes.data_as(C.c_void_p), ly.ctypes.data_as(C.c_void_p), C.c_int(o), C.c_int(w),
+       C.c_int(h), C.c_int(p), _f(orient_weights()))
+    return rec[0]
+
+
+def describe_point(pt, lt, lx, ly, o, w, patsize=10, fast=False):
+    """okz_describe_point / fkz_describe (gDescribe2 akazed.cu:1869 / 3723)"""
+    rec = np.array([pt], POINT_DTYPE)
+    h, p = lt.shape
+    i1, i2 = compare_indices()
+    fn = lib().fkz_describe if fast else lib().okz_describe_point
+    fn(rec.ctypes.data_as(C.c_void_p), lt.ctypes.data_as(C.c_void_p), lx.ctypes.data_as(C.c_void_p), ly.ctypes.data_as(C.c_void_p),
+       C.c_int(o), C.c_int(w), C.c_int(h), C.c_int(p), C.c_int(patsize), i1.ctypes.data_as(_ip), i2.ctypes.data_as(_ip))
+    return rec[0]
+
+
 def match(pts1, pts2):
     """in-place on pts1 (structured arrays)"""
     lib().okz_match(pts1.ctypes.data_as(C.c_void_p), len(pts1), pts2.ctypes.data_as(C.c_void_p), len(pts2))

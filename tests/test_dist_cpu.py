@@ -51,3 +51,33 @@ def test_shard_pairs_properties():
             parts = [bench.shard_pairs(total, world, r) for r in range(world)]
             assert parts[0][0] == 0 and parts[-1][1] == total
             assert all(a[1] == b[0] for a, b in zip(parts, parts[1:]))
+
+
+def test_launcher_command_for_two_ranks():
+    """`python bench.py --gpus 2 ...` without a launcher starts exactly this (one rank per GPU, rendezvous on 127.0.0.1)"""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.launcher_command(["--gpus", "2", "--steps", "3"], 2, 29777)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and "--nproc-per-node=2" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29777"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3"]
+
+
+def test_more_ranks_than_devices_fails_loudly():
+    """no GPU in this container: `--gpus 2` must refuse before any rank starts (exit 2, a message naming both numbers)"""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    ndev = torch.cuda.device_count()
+    if ndev >= 2:
+        pytest.skip("this box has two devices")
+    assert r.returncode == 2 and f"2 ranks requested, {ndev} device" in r.stderr
+
+
+def test_rank_count_must_match_gpus_flag():
+    """started by a launcher with the wrong WORLD_SIZE the rank refuses instead of silently using it"""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode == 2 and "WORLD_SIZE=3" in r.stderr

@@ -61,3 +61,19 @@ def test_bench_rccl_path_with_one_rank_weak_and_strong():
     assert abs(strong["value"] - 40 * 2 / (strong["ms_per_step"] * 2e-3)) / strong["value"] < 0.01
     assert strong["verified"]["points_equal"] and strong["verified"]["matches_equal"]
     assert strong["upload_inclusive_pairs_per_s"] > 0
+
+
+def test_bench_through_its_own_rank_launcher():
+    """`--launch`: bench.py starts torch.distributed.run itself (the N > 1 path of a plain `python bench.py --gpus N`) with one
+    rank; the child runs over RCCL and the parent relays its line"""
+    out = run_bench(["--gpus", "1", "--launch", "--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs",
+                     "--no-roofline"], {"MASTER_PORT": "29613", "HAK_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["verified"]["points_equal"]
+
+
+def test_bench_refuses_more_ranks_than_devices():
+    import torch
+    n = torch.cuda.device_count()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=300,
+                       cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 2 and f"{n + 1} ranks requested, {n} device" in r.stderr
