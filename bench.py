@@ -354,8 +354,8 @@ def other_configs(ah, synth, args, rank):
     det = ah.Akazer()
     det.init((w, h, p), max_pts=max_pts)
     r1, r2 = ah.AkazeData(), ah.AkazeData()
-    ah.initAkazeData(r1, max_pts, True, True)
-    ah.initAkazeData(r2, max_pts, True, True)
+    ah.initAkazeData(r1, max_pts, True, True, pinned=True)       # as the C++ layer's initAkazeData (host/akaze.cpp)
+    ah.initAkazeData(r2, max_pts, True, True, pinned=True)
     lat = []
     for i in range(25):
         torch.cuda.synchronize()

@@ -200,13 +200,24 @@ class AkazeData:
         self.max_pts = 0
         self.h_data = None      # numpy structured array (POINT_DTYPE) or None
         self.d_data = None      # device pointer (int) or None
+        self.h_pinned = None    # address of h_data when it lives in pinned host memory
 
 
-def initAkazeData(data, max_pts, host, dev):
-    """akaze.cpp:26-40"""
+def initAkazeData(data, max_pts, host, dev, pinned=False):
+    """akaze.cpp:26-40.  pinned=True gives h_data in device-visible host memory, as the C++ layer's initAkazeData does
+    (host/akaze.cpp): detectAndCompute then delivers records and count inside its launch sequence."""
     data.num_pts = 0
     data.max_pts = max_pts
-    data.h_data = np.zeros(max_pts, POINT_DTYPE) if host else None
+    data.h_pinned = None
+    if host and pinned:
+        hp = _vp()
+        check(lib.hak_host_alloc(C.byref(hp), max_pts * POINT_DTYPE.itemsize))
+        data.h_pinned = hp.value
+        buf = (C.c_uint8 * (max_pts * POINT_DTYPE.itemsize)).from_address(hp.value)
+        data.h_data = np.frombuffer(buf, dtype=POINT_DTYPE)
+        data.h_data[:] = np.zeros(1, POINT_DTYPE)[0]
+    else:
+        data.h_data = np.zeros(max_pts, POINT_DTYPE) if host else None
     data.d_data = None
     if dev:
         p = _vp()
@@ -220,6 +231,9 @@ def freeAkazeData(data):
         check(lib.hak_points_free(data.d_data))
     data.d_data = None
     data.h_data = None
+    if getattr(data, "h_pinned", None):
+        check(lib.hak_host_free(data.h_pinned))
+        data.h_pinned = None
     data.num_pts = 0
     data.max_pts = 0
 

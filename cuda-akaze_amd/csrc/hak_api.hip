@@ -173,7 +173,7 @@ struct hak_ctx {
     bool concurrent = true;
     // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
     bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
-    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; };
+    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; hak_point* hpts; };
     static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
     hipGraphExec_t graph_exec[NGRAPH] = {};
     GraphKey gkey[NGRAPH] = {};
@@ -192,6 +192,7 @@ struct hak_ctx {
     long match_keys_cap = 0;
     HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
     hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
+    hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
     bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
     bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
 };
@@ -206,6 +207,7 @@ HakKnobs hak_knobs_from_env()
     if (const char* e = getenv("HAK_HESS_CBUF")) { const int v = atoi(e); k.hess_cbuf = v < 1 ? 1 : (v > 256 ? 256 : v); }
     if (const char* e = getenv("HAK_DESC_ORDER")) { const int v = atoi(e); k.desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
     if (const char* e = getenv("HAK_DESC_PLAN")) k.desc_plan = atoi(e);
+    if (const char* e = getenv("HAK_LEVEL_TILE")) k.level_tile = atoi(e);
     return k;
 }
 
@@ -362,6 +364,11 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (e == hipSuccess) e = hipMemset(c->maps, 0, sizeof(unsigned long long) * (size_t)L.oct[0].plane * B);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming);
+    // ... and so must the survivor bitmap and the row counts (hak_launch_clear_maps restores all three)
+    if (e == hipSuccess) e = hipMemset(c->bitmap, 0, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
+    if (e == hipSuccess) e = hipMemset(c->rowcount, 0, sizeof(int) * (size_t)L.oct[0].h * B);
     for (int o = 0; o < L.noct && e == hipSuccess; o++) {
         if (o > 0) e = hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready[o], hipEventDisableTiming);
@@ -385,6 +392,8 @@ extern "C" void hak_destroy(hak_ctx* c)
     // work may still be queued on a caller-provided stream (hak_set_stream), which may itself be gone by now: wait for the
     // event recorded after the context's last enqueue instead of touching that stream
     if (c->ev_last) { (void)hipEventSynchronize(c->ev_last); (void)hipEventDestroy(c->ev_last); }
+    if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
+    if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
     for (int o = 0; o < HAK_MAX_OCTAVES; o++) {
@@ -429,8 +438,12 @@ extern "C" int hak_sync(hak_ctx* c)
 // on the context's stream and never inside a stream capture, so a replayed graph cannot miss (or needlessly carry) the clear.
 static void maps_guard_begin(hak_ctx* c)
 {
-    if (c->maps_dirty)
-        (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)c->L.oct[0].plane * c->cfg.batch, c->stream);
+    if (c->maps_dirty) {
+        const size_t h = c->L.oct[0].h, words = (c->L.oct[0].w + 63) / 64, B = c->cfg.batch;
+        (void)hipMemsetAsync(c->maps, 0, sizeof(unsigned long long) * (size_t)c->L.oct[0].plane * B, c->stream);
+        (void)hipMemsetAsync(c->bitmap, 0, sizeof(unsigned long long) * h * words * B, c->stream);
+        (void)hipMemsetAsync(c->rowcount, 0, sizeof(int) * h * B, c->stream);
+    }
     c->maps_dirty = true;
 }
 static int maps_guard_end(hak_ctx* c, int rc)
@@ -440,13 +453,20 @@ static int maps_guard_end(hak_ctx* c, int rc)
     return rc;
 }
 
+// kernels_level.hip's one-launch sublevel: by the size rule unless a test forces the streaming kernels (fuse_sf == 2)
+static bool level_tile_pays(const hak_ctx* c, const HakOct& oc, int nimg)
+{
+    const int mode = c->knobs.level_tile;
+    if (mode != 1) return mode != 0;
+    return c->fuse_sf != 2 && (long)oc.w * oc.h * nimg <= HAK_LEVEL_TILE_MAX_PX;
+}
+
 static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                          hak_point* d_points, int* d_num_pts, int desc, int max_pts)
+                          hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_points = nullptr)
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
     const hipStream_t main_st = c->stream;
-    hipStream_t st = main_st;
     float* A = c->arena;
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
@@ -454,116 +474,195 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
 
-    hak_launch_reset_state(st, c->state, nimg);        // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
-
-    for (int o = 0; o < L.noct; o++) {
+    // ---- part A of level (o, s): build Lt(o, s) and the sigma=1 low-pass `smooth` the level's Hessian reads (akaze.cpp:325-421)
+    auto build_level = [&](int o, int s, hipStream_t st) {
         const HakOct oc = L.oct[o];
-        if (c->concurrent && o > 0) {                       // this octave's chain waits only for Lt(o-1,0)
-            st = c->oct_stream[o];
-            if (hipStreamWaitEvent(st, c->ev_ready[o - 1], 0) != hipSuccess) return fail("stream wait");
-        }
         float* smooth = A + L.smooth_off[o];
         float* flow = A + L.flow_off[o];
         float* tmp = A + L.tmp_off[o];
-        for (int s = 0; s < L.ms; s++) {
-            const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
-            float* Lt = A + L.lt(o, s);
-            if (o == 0 && s == 0) {                                               // akaze.cpp:325-354
-                { ProfScope ps(c, HAK_PROF_CONTRAST, st);                          // akaze.cpp:329-332 in two passes over img
-                  hak_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp /* free until the FED cycle of (0,1) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
-                                        c->taps_base, c->base_R, c->state, cfg.per, L.noct, c->knobs); }
-                if (c->concurrent) (void)hipEventRecord(c->ev_ready[0], st);       // Lt(0,0) + contrast factors ready
-                { ProfScope ps(c, HAK_PROF_HESSIAN, st);
-                  // (the determinant goes to HBM only in the dilation > 4 fallback: `flow` is free here and at every later call)
-                  if (!hak_launch_hessian_level(st, Lt, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
-                                                lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
-                      hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]); }
-                continue;
-            }
-            const int n = lp.nsteps;
-            const int G = hak_fed_groups(n, c->max_fuse, oc.w);     // launches of this FED cycle
-            const float* fsrc;          // input of the first FED launch
-            bool fused_first = false;
-            if (s == 0) {                                                         // akaze.cpp:369-392
-                // octave head: decimation + low-pass + conductivity + the first FED group in one streaming pass when covered
-                if (c->fuse_head && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
-                    ProfScope ps(c, HAK_PROF_FED, st);
-                    fused_first = hak_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
-                                                         nimg, c->taps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
-                                                         c->state, o, G > 1);
-                    if (fused_first) {
-                        c->fed_launches++;       // reads the even rows of Lt(o-1,0), writes smooth, L' (+ g for later launches)
-                        c->fed_fused_bytes += 2.0 * L.oct[o - 1].w * L.oct[o - 1].h + (G > 1 ? 12.0 : 8.0) * oc.w * oc.h;
-                    }
-                }
-                // otherwise decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
-                float* first = (G % 2 == 0) ? Lt : tmp;
-                if (!fused_first) {
-                    ProfScope ps(c, HAK_PROF_DOWN, st);
-                    hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1);
-                }
-                fsrc = first;
-            } else {                                                              // akaze.cpp:393-421
-                fsrc = A + L.lt(o, s - 1);
-            }
-            // sublevels > 0: low-pass + conductivity + the first FED group in one streaming pass when the case is covered
-            // (PM_G2, 16-byte rows); the conductivity plane is written only if later groups of the cycle need it
-            if (s == 0) {
-                if (!fused_first) {
-                    ProfScope ps(c, HAK_PROF_FLOW, st);
-                    hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
-                }
-            } else if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg) && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 &&
-                       oc.h >= 8) {
-                const int ns0 = hak_fed_group_size(n, G, 0);
-                float* dst0 = (G % 2 == 1) ? Lt : tmp;
-                ProfScope ps(c, HAK_PROF_FED, st);
-                fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
-                                                lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
-                if (fused_first) {
-                    c->fed_launches++;           // reads L, writes smooth, L' (+ g for later launches)
-                    c->fed_fused_bytes += (G > 1 ? 16.0 : 12.0) * oc.w * oc.h;
-                }
-            }
-            if (s != 0 && !fused_first) {                                         // akaze.cpp:403-404 in one pass
-                ProfScope ps(c, HAK_PROF_LOWPASS, st);
-                hak_launch_smooth_flow(st, fsrc, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
-                                       c->state, o, 0.f);
-            }
-            {
-                // the n explicit steps of the cycle in G fused launches, ping-pong Lt <-> tmp, ending in Lt
-                const float* src = fsrc;
-                int done = 0;
-                for (int g = 0; g < G; g++) {
-                    const int ns = hak_fed_group_size(n, G, g);
-                    float* dst = ((G - g) % 2 == 1) ? Lt : tmp;
-                    if (!(g == 0 && fused_first)) {
-                        ProfScope ps(c, HAK_PROF_FED, st);
-                        hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
-                        c->fed_launches++;
-                        c->fed_fused_bytes += 12.0 * oc.w * oc.h;   // reads L and g, writes L'
-                    }
-                    done += ns;
-                    src = dst;
-                }
-                if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
-            }
-            { ProfScope ps(c, HAK_PROF_HESSIAN, st);                              // akaze.cpp:423
-              if (!hak_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
-                                            lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
-                  hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]); }
+        const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
+        float* Lt = A + L.lt(o, s);
+        if (o == 0 && s == 0) {                                                   // akaze.cpp:325-332 in two passes over img
+            ProfScope ps(c, HAK_PROF_CONTRAST, st);
+            hak_launch_base_level(st, d_images, image_stride, pitch, Lt, tmp /* free until the FED cycle of (0,1) */, S, oc.w, oc.h, oc.p, nimg, c->taps1,
+                                  c->taps_base, c->base_R, c->state, cfg.per, L.noct, c->knobs);
+            return;
         }
-        // akaze.cpp:431-433 hCalcExtremaMap: fused into the per-level Hessian kernel above
-        if (c->concurrent && o > 0) (void)hipEventRecord(c->ev_done[o], st);
+        const int n = lp.nsteps;
+        // small launches (single images, small octaves of small batches): the whole sublevel in one launch out of LDS tiles
+        if (level_tile_pays(c, oc, nimg)) {
+            ProfScope ps(c, HAK_PROF_FED, st);
+            const int nl = hak_launch_level_tile(st, s == 0 ? A + L.lt(o - 1, 0) : A + L.lt(o, s - 1), s == 0 ? L.oct[o - 1] : oc, s == 0, smooth, Lt, tmp, S,
+                                                 oc, nimg, c->taps1, cfg.diffusivity, lp.tau.data(), n, c->state, o, 0.f);
+            c->fed_launches += nl;
+            c->fed_fused_bytes += (s == 0 ? 1.0 * L.oct[o - 1].w * L.oct[o - 1].h : 4.0 * oc.w * oc.h) + 8.0 * oc.w * oc.h + (nl - 1) * 12.0 * oc.w * oc.h;
+            return;
+        }
+        const int G = hak_fed_groups(n, c->max_fuse, oc.w);     // launches of this FED cycle
+        const float* fsrc;          // input of the first FED launch
+        bool fused_first = false;
+        if (s == 0) {                                                             // akaze.cpp:369-392
+            // octave head: decimation + low-pass + conductivity + the first FED group in one streaming pass when covered
+            if (c->fuse_head && hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg)) {
+                ProfScope ps(c, HAK_PROF_FED, st);
+                fused_first = hak_launch_fed_sf_head(st, A + L.lt(o - 1, 0), L.oct[o - 1], smooth, flow, (G % 2 == 1) ? Lt : tmp, S, oc,
+                                                     nimg, c->taps1, cfg.diffusivity, lp.tau.data(), hak_fed_group_size(n, G, 0),
+                                                     c->state, o, G > 1);
+                if (fused_first) {
+                    c->fed_launches++;           // reads the even rows of Lt(o-1,0), writes smooth, L' (+ g for later launches)
+                    c->fed_fused_bytes += 2.0 * L.oct[o - 1].w * L.oct[o - 1].h + (G > 1 ? 12.0 : 8.0) * oc.w * oc.h;
+                }
+            }
+            // otherwise decimate Lt(o-1,0) so that the last of G ping-pong launches lands in Lt(o,0)
+            float* first = (G % 2 == 0) ? Lt : tmp;
+            if (!fused_first) {
+                ProfScope ps(c, HAK_PROF_DOWN, st);
+                hak_launch_down_smooth(st, A + L.lt(o - 1, 0), first, smooth, S, L.oct[o - 1], oc, nimg, c->taps1);
+            }
+            fsrc = first;
+        } else {                                                                  // akaze.cpp:393-421
+            fsrc = A + L.lt(o, s - 1);
+        }
+        // sublevels > 0: low-pass + conductivity + the first FED group in one streaming pass when the case is covered
+        // (PM_G2, 16-byte rows); the conductivity plane is written only if later groups of the cycle need it
+        if (s == 0) {
+            if (!fused_first) {
+                ProfScope ps(c, HAK_PROF_FLOW, st);
+                hak_launch_flow(st, smooth, flow, S, oc.w, oc.h, oc.p, nimg, cfg.diffusivity, c->state, o, 0.f);
+            }
+        } else if (hak_stream_pays(c->fuse_sf, oc.w, oc.h, nimg) && cfg.diffusivity == HAK_PM_G2 && (oc.w & 3) == 0 && oc.w >= 16 &&
+                   oc.h >= 8) {
+            const int ns0 = hak_fed_group_size(n, G, 0);
+            float* dst0 = (G % 2 == 1) ? Lt : tmp;
+            ProfScope ps(c, HAK_PROF_FED, st);
+            fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
+                                            lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
+            if (fused_first) {
+                c->fed_launches++;               // reads L, writes smooth, L' (+ g for later launches)
+                c->fed_fused_bytes += (G > 1 ? 16.0 : 12.0) * oc.w * oc.h;
+            }
+        }
+        if (s != 0 && !fused_first) {                                             // akaze.cpp:403-404 in one pass
+            ProfScope ps(c, HAK_PROF_LOWPASS, st);
+            hak_launch_smooth_flow(st, fsrc, smooth, flow, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
+                                   c->state, o, 0.f);
+        }
+        // the n explicit steps of the cycle in G fused launches, ping-pong Lt <-> tmp, ending in Lt
+        const float* src = fsrc;
+        int done = 0;
+        for (int g = 0; g < G; g++) {
+            const int ns = hak_fed_group_size(n, G, g);
+            float* dst = ((G - g) % 2 == 1) ? Lt : tmp;
+            if (!(g == 0 && fused_first)) {
+                ProfScope ps(c, HAK_PROF_FED, st);
+                hak_launch_fed_group(st, src, flow, dst, S, oc.w, oc.h, oc.p, nimg, lp.tau.data() + done, ns);
+                c->fed_launches++;
+                c->fed_fused_bytes += 12.0 * oc.w * oc.h;       // reads L and g, writes L'
+            }
+            done += ns;
+            src = dst;
+        }
+    };
+    // ---- part B of level (o, s): derivatives + determinant + extrema (akaze.cpp:354, 423, 431-433).  Level (0, 0) differentiates
+    // Lt itself, every other level the low-pass of its predecessor (D13).  (The determinant goes to HBM only in the dilation > 4
+    // fallback: `flow` is free at every call.)
+    auto hessian_level = [&](int o, int s, hipStream_t st) {
+        const HakOct oc = L.oct[o];
+        const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
+        const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : A + L.smooth_off[o];
+        ProfScope ps(c, HAK_PROF_HESSIAN, st);
+        if (!hak_launch_hessian_level(st, hsrc, A + L.dxy(o, s), A + L.flow_off[o], false, S, oc.w, oc.h, oc.p, nimg,
+                                      lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
+            hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]);
+    };
+
+    hak_launch_reset_state(main_st, c->state, nimg);   // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
+
+    // Octave o+1 depends only on Lt(o, 0) (the reference decimates from sublevel 0, akaze.cpp:371-375).
+    const bool spine = c->concurrent && L.noct > 1 && level_tile_pays(c, L.oct[0], nimg);
+    if (spine) {
+        // Launch-bound calls (a single image): the dependency chain base -> head(1) -> head(2) -> ... -> every sublevel of the
+        // last octave is the critical path, so it runs on ONE stream without cross-queue waits (each costs 15-35 us in a replayed
+        // graph, profiles/r03_single_*); what hangs off it -- the remaining sublevels and all Hessians of octaves 0 .. noct-2 --
+        // goes to side streams, one per octave.
+        const int last = L.noct - 1;
+        hipGraphNode_t head_node[HAK_MAX_OCTAVES] = {};
+        hipGraph_t cap_graph = nullptr;
+        for (int o = 0; o <= last; o++) {
+            build_level(o, 0, main_st);
+            if (o < last) {
+                (void)hipEventRecord(c->ev_ready[o], main_st);                    // Lt(o,0) + its low-pass ready: side stream o may start
+                // while capturing: remember the head's graph node (see below)
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                const hipGraphNode_t* deps = nullptr;
+                size_t ndeps = 0;
+                if (hipStreamGetCaptureInfo_v2(main_st, &cs, nullptr, &cap_graph, &deps, &ndeps) == hipSuccess &&
+                    cs == hipStreamCaptureStatusActive && ndeps == 1) head_node[o] = deps[0];
+                else (void)hipGetLastError();
+            }
+        }
+        // The graph executor deals a fork's branches to its queues by position: the first outgoing edge of a node stays on the
+        // node's queue, the k-th goes k-1 queues further (of four).  Every side stream forks from the spine as some head's SECOND
+        // edge, so all three would share one queue and run one after the other (measured: 440 us of side work in a row).  Empty
+        // nodes in front of a fork move its side branch further along.  The replay submits queue by queue -- the spine's first, then
+        // the others from the last to the first -- so the longest side chain (octave 0's) gets the last queue, the shortest the
+        // first.  Pure placement: results and ordering are unaffected, and a runtime that places nodes differently merely ignores
+        // the hint (HAK_GRAPH_PADS=0 switches it off).
+        static const bool pads_on = [] { const char* e = getenv("HAK_GRAPH_PADS"); return !e || atoi(e) != 0; }();
+        for (int o = 0; o < last && pads_on; o++)
+            for (int k = 0; k < last - 1 - o && head_node[o] && cap_graph; k++) {
+                hipGraphNode_t pad = nullptr;
+                if (hipGraphAddEmptyNode(&pad, cap_graph, &head_node[o], 1) != hipSuccess) (void)hipGetLastError();
+            }
+        for (int o = 0; o < last; o++)
+            if (hipStreamWaitEvent(c->oct_stream[o + 1], c->ev_ready[o], 0) != hipSuccess) return fail("stream wait");
+        // the remaining work, one level per octave in turn (the graph replays launches in capture order: the host spends
+        // several microseconds on each, so no chain should wait for all of another one to be submitted first)
+        for (int s = 0; s < L.ms; s++)
+            for (int k = 0; k <= last; k++) {
+                const int o = k == 0 ? last : k - 1;                              // the spine's own octave first
+                const hipStream_t st = o == last ? main_st : c->oct_stream[o + 1];
+                if (s > 0) build_level(o, s, st);
+                hessian_level(o, s, st);
+            }
+        for (int o = 0; o < last; o++) {
+            (void)hipEventRecord(c->ev_done[o + 1], c->oct_stream[o + 1]);
+            if (hipStreamWaitEvent(main_st, c->ev_done[o + 1], 0) != hipSuccess) return fail("stream join");
+        }
+    } else {
+        // each octave on its own stream, chained by events: the small octaves' launches are latency chains of a few hundred waves
+        // and hide under octave 0's chip-filling kernels
+        hipStream_t st = main_st;
+        for (int o = 0; o < L.noct; o++) {
+            if (c->concurrent && o > 0) {                       // this octave's chain waits only for Lt(o-1,0)
+                st = c->oct_stream[o];
+                if (hipStreamWaitEvent(st, c->ev_ready[o - 1], 0) != hipSuccess) return fail("stream wait");
+            }
+            for (int s = 0; s < L.ms; s++) {
+                build_level(o, s, st);
+                if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
+                hessian_level(o, s, st);
+            }
+            if (c->concurrent && o > 0) (void)hipEventRecord(c->ev_done[o], st);
+        }
+        if (c->concurrent)
+            for (int o = 1; o < L.noct; o++)
+                if (hipStreamWaitEvent(main_st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
     }
-    st = main_st;
-    if (c->concurrent)
-        for (int o = 1; o < L.noct; o++)
-            if (hipStreamWaitEvent(st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
-      hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts); }
+      hak_launch_nms_emit(main_st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts);
+      // the clean-up for the next sequence needs only the candidate list: beside the descriptor kernels, not in front of them
+      if (c->concurrent && L.noct > 1) {
+          (void)hipEventRecord(c->ev_tail_fork, main_st);
+          if (hipStreamWaitEvent(c->oct_stream[1], c->ev_tail_fork, 0) != hipSuccess) return fail("stream wait");
+          hak_launch_clear_maps(c->oct_stream[1], b, L);
+          (void)hipEventRecord(c->ev_tail_join, c->oct_stream[1]);
+      } else hak_launch_clear_maps(main_st, b, L); }
     { ProfScope ps(c, HAK_PROF_DESCRIBE);                                         // akaze.cpp:124-131
-      hak_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok); }
+      hak_launch_describe(main_st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok); }
+    if (h_points)                                                                 // pinned destination: records and count go out in the same sequence
+        hak_launch_download(main_st, d_points, d_num_pts, max_pts, nimg, h_points, c->h_num);
+    if (c->concurrent && L.noct > 1 && hipStreamWaitEvent(main_st, c->ev_tail_join, 0) != hipSuccess) return fail("stream join");
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     return 0;
 }
@@ -606,6 +705,16 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
                 continue;
             }
             const int n = lp.nsteps;
+            if (level_tile_pays(c, oc, nimg)) {
+                hakf_launch_level_tile(st, s == 0 ? A + L.lt(o - 1, 0) : A + L.lt(o, s - 1), s == 0 ? L.oct[o - 1] : oc, s == 0, smooth, Lt, tmp, S, oc,
+                                       nimg, c->itaps1, cfg.diffusivity, lp.tau.data(), n, c->state, o);
+                if (!hakf_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
+                                               lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
+                    hakf_launch_hessian(st, smooth, A + L.dxy(o, s), flow, S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
+                    hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold, L.flow_off[o]);
+                }
+                continue;
+            }
             // FED cycle in G fused launches (the float path's streaming kernel instantiated for int32) when the width
             // allows 16-byte rows, else one step per launch; ping-pong Lt <-> tmp so that the last launch lands in Lt
             const bool fused = (oc.w % 4) == 0;
@@ -650,6 +759,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
         }
     }
     hak_launch_nms_emit(st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts, 1);
+    hak_launch_clear_maps(st, b, L);
     hakf_launch_describe(st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok);
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     return 0;
@@ -683,22 +793,23 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
 
 // enqueue one detect+describe sequence: replay the captured graph when the arguments repeat, else capture it
 static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                            hak_point* d_points, int* d_num_pts, int desc, int max_pts);
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned);
+// h_pinned: device-visible host destination of the records (and c->h_num of the counts) written by the sequence itself, or NULL
 static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                      hak_point* d_points, int* d_num_pts, int desc, int max_pts)
+                      hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned = nullptr)
 {
     maps_guard_begin(c);
-    return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts));
+    return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned));
 }
 static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                            hak_point* d_points, int* d_num_pts, int desc, int max_pts)
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned)
 {
     if (!c->use_graph || c->prof_on)
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
     hak_ctx::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.img = d_images; key.stride = image_stride; key.pitch = pitch; key.nimg = nimg; key.pts = d_points;
-    key.num = d_num_pts; key.desc = desc; key.max_pts = max_pts; key.conc = c->concurrent ? 1 : 0; key.st = c->stream;
+    key.num = d_num_pts; key.desc = desc; key.max_pts = max_pts; key.conc = c->concurrent ? 1 : 0; key.st = c->stream; key.hpts = h_pinned;
     int slot = -1, victim = 0;
     for (int i = 0; i < hak_ctx::NGRAPH; i++) {
         if (c->graph_exec[i] && memcmp(&key, &c->gkey[i], sizeof(key)) == 0) slot = i;
@@ -715,9 +826,9 @@ static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         c->use_graph = false;                                   // e.g. legacy default stream: fall back to eager launches
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
     }
-    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts);
+    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -739,17 +850,30 @@ extern "C" int hak_detect_and_compute_batch(hak_ctx* c, const float* d_images, l
     return run_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts);
 }
 
+// is p device-visible (pinned) host memory?  A pageable pointer makes the query fail: not an error here.
+static bool host_pinned(const void* p)
+{
+    hipPointerAttribute_t a{};
+    const bool pinned = p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    (void)hipGetLastError();
+    return pinned;
+}
+
 extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitch, hak_point* d_points, int max_pts,
                                       int* num_pts, hak_point* h_points, int desc)
 {
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
     if (max_pts < 1) return fail("max_pts < 1");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
-    if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts)) return 1;
-    HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    // A pinned h_points (hak_host_alloc: what initAkazeData of the C++ layer hands out) is filled by the launch sequence itself,
+    // count included: one synchronisation and the results are there.  A pageable one takes the reference's route
+    // (akaze.cpp:134-139): count first, then a copy of the valid records.
+    hak_point* h_pinned = host_pinned(h_points) ? h_points : nullptr;
+    if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts, h_pinned)) return 1;
+    if (!h_pinned) HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     *num_pts = c->h_num[0];
-    if (h_points && *num_pts > 0)                                                 // akaze.cpp:134-139
+    if (h_points && !h_pinned && *num_pts > 0)                                    // akaze.cpp:134-139
         HIP_TRY(hipMemcpy(h_points, d_points, sizeof(hak_point) * (size_t)*num_pts, hipMemcpyDeviceToHost));
     return 0;
 }
@@ -1264,6 +1388,7 @@ extern "C" int hak_op_tail_finish(hak_ctx* c, hak_point* d_points, int max_pts, 
 {
     if (!c || !d_points || !num_pts || max_pts < 1) return fail("bad argument");
     hak_launch_nms_emit(c->stream, tail_batch(c), c->L, c->dtab, c->psz, d_points, max_pts, c->d_num, fast ? 1 : 0, refine ? 1 : 0);
+    hak_launch_clear_maps(c->stream, tail_batch(c), c->L);
     int rc = hipGetLastError() != hipSuccess ? fail("tail finish launch failed") : 0;
     if (!rc && hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream) != hipSuccess) rc = fail("count download");
     if (!rc && hipStreamSynchronize(c->stream) != hipSuccess) rc = fail("sync");

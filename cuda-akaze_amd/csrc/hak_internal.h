@@ -235,6 +235,8 @@ struct HakKnobs {
     int hess_cbuf = 256;          // HAK_HESS_CBUF: staged candidates per block of the tile kernel (1..256; tests drive the overflow path)
     int desc_order = 4;           // HAK_DESC_ORDER: image group size of the describe kernels' block order
     int desc_plan = 1;            // HAK_DESC_PLAN: planned MLDB kernel (k_describe_runs) on / off
+    int level_tile = 1;           // HAK_LEVEL_TILE: one launch per sublevel out of LDS tiles (k_level_tile) 0 never / 1 for launches of at
+                                  // most HAK_LEVEL_TILE_MAX_PX pixels unless the streaming kernels are forced / 2 always
 };
 HakKnobs hak_knobs_from_env();    // defaults overridden by the HAK_* variables (hak_api.hip)
 
@@ -317,6 +319,15 @@ void hakf_launch_smooth_flow(hipStream_t st, const int* src, int* smooth, int* f
 void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, float* flow, long stride,
                             int w, int h, int p, int nimg, const float* taps, int diffusivity,
                             const HakImgState* state, int octave, float fixed_ikc);
+// one whole sublevel (low-pass | decimation, conductivity, every FED step) per launch out of LDS tiles, for launches too small
+// to fill the chip (kernels_level.hip).  Returns the number of launches (1 up to 36 steps).
+#define HAK_LEVEL_TILE_MAX_PX (1920L * 1088L)      // by-size rule: at most one 1080p plane's worth of pixels per launch
+int hak_launch_level_tile(hipStream_t st, const float* src, HakOct so, bool head, float* smooth, float* dst, float* tmp, long stride,
+                          HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int n,
+                          const HakImgState* state, int octave, float fixed_ikc);
+int hakf_launch_level_tile(hipStream_t st, const int* src, HakOct so, bool head, int* smooth, int* dst, int* tmp, long stride,
+                           HakOct dd, int nimg, const int* itaps, int diffusivity, const float* tau, int n,
+                           const HakImgState* state, int octave);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
 bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,
@@ -359,6 +370,7 @@ void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d
                          int* h_num);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
                          hak_point* points, int max_pts, int* num_out, int fast = 0, int refine = 1);
+void hak_launch_clear_maps(hipStream_t st, const HakBatch& b, const HakLayout& L);
 void hak_launch_seed_maps(hipStream_t st, const HakBatch& b, const HakLayout& L, const unsigned* d_resp_bits, const int* d_layer);
 
 // integer FAST path (kernels_fast.hip); planes are int32 in the same arena layout

@@ -260,10 +260,12 @@ void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout
 
 // The key map is sparse: only candidate pixels are ever written.  Instead of clearing the whole 8 B/px map before every
 // call (2.1 GB for a 128-image 1080p batch), every call zeroes the entries its own candidates touched once the keypoints
-// are emitted; the map is cleared in full only when the context is created.
+// are emitted; the map is cleared in full only when the context is created.  The survivor bitmap and the per-row counts are
+// restored to zero here as well (they used to be two memsets in front of k_nms_cand, on the critical path of every call).
 __global__ __launch_bounds__(256) void k_clear_cand_maps(unsigned long long* __restrict__ maps, long map_stride,
                                                          const unsigned long long* __restrict__ cand, long cand_cap,
-                                                         const HakImgState* __restrict__ state, int p)
+                                                         const HakImgState* __restrict__ state, int p,
+                                                         unsigned long long* __restrict__ bitmap, long bitmap_words, int* __restrict__ rowcount, int h)
 {
     const int img = blockIdx.y;
     unsigned long long* map = maps + (long)img * map_stride;
@@ -274,6 +276,8 @@ __global__ __launch_bounds__(256) void k_clear_cand_maps(unsigned long long* __r
         const int x = (int)(e & 0xFFFFu), y = (int)((e >> 16) & 0xFFFFu);
         map[(long)y * p + x] = 0ull;
     }
+    for (long i = blockIdx.x * 256 + threadIdx.x; i < bitmap_words; i += (long)gridDim.x * 256) bitmap[(long)img * bitmap_words + i] = 0ull;
+    for (long i = blockIdx.x * 256 + threadIdx.x; i < h; i += (long)gridDim.x * 256) rowcount[(long)img * h + i] = 0;
 }
 
 // hand-made full-resolution maps -> key map + candidate list, with the extrema kernels' own key and list format
@@ -301,8 +305,7 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 {
     const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
     const int words = (w + 63) / 64;
-    (void)hipMemsetAsync(b.rowcount, 0, sizeof(int) * (size_t)b.nimg * h, st);
-    (void)hipMemsetAsync(b.bitmap, 0, sizeof(unsigned long long) * (size_t)b.nimg * h * words, st);
+    // (bitmap and rowcount are all zero here: hak_create, and every sequence's hak_launch_clear_maps)
     dim3 g1(64, b.nimg);
     k_nms_cand<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, tab, psz, w, h, p,
                                    b.bitmap, words, b.rowcount);
@@ -311,7 +314,15 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
     if (!fast && refine)                                            // (the FAST path refines on its int planes: k_orient<int>)
         k_refine<<<dim3((max_pts + 15) / 16, b.nimg), 256, 0, st>>>(b.base, b.stride, L, tab, b.state, points, max_pts);
-    k_clear_cand_maps<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, p);
+}
+
+// restores the all-zero state of the key map, the survivor bitmap and the row counts for the next sequence; needs the
+// candidate list and must follow k_emit (any stream ordered after it)
+void hak_launch_clear_maps(hipStream_t st, const HakBatch& b, const HakLayout& L)
+{
+    const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
+    const int words = (w + 63) / 64;
+    k_clear_cand_maps<<<dim3(64, b.nimg), 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, p, b.bitmap, (long)h * words, b.rowcount, h);
 }
 
 // ---- results -> pinned host memory in one launch (hak_download_batch): every image's valid prefix of point records and

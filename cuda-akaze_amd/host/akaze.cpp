@@ -4,6 +4,8 @@
 #include "akaze.h"
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <set>
 
 namespace
 {
@@ -12,6 +14,9 @@ namespace
         fprintf(stderr, "hip-akaze: %s failed: %s\n", what, hak_last_error());
         exit(-1);                                                     // cuda_utils.h:23
     }
+    // host buffers handed out pinned (device-visible), so that freeAkazeData knows how to release them
+    std::mutex g_pinned_mu;
+    std::set<void*> g_pinned;
 }
 
 namespace akaze
@@ -20,7 +25,18 @@ namespace akaze
     {
         data.num_pts = 0;
         data.max_pts = max_pts;
-        data.h_data = host ? (AkazePoint*)malloc(sizeof(AkazePoint) * (size_t)max_pts) : NULL;
+        data.h_data = NULL;
+        if (host) {
+            // pinned host memory: detectAndCompute's launch sequence writes the records (and the count) straight into it, so a
+            // call ends with ONE synchronisation instead of a count copy, a sync and a record copy (akaze.cpp:134-139 does the
+            // latter on pageable memory).  Without a usable device the plain allocation of the reference remains.
+            void* p = NULL;
+            if (hak_host_alloc(&p, (long)(sizeof(AkazePoint) * (size_t)max_pts)) == 0 && p) {
+                std::lock_guard<std::mutex> lock(g_pinned_mu);
+                g_pinned.insert(p);
+            } else p = malloc(sizeof(AkazePoint) * (size_t)max_pts);
+            data.h_data = (AkazePoint*)p;
+        }
         data.d_data = NULL;
         if (dev && hak_points_alloc(&data.d_data, max_pts)) die("initAkazeData");
     }
@@ -28,7 +44,12 @@ namespace akaze
     void freeAkazeData(AkazeData& data)                                                          // akaze.cpp:43-52
     {
         if (data.d_data != NULL && hak_points_free(data.d_data)) die("freeAkazeData");
-        if (data.h_data != NULL) free(data.h_data);
+        if (data.h_data != NULL) {
+            bool pinned;
+            { std::lock_guard<std::mutex> lock(g_pinned_mu); pinned = g_pinned.erase(data.h_data) > 0; }
+            if (pinned) { if (hak_host_free(data.h_data)) die("freeAkazeData"); }
+            else free(data.h_data);
+        }
         data.d_data = NULL;
         data.h_data = NULL;
         data.num_pts = 0;

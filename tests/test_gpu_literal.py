@@ -85,7 +85,7 @@ def test_refine_on_hand_made_blobs_matches_the_oracle(ah, okz, monkeypatch, stre
     monkeypatch.setenv("HAK_HESS_STREAM", stream)
     yy, xx = np.mgrid[0:lf.EXT_H, 0:lf.EXT_W].astype(np.float64)
     img = np.zeros((lf.EXT_H, lf.EXT_W))
-    for cx, cy, sx, sy in ((60.3, 70.4, 3.0, 4.0), (120.7, 60.2, 4.0, 3.0), (100.5, 120.5, 3.5, 3.5), (135.1, 100.9, 3.0, 3.2)):
+    for cx, cy, sx, sy in ((60.3, 70.4, 3.0, 4.0), (120.7, 60.2, 4.0, 3.0), (100.4, 115.3, 3.5, 3.5), (135.1, 100.9, 3.0, 3.2)):
         img += np.exp(-((xx - cx) ** 2 / (2 * sx * sx) + (yy - cy) ** 2 / (2 * sy * sy)))
     img = img.astype(np.float32)
     det = _akazer(ah, lf.EXT_W, lf.EXT_H, noctaves=1)

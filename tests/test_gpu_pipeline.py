@@ -71,8 +71,10 @@ def test_synth_golden(ah, torch, synth, golden, case):
     assert rel.max() <= 1e-4
 
 
-def test_planes_small(ah, okz, torch, synth):
+@pytest.mark.parametrize("level_tile", ["1", "2"], ids=["streaming kernels", "k_level_tile"])
+def test_planes_small(ah, okz, torch, synth, monkeypatch, level_tile):
     """every persistent plane of every level, bit for bit (localises a failing stage)"""
+    monkeypatch.setenv("HAK_LEVEL_TILE", level_tile)
     w, h = 320, 240
     u8 = _mg().case_scene(w, h, 11)
     pts, det, data = gpu_detect(ah, torch, synth, u8, keep=True)
@@ -232,9 +234,6 @@ class default_knobs:
         for k, v in self.saved.items():
             if v is not None:
                 os.environ[k] = v
-        det = self.ah.Akazer()                       # hak_create re-reads the environment: restore the process-wide modes
-        det.init((128, 96, 128), max_pts=10)
-        det.close()
 
 
 def test_720p_batch64_default_kernel_selection_vs_oracle(ah, okz, torch, synth):
@@ -396,6 +395,67 @@ def test_parameter_space_vs_oracle(ah, okz, torch, synth, kw):
     r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
     assert len(r.points) > 10
     assert_points_equal(pts, r.points)
+
+
+LEVEL_TILE_CASES = [
+    # w, h, seed, parameters: odd extents (no 16-byte rows), every diffusivity, a 5-octave pyramid whose last octave runs FED cycles
+    # of 34 / 40 / 48 / 57 steps (more than one launch per sublevel: the continuation variant), upright, other pattern size
+    (211, 173, 12, {}),
+    (333, 251, 13, dict(diffusivity=0)),
+    (320, 240, 14, dict(diffusivity=2)),
+    (400, 300, 15, dict(diffusivity=3, upright=True)),
+    (1280, 1296, 16, dict(noctaves=5)),
+    (640, 360, 17, dict(noctaves=3, descriptor_pattern_size=8)),
+]
+
+
+@pytest.mark.parametrize("w,h,seed,kw", LEVEL_TILE_CASES, ids=lambda v: str(v))
+def test_level_tile_vs_oracle(ah, okz, torch, synth, monkeypatch, w, h, seed, kw):
+    """kernels_level.hip (one launch per sublevel out of LDS tiles: what single-image calls use) against the oracle, both pipelines"""
+    monkeypatch.setenv("HAK_LEVEL_TILE", "2")
+    u8 = _mg().case_scene(w, h, seed)
+    pts = gpu_detect(ah, torch, synth, u8, **kw)
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
+    assert len(r.points) > 10
+    assert_points_equal(pts, r.points)
+    # the integer FAST path through the same kernel template
+    p = ah.iAlignUp(w, 128)
+    pad = np.zeros((h, p), np.uint8)
+    pad[:, :w] = u8
+    img = torch.from_numpy(pad).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=10000, **kw)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, 10000, True, True)
+    det.fastDetectAndCompute(img.data_ptr(), data, (w, h, p), True)
+    rf = okz.fast_detect_and_compute(u8, okz.default_params(**okw))
+    assert_points_equal(data.h_data[:data.num_pts], rf.points)
+    ah.freeAkazeData(data)
+    det.close()
+
+
+def test_pinned_results_equal_pageable(ah, torch, synth):
+    """h_data in pinned host memory (what the C++ layer's initAkazeData hands out): records and count are written by the launch
+    sequence itself; they must equal the pageable route's, call after call, for both images of a pair and for an empty image"""
+    w, h, mp = 960, 540, 3000
+    p = ah.iAlignUp(w, 128)
+    a, b = synth.pair(w, h, 9)
+    imgs = [torch.from_numpy(synth.to_float(u, p)).cuda() for u in (a, b)] + [torch.full((h, p), 0.25, dtype=torch.float32, device="cuda")]
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=mp)
+    pin, pag = ah.AkazeData(), ah.AkazeData()
+    ah.initAkazeData(pin, mp, True, True, pinned=True)
+    ah.initAkazeData(pag, mp, True, True)
+    for rep in range(3):
+        for i, img in enumerate(imgs):
+            det.detectAndCompute(img.data_ptr(), pin, (w, h, p), True)
+            det.detectAndCompute(img.data_ptr(), pag, (w, h, p), True)
+            assert pin.num_pts == pag.num_pts and (pin.num_pts > 100 or i == 2)
+            assert pin.h_data[:pin.num_pts].tobytes() == pag.h_data[:pag.num_pts].tobytes()
+    assert pin.num_pts == 0                                    # the flat image came last
+    ah.freeAkazeData(pin); ah.freeAkazeData(pag)
+    det.close()
 
 
 def test_serial_equals_concurrent_streams(ah, torch, synth):
@@ -586,8 +646,10 @@ def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth):
     det.close()
 
 
-def test_fast_planes_small(ah, okz, torch):
+@pytest.mark.parametrize("level_tile", ["1", "2"], ids=["streaming kernels", "k_level_tile"])
+def test_fast_planes_small(ah, okz, torch, monkeypatch, level_tile):
     """every persistent int32 plane of every level of the FAST path, bit for bit (localises a failing stage)"""
+    monkeypatch.setenv("HAK_LEVEL_TILE", level_tile)
     w, h = 320, 240
     u8 = _mg().case_scene(w, h, 11)
     p = ah.iAlignUp(w, 128)
