@@ -43,6 +43,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _sub in ("cuda-akaze_amd", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, _sub))
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime initialises (akaze_hip/__init__.py says why)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402

@@ -12,6 +12,15 @@
 #include <string>
 #include <vector>
 
+// A single-image call keeps four launch chains in flight (enqueue_detect's spine + one side stream per remaining octave).  The
+// HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- four by default, one of them taken by
+// the null stream -- and two chains that share a queue run one after the other (C++ demo, ms per 1080p pair: 1.10 shared, 0.94 with
+// eight queues).  The variable is read when the runtime initialises, so it is set when the library is loaded, unless the host
+// application has already chosen a value (or has initialised HIP before loading us: then nothing changes, results never depend on it).
+namespace {
+struct HakQueueHint { HakQueueHint() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queue_hint;
+}
+
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
@@ -173,6 +182,7 @@ struct hak_ctx {
     bool concurrent = true;
     // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
     bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
+    int graph_mode = 1;             // HAK_GRAPH: 0 never, 1 replay except for launch-bound single-image sequences, 2 always
     struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; hak_point* hpts; };
     static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
     hipGraphExec_t graph_exec[NGRAPH] = {};
@@ -184,6 +194,7 @@ struct hak_ctx {
     double fed_fused_bytes = 0;     // compulsory HBM bytes per image of the FED launches as enqueued (read L [+ g], write L' [+ smooth, g])
     int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
     int fuse_head = 1;              // octave heads through the decimating k_fed_sf variant (env HAK_FUSE_HEAD=0 disables)
+    int level_min_steps = 8;        // shortest FED cycle that goes through k_level_tile under the size rule (env HAK_LEVEL_MIN_STEPS)
     int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
@@ -193,6 +204,7 @@ struct hak_ctx {
     HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
     hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
     hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
+    hipStream_t sync_stream = nullptr;                            // where the last detect sequence ends (c->stream unless it was left on the chain)
     bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
     bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
 };
@@ -336,6 +348,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (c->cfg.max_pts < 1) c->cfg.max_pts = 1;
     if (const char* e = getenv("HAK_FUSE_SF")) c->fuse_sf = atoi(e);
     if (const char* e = getenv("HAK_FUSE_HEAD")) c->fuse_head = atoi(e);
+    if (const char* e = getenv("HAK_LEVEL_MIN_STEPS")) c->level_min_steps = atoi(e);
     c->knobs = hak_knobs_from_env();
     if (const char* e = getenv("HAK_FED_MAX_FUSE")) {
         int v = atoi(e);
@@ -375,7 +388,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_done[o], hipEventDisableTiming);
     }
     if (const char* s = getenv("HAK_SERIAL")) c->concurrent = atoi(s) == 0;
-    if (const char* s = getenv("HAK_GRAPH")) c->use_graph = atoi(s) != 0;
+    if (const char* s = getenv("HAK_GRAPH")) { c->graph_mode = atoi(s); c->use_graph = c->graph_mode != 0; }
     if (e != hipSuccess) {
         fail(std::string("hak_create: ") + hipGetErrorString(e));
         hak_destroy(c);
@@ -449,7 +462,8 @@ static void maps_guard_begin(hak_ctx* c)
 static int maps_guard_end(hak_ctx* c, int rc)
 {
     if (!rc) c->maps_dirty = false;
-    if (c->ev_last) (void)hipEventRecord(c->ev_last, c->stream);
+    // (on the stream the sequence ended on: a marker on the caller's idle stream would make the next call's idle test fail)
+    if (c->ev_last) (void)hipEventRecord(c->ev_last, c->sync_stream ? c->sync_stream : c->stream);
     return rc;
 }
 
@@ -466,7 +480,10 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
+    // Octave o+1 depends only on Lt(o, 0) (the reference decimates from sublevel 0, akaze.cpp:371-375).
+    const bool spine = c->concurrent && L.noct > 1 && level_tile_pays(c, L.oct[0], nimg);
     const hipStream_t main_st = c->stream;
+    c->sync_stream = c->stream;
     float* A = c->arena;
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
@@ -489,8 +506,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             return;
         }
         const int n = lp.nsteps;
-        // small launches (single images, small octaves of small batches): the whole sublevel in one launch out of LDS tiles
-        if (level_tile_pays(c, oc, nimg)) {
+        // small launches (single images, small octaves of small batches): the whole sublevel in one launch out of LDS tiles --
+        // octave heads (one launch instead of decimation + conductivity + FED groups) and every cycle long enough that the tile
+        // kernel's halo work costs less than the launches it saves (by the size rule: n >= 8, i.e. octaves 2 and up of the demo
+        // schedule; shorter cycles keep k_smooth_flow + k_fed_multi, which spend less GPU time per pixel)
+        if (level_tile_pays(c, oc, nimg) && (s == 0 || n >= c->level_min_steps || c->knobs.level_tile == 2)) {
             ProfScope ps(c, HAK_PROF_FED, st);
             const int nl = hak_launch_level_tile(st, s == 0 ? A + L.lt(o - 1, 0) : A + L.lt(o, s - 1), s == 0 ? L.oct[o - 1] : oc, s == 0, smooth, Lt, tmp, S,
                                                  oc, nimg, c->taps1, cfg.diffusivity, lp.tau.data(), n, c->state, o, 0.f);
@@ -578,8 +598,6 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
 
     hak_launch_reset_state(main_st, c->state, nimg);   // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
 
-    // Octave o+1 depends only on Lt(o, 0) (the reference decimates from sublevel 0, akaze.cpp:371-375).
-    const bool spine = c->concurrent && L.noct > 1 && level_tile_pays(c, L.oct[0], nimg);
     if (spine) {
         // Launch-bound calls (a single image): the dependency chain base -> head(1) -> head(2) -> ... -> every sublevel of the
         // last octave is the critical path, so it runs on ONE stream without cross-queue waits (each costs 15-35 us in a replayed
@@ -649,10 +667,13 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
             for (int o = 1; o < L.noct; o++)
                 if (hipStreamWaitEvent(main_st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
     }
+    bool tail_fork = false;
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455
       hak_launch_nms_emit(main_st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts);
       // the clean-up for the next sequence needs only the candidate list: beside the descriptor kernels, not in front of them
-      if (c->concurrent && L.noct > 1) {
+      static const bool tail_fork_on = [] { const char* e = getenv("HAK_TAIL_FORK"); return !e || atoi(e) != 0; }();
+      tail_fork = spine && tail_fork_on;         // (batches: no gain beside 5 ms of descriptor kernels, A/B 5 640 vs 5 710 pairs/s)
+      if (tail_fork) {
           (void)hipEventRecord(c->ev_tail_fork, main_st);
           if (hipStreamWaitEvent(c->oct_stream[1], c->ev_tail_fork, 0) != hipSuccess) return fail("stream wait");
           hak_launch_clear_maps(c->oct_stream[1], b, L);
@@ -662,7 +683,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
       hak_launch_describe(main_st, b, L, c->dtab, d_points, max_pts, cfg.descriptor_pattern_size, cfg.upright, desc, c->htab.dsc_plan_ok); }
     if (h_points)                                                                 // pinned destination: records and count go out in the same sequence
         hak_launch_download(main_st, d_points, d_num_pts, max_pts, nimg, h_points, c->h_num);
-    if (c->concurrent && L.noct > 1 && hipStreamWaitEvent(main_st, c->ev_tail_join, 0) != hipSuccess) return fail("stream join");
+    if (tail_fork && hipStreamWaitEvent(main_st, c->ev_tail_join, 0) != hipSuccess) return fail("stream join");
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
     return 0;
 }
@@ -680,6 +701,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
     const int idthreshold = 65;                                                   // akaze.cpp:559
     c->last_fast = true;
+    c->sync_stream = c->stream;
     hakf_launch_reset(st, c->state, nimg);              // (the key map is all zero here: hak_create / k_clear_cand_maps / maps_guard)
     for (int o = 0; o < L.noct; o++) {
         const HakOct oc = L.oct[o];
@@ -804,7 +826,11 @@ static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int 
 static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
                             hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned)
 {
-    if (!c->use_graph || c->prof_on)
+    // A launch-bound sequence (single images: the spine order of enqueue_detect) is issued eagerly: with ~50 launches on four
+    // streams the host keeps ahead of the GPU, and the graph replay of ROCm 7.2 submits queue by queue in an order of its own
+    // (measured on the C++ demo, ms per 1080p pair: eager 1.18, replay 1.31; HAK_GRAPH=2 forces the replay).
+    const bool launch_bound = c->concurrent && c->L.noct > 1 && level_tile_pays(c, c->L.oct[0], nimg);
+    if (!c->use_graph || c->prof_on || (launch_bound && c->graph_mode != 2))
         return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
     hak_ctx::GraphKey key;
     memset(&key, 0, sizeof(key));
@@ -870,8 +896,8 @@ extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitc
     // (akaze.cpp:134-139): count first, then a copy of the valid records.
     hak_point* h_pinned = host_pinned(h_points) ? h_points : nullptr;
     if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts, h_pinned)) return 1;
-    if (!h_pinned) HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!h_pinned) HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->sync_stream));
+    HIP_TRY(hipStreamSynchronize(c->sync_stream));
     *num_pts = c->h_num[0];
     if (h_points && !h_pinned && *num_pts > 0)                                    // akaze.cpp:134-139
         HIP_TRY(hipMemcpy(h_points, d_points, sizeof(hak_point) * (size_t)*num_pts, hipMemcpyDeviceToHost));
@@ -1328,6 +1354,7 @@ extern "C" int hak_op_tail_begin(hak_ctx* c)
 {
     if (!c) return fail("null context");
     c->last_fast = false;
+    c->sync_stream = c->stream;
     maps_guard_begin(c);                                            // (stays set until hak_op_tail_finish has cleaned the map)
     hak_launch_reset_state(c->stream, c->state, 1);
     HIP_TRY(hipStreamSynchronize(c->stream));
@@ -1417,6 +1444,20 @@ extern "C" int hak_op_copy_probe(long bytes, int iters, double* gbytes_per_s)
     if (hak_launch_copy_probe(bytes, iters, &ms) || ms <= 0) return fail("copy probe failed");
     *gbytes_per_s = 2.0 * (double)bytes / (ms * 1e-3) / 1e9;                      // read + write
     return 0;
+}
+
+extern "C" int hak_op_copy_probe_shapes(long bytes, int iters, double* gbytes_per_s, int n)
+{
+    if (bytes < 16 || iters < 1 || !gbytes_per_s || n < HAK_COPY_SHAPES) return fail("bad probe argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    bytes &= ~15L;
+    double best = 0, ms[HAK_COPY_SHAPES] = {};
+    if (hak_launch_copy_probe(bytes, iters, &best, ms)) return fail("copy probe failed");
+    for (int i = 0; i < HAK_COPY_SHAPES; i++) {
+        const double moved = i < HAK_COPY_SHAPES - 2 ? 2.0 * (double)bytes : (double)bytes;     // copy: read + write
+        gbytes_per_s[i] = ms[i] > 0 ? moved / (ms[i] * 1e-3) / 1e9 : 0.0;
+    }
+    return HAK_COPY_SHAPES;
 }
 
 extern "C" int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch)

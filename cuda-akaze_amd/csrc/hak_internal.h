@@ -42,6 +42,7 @@ struct HakImgState {
     int ncand;                                  // entries in the image's extrema candidate list
     int total_pts;                              // NMS survivors before clamping to max_pts
     int num_pts;                                // min(total, max_pts)
+    int hist_done;                              // blocks of the histogram pass that have added their bins (the last one finishes the contrast factor)
 };
 
 // Read-only tables shared by all images of a context.
@@ -398,7 +399,8 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
                          hak_point* points, int max_pts, int patsize, int upright, int desc, int planned, int orient = 1);
 
 // bandwidth probes (kernels_probe.hip)
-int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy);
+#define HAK_COPY_SHAPES 26                  // 3 x 2 x 4 copy shapes + read-only + write-only (kernels_probe.hip)
+int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy, double* shapes_ms = nullptr);
 int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
 
 // matcher (kernels_match.hip)

@@ -211,10 +211,35 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
 // ---- pass B': the same histogram from the gradient plane pass A left behind (4 B/px read, no recomputation)
 #define HIST_COPIES 8          // private LDS histograms per block, selected by lane: smooth images put most pixels into a few
                                 // bins, and LDS atomics on one address serialise
+// host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371) and ikc = 1/(k*k)
+// (akazed.cu:2493), kept on the device.  hist_words: the image's 300 bins (global memory, or an LDS copy fetched coherently).
+__device__ __forceinline__ void hak_finish_kcontrast(HakImgState* st, const int* hist_words, int npix, float per, int noct)
+{
+    auto hist = [&](int k) { return hist_words[k]; };
+    const float hmax = __uint_as_float(st->hmax_bits);
+    const float hfactor = HAK_NBINS / hmax;
+    int thresh = (int)((npix - hist(0)) * per);
+    int cumuv = 0, k = 1;
+    while (k < HAK_NBINS) {
+        if (cumuv >= thresh) break;
+        cumuv += hist(k);
+        k++;
+    }
+    float kc = k / hfactor;
+    for (int o = 0; o < noct; o++) {
+        if (o > 0) kc *= 0.75f;
+        st->kcontrast[o] = kc;
+        st->ikc[o] = 1.f / (kc * kc);
+    }
+}
+
+// noct > 0: the block that adds its bins last also finishes the contrast factor (one launch less on the critical chain of a
+// single-image call); noct == 0: histogram only (k_kcontrast2 follows)
 __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict__ grad, long stride, int w, int h, int p,
-                                                         HakImgState* state, int rows_per_block)
+                                                         HakImgState* state, int rows_per_block, float per, int noct)
 {
     __shared__ int shist[HIST_COPIES * HAK_NBINS];
+    __shared__ int last_block;
     const int im = blockIdx.y;
     const float* g0 = grad + (long)im * stride;
     const int tid = threadIdx.x;
@@ -246,29 +271,27 @@ __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict
         for (int c = 0; c < HIST_COPIES; c++) sum += shist[c * HAK_NBINS + i];
         if (sum) atomicAdd(&state[im].hist[i], sum);
     }
+    if (noct > 0) {
+        __threadfence();                                            // this block's bins are visible before its ticket is
+        __syncthreads();
+        if (tid == 0) last_block = atomicAdd(&state[im].hist_done, 1) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (last_block) {
+            // every other block's bins have landed in L2 (their fences precede their tickets); fetch the 300 words past this CU's
+            // L1 -- which may hold a stale line of the state record -- with all lanes at once, then scan them from LDS
+            __threadfence();
+            for (int i = tid; i < HAK_NBINS; i += 256)
+                shist[i] = __hip_atomic_load(&state[im].hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid == 0) hak_finish_kcontrast(state + im, shist, w * h, per, noct);
+        }
+    }
 }
 
-// host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371)
-// and ikc = 1/(k*k) (akazed.cu:2493), kept on the device
 __global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
 {
-    HakImgState* st = state + blockIdx.x;
     if (threadIdx.x != 0) return;
-    const float hmax = __uint_as_float(st->hmax_bits);
-    const float hfactor = HAK_NBINS / hmax;
-    int thresh = (int)((npix - st->hist[0]) * per);
-    int cumuv = 0, k = 1;
-    while (k < HAK_NBINS) {
-        if (cumuv >= thresh) break;
-        cumuv += st->hist[k];
-        k++;
-    }
-    float kc = k / hfactor;
-    for (int o = 0; o < noct; o++) {
-        if (o > 0) kc *= 0.75f;
-        st->kcontrast[o] = kc;
-        st->ikc[o] = 1.f / (kc * kc);
-    }
+    hak_finish_kcontrast(state + blockIdx.x, state[blockIdx.x].hist, npix, per, noct);
 }
 
 // img -> Lt(0,0) and the per-image contrast factors.  Returns false when R is not supported here.
@@ -299,7 +322,10 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     if (grad_scratch) {
         int rpb = 8;
         while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < 2048) rpb >>= 1;
-        k_grad_hist_plane<<<dim3((h + rpb - 1) / rpb, nimg), 256, 0, st>>>(grad_scratch, stride, w, h, p, state, rpb);
+        // (noct = 0: the contrast factor stays a launch of its own.  Letting the last histogram block finish it was measured:
+        // the fence every block then needs behind its ~300 bin atomics, which are otherwise fire-and-forget, took the kernel from
+        // 22 to 73 us on a single 1080p image -- far more than the launch it saves)
+        k_grad_hist_plane<<<dim3((h + rpb - 1) / rpb, nimg), 256, 0, st>>>(grad_scratch, stride, w, h, p, state, rpb, per, 0);
     } else {
         k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb, ntx, nby, nimg);
     }

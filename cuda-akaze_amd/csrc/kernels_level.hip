@@ -177,8 +177,9 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
     // the largest tile (multiple of 8, at most 64) whose three planes fit the LDS budget
     int T = 64;
     while (T > 8 && 3L * (T + 2 * (ns + 3)) * (T + 2 * (ns + 3)) > LV_LDS_FLOATS) T -= 8;
-    // ... but not so large that a small plane leaves most CUs idle
-    while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 256) T -= 8;
+    // ... but not so large that a small plane runs on a handful of CUs.  Smaller tiles mean more halo work in total (the planes are
+    // (T + 2 ns + 6)^2): ~100 blocks keep a block short without multiplying the work of the octaves that run beside the critical chain
+    while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 96) T -= 8;
     const int E = T + 2 * (ns + 3);
     const size_t lds = sizeof(V) * 3 * (size_t)E * E;
     static bool attr_done = false;                           // (per instantiation: each has its own static)

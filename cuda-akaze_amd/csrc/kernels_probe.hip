@@ -8,20 +8,43 @@
 //                   (MI355X_MICROARCH.md: only 16 B/lane streams are calibrated).
 #include "fed_common.h"
 
-template <int NI>
+// NI independent 16-byte loads in flight per lane and iteration; NT: non-temporal stores (the streaming kernels' own) or plain ones
+template <int NI, bool NT>
 __global__ __launch_bounds__(256) void k_copy_probe(const float4* __restrict__ src, float4* __restrict__ dst, long n4)
 {
     const long stride = (long)gridDim.x * 256 * NI;
     long i = (long)blockIdx.x * 256 * NI + threadIdx.x;
-    // NI independent 16-byte loads in flight per lane and iteration
     for (; i + 256 * (NI - 1) < n4; i += stride) {
         float4 v[NI];
 #pragma unroll
         for (int j = 0; j < NI; j++) v[j] = src[i + 256 * j];
 #pragma unroll
-        for (int j = 0; j < NI; j++) hak_store_nt(dst + i + 256 * j, v[j]);
+        for (int j = 0; j < NI; j++) {
+            if (NT) hak_store_nt(dst + i + 256 * j, v[j]);
+            else dst[i + 256 * j] = v[j];
+        }
     }
-    for (; i < n4; i += 256) hak_store_nt(dst + i, src[i]);
+    for (; i < n4; i += 256) dst[i] = src[i];
+}
+
+// read-only and write-only streams of the same shape (what each direction reaches alone)
+__global__ __launch_bounds__(256) void k_read_probe(const float4* __restrict__ src, float4* __restrict__ sink, long n4)
+{
+    const long stride = (long)gridDim.x * 256 * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (long i = (long)blockIdx.x * 256 * 4 + threadIdx.x; i + 768 < n4; i += stride) {
+        const float4 a = src[i], b = src[i + 256], c = src[i + 512], d = src[i + 768];
+        acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y; acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w;
+    }
+    if (acc.x == 123.456f) sink[0] = acc;                   // keeps the loads alive; never true for the constant fill
+}
+__global__ __launch_bounds__(256) void k_write_probe(float4* __restrict__ dst, long n4)
+{
+    const long stride = (long)gridDim.x * 256 * 4;
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (long i = (long)blockIdx.x * 256 * 4 + threadIdx.x; i + 768 < n4; i += stride) {
+        hak_store_nt(dst + i, v); hak_store_nt(dst + i + 256, v); hak_store_nt(dst + i + 512, v); hak_store_nt(dst + i + 768, v);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_gather_probe(const unsigned* __restrict__ src, unsigned* __restrict__ sink, long nlines, int per_lane)
@@ -50,8 +73,10 @@ static int probe_time(hipEvent_t a, hipEvent_t b, int iters, double* ms)
     return 0;
 }
 
-// copies `bytes` (a multiple of 16) `iters` times; *ms_per_copy = average duration of one copy kernel
-int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy)
+// Copies `bytes` (a multiple of 16) `iters` times per launch shape; *ms_per_copy = average duration of one copy kernel of the
+// BEST shape.  shapes_ms (nullable, HAK_COPY_SHAPES entries): every shape's figure, then read-only and write-only.
+// Shapes: loads in flight per lane {2, 4, 8} x stores {nt, plain} x grid {8, 16, 32 blocks per CU, one pass (no loop)}.
+int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy, double* shapes_ms)
 {
     float4 *s = nullptr, *d = nullptr;
     if (hipMalloc((void**)&s, (size_t)bytes) != hipSuccess) return 1;
@@ -60,22 +85,35 @@ int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy)
     const long n4 = bytes / 16;
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    // the ceiling is the best of a few launch shapes (loads in flight per lane x blocks per CU)
     double best = 0;
     int rc = 0;
-    for (int shape = 0; shape < 6 && !rc; shape++) {
-        const unsigned grid = 256u * (shape % 3 == 0 ? 8 : shape % 3 == 1 ? 16 : 32);
-        auto launch = [&]() {
-            if (shape < 3) k_copy_probe<4><<<grid, 256>>>(s, d, n4);
-            else k_copy_probe<8><<<grid, 256>>>(s, d, n4);
-        };
+    auto timed = [&](auto launch, double* out) {
         launch();                                           // warm-up (page tables, clocks)
         (void)hipEventRecord(a, nullptr);
         for (int i = 0; i < iters; i++) launch();
         (void)hipEventRecord(b, nullptr);
         double ms = 0;
         rc = probe_time(a, b, iters, &ms) || hipGetLastError() != hipSuccess;
+        if (!rc && out) *out = ms;
+        return ms;
+    };
+    for (int shape = 0; shape < HAK_COPY_SHAPES - 2 && !rc; shape++) {
+        const int ni = 2 << (shape % 3);                    // 2, 4, 8
+        const bool nt = (shape / 3) % 2 == 0;
+        const int gsel = shape / 6;                         // 0..3
+        const long one_pass = (n4 + 256L * ni - 1) / (256L * ni);
+        const unsigned grid = gsel == 3 ? (unsigned)(one_pass < 0x7FFFFFFFL ? one_pass : 0x7FFFFFFFL) : 256u * (8u << gsel);
+        auto launch = [&]() {
+            if (ni == 2) { if (nt) k_copy_probe<2, true><<<grid, 256>>>(s, d, n4); else k_copy_probe<2, false><<<grid, 256>>>(s, d, n4); }
+            else if (ni == 4) { if (nt) k_copy_probe<4, true><<<grid, 256>>>(s, d, n4); else k_copy_probe<4, false><<<grid, 256>>>(s, d, n4); }
+            else { if (nt) k_copy_probe<8, true><<<grid, 256>>>(s, d, n4); else k_copy_probe<8, false><<<grid, 256>>>(s, d, n4); }
+        };
+        const double ms = timed(launch, shapes_ms ? shapes_ms + shape : nullptr);
         if (!rc && (best == 0 || ms < best)) best = ms;
+    }
+    if (!rc && shapes_ms) {
+        timed([&]() { k_read_probe<<<256u * 16u, 256>>>(s, d, n4); }, shapes_ms + HAK_COPY_SHAPES - 2);
+        timed([&]() { k_write_probe<<<256u * 16u, 256>>>(d, n4); }, shapes_ms + HAK_COPY_SHAPES - 1);
     }
     *ms_per_copy = best;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256) void k_reset_state(HakImgState* state)
         st->ncand = 0;
         st->total_pts = 0;
         st->num_pts = 0;
+        st->hist_done = 0;
     }
 }
 

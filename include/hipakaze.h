@@ -261,12 +261,16 @@ int hak_op_tail_finish(hak_ctx* ctx, hak_point* d_points, int max_pts, int refin
 int hak_op_orient_describe(hak_ctx* ctx, hak_point* d_points, int n, int desc);
 
 /* ---- bandwidth ceilings of the box (SURVEY 8d "copy-kernel ceiling"; not on the hot path).
- * hak_op_copy_probe: float4 copy of `bytes` with the streaming kernels' access shape (16 B/lane, nt stores), `iters`
- * times; *gbytes_per_s = (read + write bytes) / average kernel time.
+ * hak_op_copy_probe: float4 copy of `bytes` with the streaming kernels' access shape (16 B/lane), `iters` times per launch
+ * shape (24 shapes: loads in flight, nt / plain stores, grid size); *gbytes_per_s = (read + write bytes) / average kernel
+ * time of the best shape.
  * hak_op_gather_probe: `blocks` x 256 lanes each gather `per_lane` dwords from pseudo-random 128-byte lines of a
  * `bytes`-sized buffer (the descriptor's access shape), `iters` times; *ms_per_launch = average kernel time.  Used to
  * calibrate the FETCH_SIZE counter for 4-byte gathers. */
 int hak_op_copy_probe(long bytes, int iters, double* gbytes_per_s);
+/* every launch shape of the probe: entry (g * 6 + s * 3 + l) = grid g {8, 16, 32 blocks per CU, one pass} x stores s {nt, plain} x
+ * loads in flight per lane l {2, 4, 8}; then the read-only and the write-only stream.  Returns the number of entries (26). */
+int hak_op_copy_probe_shapes(long bytes, int iters, double* gbytes_per_s, int n);
 int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
 
 #ifdef __cplusplus

@@ -12,7 +12,11 @@ run() {
   echo "$tag: $best"
 }
 run "default                         "
-run "HAK_GRAPH_PADS=0                " HAK_GRAPH_PADS=0
+run "HAK_GRAPH=2 (replay)            " HAK_GRAPH=2
+run "GPU_MAX_HW_QUEUES=8             " GPU_MAX_HW_QUEUES=8
+run "HAK_LEVEL_MIN_STEPS=1           " HAK_LEVEL_MIN_STEPS=1
+run "HAK_LEVEL_MIN_STEPS=5           " HAK_LEVEL_MIN_STEPS=5
+run "HAK_LEVEL_MIN_STEPS=12          " HAK_LEVEL_MIN_STEPS=12
 run "HAK_LEVEL_TILE=0 (round-2 path) " HAK_LEVEL_TILE=0
 run "HAK_SERIAL=1                    " HAK_SERIAL=1
 run "HAK_GRAPH=0 (eager launches)    " HAK_GRAPH=0
