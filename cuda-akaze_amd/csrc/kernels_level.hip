@@ -11,7 +11,7 @@
 // (profiles/r03_single_*): 94 launches per 1080p image, 72 of them the tile-path's low-pass / conductivity / <= 4-step FED
 // kernels of sixteen sublevels.  Here a 1024-thread block owns a TxT tile and keeps it in LDS with a halo as deep as the
 // number of explicit steps (<= 36): raw L, sigma=1 low-pass, conductivity and ALL steps of the FED cycle run out of LDS, the
-// valid window shrinking by one pixel per step.  One launch per sublevel: 94 -> 43 launches per image.
+// valid window shrinking by one pixel per step; a thread works on four pixels of a row at a time (16-byte LDS accesses).  One launch per sublevel: 94 -> 43 launches per image.
 //
 // Bit-exactness: every expression is the reference's (and the oracle's) own -- no regrouping: the separable Gaussian through
 // sf_conv, the Scharr / conductivity of k_smooth_flow, and  step = tE + tW + tS + tN  then  fma(stepfac, step, L)  with the
@@ -22,7 +22,7 @@
 
 #define LV_MAX_STEPS 36
 #define LV_NT 1024                    // threads per block: four waves per SIMD hide the LDS latency of the per-pixel loops
-#define LV_LDS_FLOATS 38400          // 150 KB of the CU's 160 KB: three planes of (T + 2 * (ns + 3))^2 elements
+#define LV_LDS_FLOATS 38400          // 150 KB of the CU's 160 KB: three planes of (T + 2 HX) x (T + 2 (ns + 3)) elements
 
 template <typename V> struct LvFacs { V f[LV_MAX_STEPS]; };
 
@@ -51,116 +51,189 @@ __device__ __forceinline__ float lv_conductivity(V dx, V dy, float ikc, int type
     return 1.f / sqrtf(1.f + dif2);
 }
 
+// ---- four pixels per thread: a thread owns one 16-byte group of a plane row per item, so a stencil row costs one ds_read_b128
+// plus the two edge words instead of six ds_read_b32, and the index arithmetic is paid once per four pixels (the scalar version
+// spent ~60 VALU instructions per pixel-step, most of them addressing)
+template <typename V> struct Lv6 { V v[6]; };                // columns c-1 .. c+4 of one plane row
+template <typename V>
+__device__ __forceinline__ Lv6<V> lv_row6(const V* row, int c)
+{
+    using V4 = typename FedV<V>::V4;
+    const V4 q = *reinterpret_cast<const V4*>(row + c);
+    Lv6<V> o;
+    o.v[0] = row[c - 1]; o.v[1] = q.x; o.v[2] = q.y; o.v[3] = q.z; o.v[4] = q.w; o.v[5] = row[c + 4];
+    return o;
+}
+// reflect-101 in x on the image extents (abs(x - 1), borderAdd(x, 1, w)): pixel j of the group sits at image column x0 + j
+template <typename V> __device__ __forceinline__ V lv_left(const Lv6<V>& r, int j, int x0) { return x0 + j == 0 ? r.v[j + 2] : r.v[j]; }
+template <typename V> __device__ __forceinline__ V lv_right(const Lv6<V>& r, int j, int x0, int w) { return x0 + j == w - 1 ? r.v[j] : r.v[j + 2]; }
+
 // HEAD: src = L(o-1, 0) of the previous octave (extents sw x sh, pitch sp); else src = L(o, s-1) of this octave.
 // FIRST = false continues a cycle of more than LV_MAX_STEPS steps: L comes from src, the low-pass from `smooth`.
+// Planes: EH = T + 2 (ns + 3) rows of EW = T + 2 HX elements, HX = ns + 5 rounded up to 4: image column X0 + c of plane column c
+// is a multiple of 4 for every group, so interior groups load and store 16 bytes at once.
 template <typename V, bool HEAD, bool FIRST>
 __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src, V* __restrict__ smooth, V* __restrict__ dst,
-                                                    long stride, int sw, int sh, int sp, int w, int h, int p,
-                                                    SfTaps<V> t, int type, const HakImgState* __restrict__ state, int octave,
-                                                    float fixed_ikc, LvFacs<V> fac, int ns, int T, int nbx, int nby, int nimg)
+                                                      long stride, int sw, int sh, int sp, int w, int h, int p,
+                                                      SfTaps<V> t, int type, const HakImgState* __restrict__ state, int octave,
+                                                      float fixed_ikc, LvFacs<V> fac, int ns, int T, int nbx, int nby, int nimg)
 {
+    using V4 = typename FedV<V>::V4;
     extern __shared__ __align__(16) unsigned char lv_lds_raw[];
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
     const int H = ns;                                        // FED halo
-    const int E = T + 2 * (H + 3);                           // plane edge (raw region: core +- (H + 3))
+    // rows: raw region core +- (H + 3).  columns: the phases work on whole groups and skip the first and last one, so the smooth
+    // plane is valid from plane column 4 and g from column 5: the FED halo needs HX - H >= 5, rounded up to whole groups
+    const int HY = H + 3, HX = (H + 5 + 3) & ~3;
+    const int EW = T + 2 * HX, EH = T + 2 * HY, NG = EW >> 2;
     V* A = reinterpret_cast<V*>(lv_lds_raw);                 // raw = L0, then L ping
-    V* B = A + E * E;                                        // row pass, then g
-    V* C = B + E * E;                                        // smooth, then L pong
+    V* B = A + EW * EH;                                      // row pass, then g
+    V* C = B + EW * EH;                                      // smooth, then L pong
     const V* s = src + (long)img * stride;
     V* osm = smooth + (long)img * stride;
     V* od = dst + (long)img * stride;
     const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
     const int tid = threadIdx.x;
-    const int X0 = bx * T - (H + 3), Y0 = by * T - (H + 3);  // image coordinates of plane element (0, 0)
-    // idx / E by one multiply-high: M = ceil(2^32 / E) is exact for idx < 2^14 and E <= 128 (idx * (M * E - 2^32) < 2^32 / E)
-    const unsigned ME = 0xFFFFFFFFu / (unsigned)E + 1u;
+    const int X0 = bx * T - HX, Y0 = by * T - HY;            // image coordinates of plane element (0, 0)
+    // idx / NG by one multiply-high: M = ceil(2^32 / NG) is exact for idx < 2^14 and NG <= 64 (idx * (M * NG - 2^32) < 2^32 / NG)
+    const unsigned MG = 0xFFFFFFFFu / (unsigned)NG + 1u;
+    const int nitems = EH * NG;
 
-    // ---- raw plane (A): L0 with mirrored indices
-    for (int idx = tid; idx < E * E; idx += LV_NT) {
-        const int r = (int)__umulhi((unsigned)idx, ME), c = idx - r * E;
-        V v;
-        if (HEAD && FIRST) v = s[(long)lv_src_index(Y0 + r, sh) * sp + lv_src_index(X0 + c, sw)];
-        else v = s[(long)hak_refl(Y0 + r, h) * p + hak_refl(X0 + c, w)];
-        A[idx] = v;
+    // ---- raw plane (A): L0 with mirrored indices (on the source extents for an octave head)
+    for (int idx = tid; idx < nitems; idx += LV_NT) {
+        const int r = (int)__umulhi((unsigned)idx, MG), c = (idx - r * NG) << 2;
+        const int x = X0 + c, y = Y0 + r;
+        V4 v;
+        if (HEAD && FIRST) {
+            const V* row = s + (long)lv_src_index(y, sh) * sp;
+            v = mk4(row[lv_src_index(x, sw)], row[lv_src_index(x + 1, sw)], row[lv_src_index(x + 2, sw)], row[lv_src_index(x + 3, sw)]);
+        } else {
+            const V* row = s + (long)hak_refl(y, h) * p;
+            if (x >= 0 && x + 3 < w) v = *reinterpret_cast<const V4*>(row + x);
+            else v = mk4(row[hak_refl(x, w)], row[hak_refl(x + 1, w)], row[hak_refl(x + 2, w)], row[hak_refl(x + 3, w)]);
+        }
+        *reinterpret_cast<V4*>(A + r * EW + c) = v;
     }
     if (FIRST) {
         hak_lds_barrier();
-        // ---- row pass (akazed.cu:227-239 / 469-471) into B: all rows, columns 2 .. E-3
-        for (int idx = tid; idx < E * E; idx += LV_NT) {
-            const int r = (int)__umulhi((unsigned)idx, ME), c = idx - r * E;
-            if (c >= 2 && c < E - 2) {
-                const V* q = A + idx;
-                B[idx] = sf_conv(q[0], q[-1], q[1], q[-2], q[2], t);
+        // ---- row pass (akazed.cu:227-239 / 469-471) into B: all rows, groups 1 .. NG-2
+        for (int idx = tid; idx < nitems; idx += LV_NT) {
+            const int r = (int)__umulhi((unsigned)idx, MG), g = idx - r * NG, c = g << 2;
+            if (g >= 1 && g < NG - 1) {
+                const V* q = A + r * EW + c;
+                const V4 l = *reinterpret_cast<const V4*>(q - 4), m = *reinterpret_cast<const V4*>(q), rr = *reinterpret_cast<const V4*>(q + 4);
+                *reinterpret_cast<V4*>(B + r * EW + c) = mk4(sf_conv(m.x, l.w, m.y, l.z, m.z, t), sf_conv(m.y, m.x, m.z, l.w, m.w, t),
+                                                            sf_conv(m.z, m.y, m.w, m.x, rr.x, t), sf_conv(m.w, m.z, rr.x, m.y, rr.y, t));
             }
         }
         hak_lds_barrier();
         // ---- column pass (akazed.cu:283-288 / 507-509) into C = smooth on core +- (H + 1); the core goes to HBM
-        for (int idx = tid; idx < E * E; idx += LV_NT) {
-            const int r = (int)__umulhi((unsigned)idx, ME), c = idx - r * E;
-            if (r >= 2 && r < E - 2 && c >= 2 && c < E - 2) {
-                const V* q = B + idx;
-                const V ws = sf_conv(q[0], q[-E], q[E], q[-2 * E], q[2 * E], t);
-                C[idx] = ws;
+        for (int idx = tid; idx < nitems; idx += LV_NT) {
+            const int r = (int)__umulhi((unsigned)idx, MG), g = idx - r * NG, c = g << 2;
+            if (r >= 2 && r < EH - 2 && g >= 1 && g < NG - 1) {
+                const V* q = B + r * EW + c;
+                const V4 m = *reinterpret_cast<const V4*>(q), u1 = *reinterpret_cast<const V4*>(q - EW), d1 = *reinterpret_cast<const V4*>(q + EW);
+                const V4 u2 = *reinterpret_cast<const V4*>(q - 2 * EW), d2 = *reinterpret_cast<const V4*>(q + 2 * EW);
+                const V4 ws = mk4(sf_conv(m.x, u1.x, d1.x, u2.x, d2.x, t), sf_conv(m.y, u1.y, d1.y, u2.y, d2.y, t),
+                                  sf_conv(m.z, u1.z, d1.z, u2.z, d2.z, t), sf_conv(m.w, u1.w, d1.w, u2.w, d2.w, t));
+                *reinterpret_cast<V4*>(C + r * EW + c) = ws;
                 const int x = X0 + c, y = Y0 + r;
-                if (r >= H + 3 && r < H + 3 + T && c >= H + 3 && c < H + 3 + T && x < w && y < h) osm[(long)y * p + x] = ws;
+                if (r >= HY && r < HY + T && c >= HX && c < HX + T && y < h) {
+                    V* o = osm + (long)y * p + x;
+                    if (x + 3 < w) *reinterpret_cast<V4*>(o) = ws;
+                    else {
+                        if (x < w) o[0] = ws.x;
+                        if (x + 1 < w) o[1] = ws.y;
+                        if (x + 2 < w) o[2] = ws.z;
+                    }
+                }
             }
         }
     } else {
         // continuation: the low-pass of this sublevel was written by the first launch of the cycle
-        for (int idx = tid; idx < E * E; idx += LV_NT) {
-            const int r = (int)__umulhi((unsigned)idx, ME), c = idx - r * E;
-            C[idx] = osm[(long)hak_refl(Y0 + r, h) * p + hak_refl(X0 + c, w)];
+        for (int idx = tid; idx < nitems; idx += LV_NT) {
+            const int r = (int)__umulhi((unsigned)idx, MG), c = (idx - r * NG) << 2;
+            const int x = X0 + c;
+            const V* row = osm + (long)hak_refl(Y0 + r, h) * p;
+            *reinterpret_cast<V4*>(C + r * EW + c) = mk4(row[hak_refl(x, w)], row[hak_refl(x + 1, w)], row[hak_refl(x + 2, w)], row[hak_refl(x + 3, w)]);
         }
     }
     hak_lds_barrier();
-    // ---- conductivity (akazed.cu:1078-1106) into B on core +- H, in-image pixels only, neighbours at reflect-101 indices
-    for (int idx = tid; idx < E * E; idx += LV_NT) {
-        const int r = (int)__umulhi((unsigned)idx, ME), c = idx - r * E;
+    // ---- conductivity (akazed.cu:1078-1106) into B on core +- H (whole groups), neighbours at reflect-101 indices.
+    // (pixels outside the image or outside core +- H get values nobody reads)
+    for (int idx = tid; idx < nitems; idx += LV_NT) {
+        const int r = (int)__umulhi((unsigned)idx, MG), g = idx - r * NG, c = g << 2;
         const int x = X0 + c, y = Y0 + r;
-        if (r >= 3 && r < E - 3 && c >= 3 && c < E - 3 && x >= 0 && x < w && y >= 0 && y < h) {
-            const int cl_ = c + (x == 0 ? 1 : -1), cr_ = c + (x == w - 1 ? -1 : 1);       // abs(x - 1), borderAdd(x, 1, w)
-            const int ru = (r + (y == 0 ? 1 : -1)) * E, rl = (r + (y == h - 1 ? -1 : 1)) * E, rc = r * E;
-            const V ul = C[ru + cl_], uc = C[ru + c], ur = C[ru + cr_];
-            const V cl = C[rc + cl_], cr = C[rc + cr_];
-            const V ll = C[rl + cl_], lc = C[rl + c], lr = C[rl + cr_];
-            const V dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
-            const V dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
-            B[idx] = sf_g_as<V>(lv_conductivity<V>(dx, dy, ikc, type));
+        if (r >= 3 && r < EH - 3 && g >= 1 && g < NG - 1 && y >= 0 && y < h) {
+            const Lv6<V> U = lv_row6<V>(C + (r + (y == 0 ? 1 : -1)) * EW, c);
+            const Lv6<V> M = lv_row6<V>(C + r * EW, c);
+            const Lv6<V> D = lv_row6<V>(C + (r + (y == h - 1 ? -1 : 1)) * EW, c);
+            V gq[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const V ul = lv_left(U, j, x), uc = U.v[j + 1], ur = lv_right(U, j, x, w);
+                const V cl = lv_left(M, j, x), cr = lv_right(M, j, x, w);
+                const V ll = lv_left(D, j, x), lc = D.v[j + 1], lr = lv_right(D, j, x, w);
+                const V dx = 10 * (cr - cl) + 3 * (ur + lr - ul - ll);
+                const V dy = 10 * (lc - uc) + 3 * (ll + lr - ul - ur);
+                gq[j] = sf_g_as<V>(lv_conductivity<V>(dx, dy, ikc, type));
+            }
+            *reinterpret_cast<V4*>(B + r * EW + c) = mk4(gq[0], gq[1], gq[2], gq[3]);
         }
     }
     hak_lds_barrier();
-    // ---- ns explicit steps (akazed.cu:1241-1264), ping-pong A <-> C; step k is valid on core +- (ns - k)
+    // ---- ns explicit steps (akazed.cu:1241-1264), ping-pong A <-> C; step k is valid on core +- (ns - k).  A step works on the
+    // whole groups that cover its window: the few pixels beyond it are computed from values that are no longer valid and
+    // written where no valid pixel of a later step looks (window k+1 +- 1 lies inside window k).
     V* cur = A;
     V* nxt = C;
     for (int k = 1; k <= ns; k++) {
-        const int m = H + 3 - (ns - k);                      // first plane row / column of this step's window
-        const int n = T + 2 * (ns - k);                      // window edge
+        const int r0 = HY - (ns - k), nr = T + 2 * (ns - k);                          // rows of this step's window
+        const int g0 = (HX - (ns - k)) >> 2, g1 = (HX + T + (ns - k) + 3) >> 2;       // groups covering its columns
+        const int ng = g1 - g0;
         const V f = fac.f[k - 1];
-        const unsigned MN = 0xFFFFFFFFu / (unsigned)n + 1u;
-        for (int idx = tid; idx < n * n; idx += LV_NT) {
-            const int rr = (int)__umulhi((unsigned)idx, MN), cc = idx - rr * n;
-            const int r = m + rr, c = m + cc, x = X0 + c, y = Y0 + r;
-            if (x < 0 || x >= w || y < 0 || y >= h) continue;
-            const int ro = r * E;
-            const int rn = (r + (y == 0 ? 1 : -1)) * E, rs = (r + (y == h - 1 ? -1 : 1)) * E;
-            const int cw = c + (x == 0 ? 1 : -1), ce = c + (x == w - 1 ? -1 : 1);
-            const V L = cur[ro + c], g = B[ro + c];
-            const V tE = vmul(vadd(g, B[ro + ce]), vsub(cur[ro + ce], L));
-            const V tW = vmul(vadd(g, B[ro + cw]), vsub(cur[ro + cw], L));
-            const V tS = vmul(vadd(g, B[rs + c]), vsub(cur[rs + c], L));
-            const V tN = vmul(vadd(g, B[rn + c]), vsub(cur[rn + c], L));
-            nxt[ro + c] = vstep(f, vadd(vadd(vadd(tE, tW), tS), tN), L);                  // akazed.cu:1259-1263
+        const unsigned MN = 0xFFFFFFFFu / (unsigned)ng + 1u;
+        for (int idx = tid; idx < nr * ng; idx += LV_NT) {
+            const int rr = (int)__umulhi((unsigned)idx, MN), gg = idx - rr * ng;
+            const int r = r0 + rr, c = (g0 + gg) << 2, x = X0 + c, y = Y0 + r;
+            if (y < 0 || y >= h) continue;
+            const int rn = (r + (y == 0 ? 1 : -1)) * EW, rs = (r + (y == h - 1 ? -1 : 1)) * EW, ro = r * EW;
+            const Lv6<V> Lm = lv_row6<V>(cur + ro, c), Gm = lv_row6<V>(B + ro, c);
+            const V4 Ln = *reinterpret_cast<const V4*>(cur + rn + c), Gn = *reinterpret_cast<const V4*>(B + rn + c);
+            const V4 Ls = *reinterpret_cast<const V4*>(cur + rs + c), Gs = *reinterpret_cast<const V4*>(B + rs + c);
+            const V ln[4] = {Ln.x, Ln.y, Ln.z, Ln.w}, gn[4] = {Gn.x, Gn.y, Gn.z, Gn.w};
+            const V ls[4] = {Ls.x, Ls.y, Ls.z, Ls.w}, gs[4] = {Gs.x, Gs.y, Gs.z, Gs.w};
+            V o[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const V L = Lm.v[j + 1], g = Gm.v[j + 1];
+                const V tE = vmul(vadd(g, lv_right(Gm, j, x, w)), vsub(lv_right(Lm, j, x, w), L));
+                const V tW = vmul(vadd(g, lv_left(Gm, j, x)), vsub(lv_left(Lm, j, x), L));
+                const V tS = vmul(vadd(g, gs[j]), vsub(ls[j], L));
+                const V tN = vmul(vadd(g, gn[j]), vsub(ln[j], L));
+                o[j] = vstep(f, vadd(vadd(vadd(tE, tW), tS), tN), L);                     // akazed.cu:1259-1263
+            }
+            *reinterpret_cast<V4*>(nxt + ro + c) = mk4(o[0], o[1], o[2], o[3]);
         }
         hak_lds_barrier();
         V* tmp = cur; cur = nxt; nxt = tmp;
     }
     // ---- the core of the last step -> HBM
-    const unsigned MT = 0xFFFFFFFFu / (unsigned)T + 1u;
-    for (int idx = tid; idx < T * T; idx += LV_NT) {
-        const int r = (int)__umulhi((unsigned)idx, MT), c = idx - r * T;
+    const int tg = T >> 2;
+    const unsigned MT = 0xFFFFFFFFu / (unsigned)tg + 1u;
+    for (int idx = tid; idx < T * tg; idx += LV_NT) {
+        const int r = (int)__umulhi((unsigned)idx, MT), c = (idx - r * tg) << 2;
         const int x = bx * T + c, y = by * T + r;
-        if (x < w && y < h) od[(long)y * p + x] = cur[(r + H + 3) * E + c + H + 3];
+        if (y >= h || x >= w) continue;
+        const V4 v = *reinterpret_cast<const V4*>(cur + (r + HY) * EW + c + HX);
+        V* o = od + (long)y * p + x;
+        if (x + 3 < w) *reinterpret_cast<V4*>(o) = v;
+        else {
+            o[0] = v.x;
+            if (x + 1 < w) o[1] = v.y;
+            if (x + 2 < w) o[2] = v.z;
+        }
     }
 }
 
@@ -175,13 +248,14 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
         else fac.f[k] = (int)(0.5f * tk * 65536 + 0.5f);                                // akazed.cu:4235
     }
     // the largest tile (multiple of 8, at most 64) whose three planes fit the LDS budget
+    const int HX = (ns + 5 + 3) & ~3;                      // (as in the kernel)
+    auto plane = [&](int t) { return (long)(t + 2 * HX) * (t + 2 * (ns + 3)); };
     int T = 64;
-    while (T > 8 && 3L * (T + 2 * (ns + 3)) * (T + 2 * (ns + 3)) > LV_LDS_FLOATS) T -= 8;
+    while (T > 8 && 3L * plane(T) > LV_LDS_FLOATS) T -= 8;
     // ... but not so large that a small plane runs on a handful of CUs.  Smaller tiles mean more halo work in total (the planes are
     // (T + 2 ns + 6)^2): ~100 blocks keep a block short without multiplying the work of the octaves that run beside the critical chain
     while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 96) T -= 8;
-    const int E = T + 2 * (ns + 3);
-    const size_t lds = sizeof(V) * 3 * (size_t)E * E;
+    const size_t lds = sizeof(V) * 3 * (size_t)plane(T);
     static bool attr_done = false;                           // (per instantiation: each has its own static)
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_tile<V, HEAD, FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize,
