@@ -43,13 +43,12 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for _sub in ("cuda-akaze_amd", "oracle"):
     sys.path.insert(0, os.path.join(ROOT, _sub))
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime initialises (akaze_hip/__init__.py says why)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 # kernel-name substrings and the sources whose hash ties a PMC pass to the kernels it measured (tools/pmc_traffic.py)
 CLASS_KERNELS = {
     "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic"),
@@ -69,9 +68,14 @@ CLASS_SOURCES = {
 }
 
 
+# ... plus what every class depends on: the shared header (row-segment rule hak_stream_rows, plane layout, hak_det_at), the launch
+# sequence (which kernels run, what is fused) and the compiler flags
+COMMON_SOURCES = ("hak_internal.h", "hak_api.hip", "Makefile")
+
+
 def class_source_hash(klass):
     h = hashlib.sha256()
-    for f in CLASS_SOURCES[klass]:
+    for f in CLASS_SOURCES[klass] + COMMON_SOURCES:
         with open(os.path.join(ROOT, "cuda-akaze_amd", "csrc", f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
@@ -346,35 +350,12 @@ def other_configs(ah, synth, args, rank):
     """BASELINE.json configs[1] as a single pair, configs[2], configs[3]'s shape on one GPU, configs[4]; never `value`"""
     out = {}
     max_pts = 10000
-    # ---- configs[1] literally: ONE 1080p pair at a time, synchronous calls like the reference demo (main.cpp:199-209)
-    w, h = 1920, 1080
-    p = ah.iAlignUp(w, 128)
-    a, b = synth.pair(w, h, 1)
-    d1 = torch.from_numpy(synth.to_float(a, p)).cuda()
-    d2 = torch.from_numpy(synth.to_float(b, p)).cuda()
-    det = ah.Akazer()
-    det.init((w, h, p), max_pts=max_pts)
-    r1, r2 = ah.AkazeData(), ah.AkazeData()
-    ah.initAkazeData(r1, max_pts, True, True, pinned=True)       # as the C++ layer's initAkazeData (host/akaze.cpp)
-    ah.initAkazeData(r2, max_pts, True, True, pinned=True)
-    lat = []
-    for i in range(25):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        det.detectAndCompute(d1.data_ptr(), r1, (w, h, p), True)
-        det.detectAndCompute(d2.data_ptr(), r2, (w, h, p), True)
-        ah.cuMatch(r1, r2, det)
-        if i >= 5:
-            lat.append((time.perf_counter() - t0) * 1e3)
-    out["single_pair_latency_ms"] = round(statistics.median(lat), 3)
-    out["single_pair_keypoints"] = [r1.num_pts, r2.num_pts]
-    ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
-    del d1, d2
+    out.update(args.single_pair_result or {})               # configs[1] literally: measured first, in a child process (run_single_pair_leg)
     # ---- configs[2]: 3840x2160, 5 octaves, MLDB-upright
     w, h = 3840, 2160
     p = ah.iAlignUp(w, 128)
     B = fit_batch(16, w, h, max_pts, 2, floor=2)
-    pr = synth.pair(w, h, 2, nshapes=700)
+    pr = synth.pair(w, h, 2, nshapes=330)       # ~8 k keypoints per image, as configs[2] says (unclamped: max_pts is 10 000)
     d = torch.from_numpy(np.stack([synth.to_float(pr[i % 2], p) for i in range(2 * B)])).cuda()
     pipe = Pipeline(ah, w, h, p, 2 * B, max_pts, 2, octaves=5, upright=True, torch_stream=False)
     out["pairs_per_s_4k_5oct_upright"] = round(timed_throughput(pipe, d, B, 3, 1), 1)
@@ -410,6 +391,61 @@ def other_configs(ah, synth, args, rank):
     return out
 
 
+def run_single_pair_leg():
+    """configs[1] literally -- ONE 1080p pair at a time, synchronous calls like the reference demo (main.cpp:199-209) -- in a child
+    process started with GPU_MAX_HW_QUEUES=8: a single-image call keeps four launch chains in flight and wants them on queues of
+    their own, while the batched legs of the bench process are 2-13 % slower with eight queues, and the variable is read once, when
+    the HIP runtime initialises (INTEGRATION.md "Hardware queues").  Called BEFORE this process touches the GPU: two
+    processes with live queues on one device slow each other's short synchronous calls (match 0.06 -> 0.16 ms)."""
+    import subprocess
+    env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("HAK_SINGLE_HW_QUEUES", "8"))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-pair-leg"], capture_output=True, text=True, env=env, timeout=600)
+    leg = None
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            leg = json.loads(ln)
+    if r.returncode != 0 or leg is None:
+        raise RuntimeError("single-pair leg failed: " + r.stdout[-500:] + r.stderr[-2000:])
+    return leg
+
+
+def single_pair_leg():
+    """one 1080p pair at a time through the drop-in class: two synchronous detectAndCompute calls + cuMatch per iteration, h_data pinned as
+    the C++ layer's initAkazeData hands it out (host/akaze.cpp); prints one JSON object"""
+    import akaze_hip as ah
+    from akaze_hip import synth
+    assert torch.cuda.is_available(), "needs a HIP device"
+    max_pts = 10000
+    w, h = 1920, 1080
+    p = ah.iAlignUp(w, 128)
+    a, b = synth.pair(w, h, 1)
+    d1 = torch.from_numpy(synth.to_float(a, p)).cuda()
+    d2 = torch.from_numpy(synth.to_float(b, p)).cuda()
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=max_pts)
+    r1, r2 = ah.AkazeData(), ah.AkazeData()
+    ah.initAkazeData(r1, max_pts, True, True, pinned=True)
+    ah.initAkazeData(r2, max_pts, True, True, pinned=True)
+    lat, det_ms, match_ms = [], [], []
+    for i in range(45):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        det.detectAndCompute(d1.data_ptr(), r1, (w, h, p), True)
+        det.detectAndCompute(d2.data_ptr(), r2, (w, h, p), True)
+        t1 = time.perf_counter()
+        ah.cuMatch(r1, r2, det)
+        t2 = time.perf_counter()
+        if i >= 5:
+            lat.append((t2 - t0) * 1e3); det_ms.append((t1 - t0) * 1e3); match_ms.append((t2 - t1) * 1e3)
+    print(json.dumps({"single_pair_latency_ms": round(statistics.median(lat), 3),
+                      "single_pair_detect_ms": round(statistics.median(det_ms), 3), "single_pair_match_ms": round(statistics.median(match_ms), 3),
+                      "single_pair_keypoints": [r1.num_pts, r2.num_pts],
+                      "single_pair_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}))
+    ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -435,9 +471,12 @@ def main():
     ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
     ap.add_argument("--serial", action="store_true",
                     help="run the timed region on one stream too (default: octaves on concurrent streams)")
+    ap.add_argument("--single-pair-leg", action="store_true", help="internal: run only the one-pair-at-a-time leg of `configs` and print it")
     ap.add_argument("--launch", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 without a launcher always does)")
     args = ap.parse_args()
+    if args.single_pair_leg:
+        return single_pair_leg()
 
     if (args.gpus > 1 or args.launch) and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])                     # never returns
@@ -448,6 +487,9 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
+    args.single_pair_result = None
+    if rank == 0 and world == 1 and not args.no_configs and not args.total_pairs and (args.width, args.height, args.octaves) == (1920, 1080, 4):
+        args.single_pair_result = run_single_pair_leg()     # before this process initialises HIP
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     numa_node = pin_to_gpu_numa_node(local_rank, world)
@@ -610,6 +652,11 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None if traffic is None else round(traffic),
+                # where `traffic` comes from: NOT a counter read in this run -- the committed rocprofv3 --pmc passes of the builder's
+                # box (tools/pmc_traffic.py), accepted only while the hash of the class's kernel sources + shared header + launch
+                # sequence + Makefile matches, rescaled to this run's images per launch sequence and divided by this run's times
+                "traffic_source": None if traffic is None else "profiles/" + os.path.basename(PMC_FILE) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                  "passes on the builder's box, source-hash-guarded; durations are this run's)",
                 "traffic_GBs": None if traffic is None else round(traffic / avg_s / 1e9, 1),
                 "traffic_frac": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1), "frac_copy": round(achieved / copy_gbs, 4),
@@ -630,7 +677,7 @@ def main():
                                    "pmc_frac_peak": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
                                    "pmc_frac_copy": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (copy_gbs * world), 4)})(
                                        sum(pmc.values()) / nim))},
-                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r02_*_serial_kernel_stats.csv"}
+                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r03_*_serial_kernel_stats.csv"}
 
     # ---- the oracle legs: verification of the timed batch, then the CPU baseline (rank 0)
     verified, cpu = None, None

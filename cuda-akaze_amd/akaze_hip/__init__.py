@@ -20,10 +20,6 @@ import numpy as np
 # loads /opt/rocm's copy first makes torch see "No HIP GPUs" (and vice versa: measured on the GPU
 # box, tools/probe_runtime.py).  Importing torch first lets libhipakaze.so bind to the runtime
 # torch already loaded (same soname); without torch the library uses /opt/rocm's.
-# The library asks for eight hardware queues when it is loaded (csrc/hak_api.hip HakQueueHint: a single-image call keeps four or
-# five launch chains in flight and the runtime's default of four queues makes two of them share one).  The variable only counts
-# if it is set before the HIP runtime initialises, so it is also set here, ahead of anything that could touch the GPU.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 try:
     import torch as _torch  # noqa: F401
 except ImportError:          # pure C-ABI use without PyTorch
@@ -130,6 +126,7 @@ SYMBOLS = {
     "hak_op_orient_describe": (C.c_int, [_vp, _vp, C.c_int, C.c_int]),
     "hak_op_copy_probe": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_double)]),
     "hak_op_copy_probe_shapes": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int]),
+    "hak_op_stream_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hak_op_gather_probe": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

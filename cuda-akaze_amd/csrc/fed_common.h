@@ -92,6 +92,26 @@ __device__ __forceinline__ void hak_buf_store_nt(__amdgpu_buffer_rsrc_t r, unsig
     __builtin_amdgcn_raw_buffer_store_b128(d, r, voff, 0, 2);
 }
 
+// 16-byte streaming load of a row piece.  HAK_NT_LOADS (A/B builds only) marks it non-temporal.
+__device__ __forceinline__ float4 hak_load_stream(const float4* p)
+{
+#ifdef HAK_NT_LOADS
+    const hak_v4f t = __builtin_nontemporal_load(reinterpret_cast<const hak_v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+#else
+    return *p;
+#endif
+}
+__device__ __forceinline__ int4 hak_load_stream(const int4* p)
+{
+#ifdef HAK_NT_LOADS
+    const hak_v4i t = __builtin_nontemporal_load(reinterpret_cast<const hak_v4i*>(p));
+    return make_int4(t.x, t.y, t.z, t.w);
+#else
+    return *p;
+#endif
+}
+
 constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
 
 // horizontal pair sums of one g row as seen by a lane: h[j] = g[x0+j-1] + g[x0+j], j = 1..4 (h4 needs the right lane's g.x)

@@ -12,15 +12,6 @@
 #include <string>
 #include <vector>
 
-// A single-image call keeps four launch chains in flight (enqueue_detect's spine + one side stream per remaining octave).  The
-// HIP runtime multiplexes all streams of a process onto GPU_MAX_HW_QUEUES hardware queues -- four by default, one of them taken by
-// the null stream -- and two chains that share a queue run one after the other (C++ demo, ms per 1080p pair: 1.10 shared, 0.94 with
-// eight queues).  The variable is read when the runtime initialises, so it is set when the library is loaded, unless the host
-// application has already chosen a value (or has initialised HIP before loading us: then nothing changes, results never depend on it).
-namespace {
-struct HakQueueHint { HakQueueHint() { setenv("GPU_MAX_HW_QUEUES", "8", 0); } } g_queue_hint;
-}
-
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 static int fail(const std::string& m) { g_err = m; return 1; }
@@ -632,20 +623,27 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 hipGraphNode_t pad = nullptr;
                 if (hipGraphAddEmptyNode(&pad, cap_graph, &head_node[o], 1) != hipSuccess) (void)hipGetLastError();
             }
-        for (int o = 0; o < last; o++)
-            if (hipStreamWaitEvent(c->oct_stream[o + 1], c->ev_ready[o], 0) != hipSuccess) return fail("stream wait");
-        // the remaining work, one level per octave in turn (the graph replays launches in capture order: the host spends
-        // several microseconds on each, so no chain should wait for all of another one to be submitted first)
+        // Side streams: one per remaining octave by default.  The chain + noct-1 side streams want noct hardware queues besides the
+        // null stream's; the runtime gives a process four (GPU_MAX_HW_QUEUES), so at four octaves two side chains share a queue and
+        // run one after the other (C++ demo: 1.08 instead of 0.91 ms per 1080p pair).  A process that makes single-image calls
+        // should start with GPU_MAX_HW_QUEUES=8 (the demo does) -- the library does not set it itself, because a
+        // process that runs BATCHES loses 2 % (1080p) to 13 % (720p) with eight queues.  HAK_SIDE_STREAMS = n < noct-1 makes
+        // octaves n-1 .. noct-2 share the last side stream by design (same time as the shared queue).
+        static const int nside_env = [] { const char* e = getenv("HAK_SIDE_STREAMS"); const int v = e ? atoi(e) : HAK_MAX_OCTAVES; return v < 1 ? 1 : v; }();
+        const int nside = nside_env < last ? nside_env : (last > 0 ? last : 1);
+        auto side_of = [&](int o) { return c->oct_stream[1 + (o < nside ? o : nside - 1)]; };
+        // the remaining work, one level per octave in turn, each octave's first node behind the wait for its head
         for (int s = 0; s < L.ms; s++)
             for (int k = 0; k <= last; k++) {
                 const int o = k == 0 ? last : k - 1;                              // the spine's own octave first
-                const hipStream_t st = o == last ? main_st : c->oct_stream[o + 1];
+                const hipStream_t st = o == last ? main_st : side_of(o);
+                if (s == 0 && o != last && hipStreamWaitEvent(st, c->ev_ready[o], 0) != hipSuccess) return fail("stream wait");
                 if (s > 0) build_level(o, s, st);
                 hessian_level(o, s, st);
             }
-        for (int o = 0; o < last; o++) {
-            (void)hipEventRecord(c->ev_done[o + 1], c->oct_stream[o + 1]);
-            if (hipStreamWaitEvent(main_st, c->ev_done[o + 1], 0) != hipSuccess) return fail("stream join");
+        for (int i = 0; i < nside && last > 0; i++) {
+            (void)hipEventRecord(c->ev_done[i + 1], c->oct_stream[i + 1]);
+            if (hipStreamWaitEvent(main_st, c->ev_done[i + 1], 0) != hipSuccess) return fail("stream join");
         }
     } else {
         // each octave on its own stream, chained by events: the small octaves' launches are latency chains of a few hundred waves
@@ -1458,6 +1456,17 @@ extern "C" int hak_op_copy_probe_shapes(long bytes, int iters, double* gbytes_pe
         gbytes_per_s[i] = ms[i] > 0 ? moved / (ms[i] * 1e-3) / 1e9 : 0.0;
     }
     return HAK_COPY_SHAPES;
+}
+
+extern "C" int hak_op_stream_probe(int w, int h, int nimg, int nwrite, int warm_rows, int iters, double* ms_per_launch, double* gbytes_per_s)
+{
+    if (!ms_per_launch || !gbytes_per_s) return fail("null argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    double ms = 0, bytes = 0;
+    if (hak_launch_stream_probe(w, h, nimg, nwrite, warm_rows, iters, &ms, &bytes) || ms <= 0) return fail("stream probe failed (w % 4, sizes, memory?)");
+    *ms_per_launch = ms;
+    *gbytes_per_s = bytes / (ms * 1e-3) / 1e9;
+    return 0;
 }
 
 extern "C" int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch)

@@ -402,6 +402,7 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 #define HAK_COPY_SHAPES 26                  // 3 x 2 x 4 copy shapes + read-only + write-only (kernels_probe.hip)
 int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy, double* shapes_ms = nullptr);
 int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
+int hak_launch_stream_probe(int w, int h, int nimg, int nwrite, int warm, int iters, double* ms, double* bytes);
 
 // matcher (kernels_match.hip)
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,

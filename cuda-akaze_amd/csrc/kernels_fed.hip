@@ -66,8 +66,8 @@ __device__ __forceinline__ void fed_iter(FedState<V, NS>& S, const int t, const 
         // bytes in flight, not issue rate, bound this kernel (one row ahead = 2 KB per wave < latency x bandwidth):
         // keep PD rows of L and g outstanding per wave
         const long nrow = (long)min(t + PD, h - 1) * p + xl;
-        S.Lq[pmod(U, PD)] = *reinterpret_cast<const V4*>(L + nrow);
-        S.Gq[pmod(U, PD)] = *reinterpret_cast<const V4*>(G + nrow);
+        S.Lq[pmod(U, PD)] = hak_load_stream(reinterpret_cast<const V4*>(L + nrow));
+        S.Gq[pmod(U, PD)] = hak_load_stream(reinterpret_cast<const V4*>(G + nrow));
         const V gr = wave_shl1(g.x);
         S.GH[pmod(U, GS)] = GHrow<V>{vadd(g.x, g.y), vadd(g.y, g.z), vadd(g.z, g.w), vadd(g.w, gr)};
         S.GV[pmod(U - 1, GS)] = mk4(vadd(S.gprev.x, g.x), vadd(S.gprev.y, g.y), vadd(S.gprev.z, g.z), vadd(S.gprev.w, g.w));
@@ -117,8 +117,8 @@ __device__ __forceinline__ void fed_strip(const V* __restrict__ L, const V* __re
 #pragma unroll
     for (int i = 0; i < FedState<V, NS>::PD; i++) {
         const long row = (long)min(t0 + i, h - 1) * p + xl;
-        S.Lq[i] = *reinterpret_cast<const V4*>(L + row);
-        S.Gq[i] = *reinterpret_cast<const V4*>(G + row);
+        S.Lq[i] = hak_load_stream(reinterpret_cast<const V4*>(L + row));
+        S.Gq[i] = hak_load_stream(reinterpret_cast<const V4*>(G + row));
     }
     for (int tb = t0; tb <= tend; tb += 6) {                // ring slot = (row - t0) mod 2 / mod 6: static per unrolled body
         // the reflect rule can only fire while some level is at row 0 (t <= NS) or at row h-1

@@ -53,10 +53,10 @@ struct FsState {
 template <bool DEC, typename V, typename V4>
 __device__ __forceinline__ V4 fs_fetch(const V* __restrict__ L, const int row, const int lp, const int xl, const int sh)
 {
-    if constexpr (!DEC) return *reinterpret_cast<const V4*>(L + (long)row * lp + xl);
+    if constexpr (!DEC) return hak_load_stream(reinterpret_cast<const V4*>(L + (long)row * lp + xl));
     else {
         const V* r = L + (long)min(2 * row, sh - 1) * lp + min(2 * xl, lp - 8);
-        const V4 a = *reinterpret_cast<const V4*>(r), b = *reinterpret_cast<const V4*>(r + 4);
+        const V4 a = hak_load_stream(reinterpret_cast<const V4*>(r)), b = hak_load_stream(reinterpret_cast<const V4*>(r + 4));
         return mk4(a.x, a.z, b.x, b.z);
     }
 }

@@ -187,7 +187,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
     // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
     // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
     // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
-    T.A[pmod(U + HsGeo<S>::PD, R)] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S>::PD, h - 1) * p + xl));
+    T.A[pmod(U + HsGeo<S>::PD, R)] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S>::PD, h - 1) * p + xl)));
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -368,7 +368,7 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
 #pragma unroll
-    for (int i = 0; i < G::PD; i++) T.A[i] = *reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl));
+    for (int i = 0; i < G::PD; i++) T.A[i] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl)));
     for (int tb = t0; tb <= tend; tb += G::R) {
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
         if (tb <= 2 * S || tb + G::R - 1 >= h)

@@ -65,6 +65,47 @@ __global__ __launch_bounds__(256) void k_gather_probe(const unsigned* __restrict
     if (acc == 0xDEADBEEFu) sink[0] = acc;                  // keeps the loads alive; practically never true
 }
 
+// ---- the FED family's access shape with the arithmetic taken out: a wave streams down its 256-lane strip (240 stored columns,
+// 8-column halo on both sides) through the rows of its segment plus `warm` rows above it, one 16-byte load per lane and row with
+// three rows in flight, and stores NW planes with the kernels' own unconditional nt buffer stores.  What k_fed_sf<NS> would take
+// if its ~330 VALU instructions per row cost nothing: the floor of the launch geometry and the read : write mix.
+template <int NW>
+__global__ __launch_bounds__(256) void k_stream_probe(const float* __restrict__ src, float* __restrict__ dst, long stride, long plane,
+                                                      int w, int h, int p, int ry, int warm, int nbx, int nby, int nimg)
+{
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    const float* L = src + (long)img * stride;
+    float* D = dst + (long)img * stride * NW;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = bx * 240 - 8 + 4 * lane;
+    const int ybeg = (by * 4 + wv) * ry;
+    if (ybeg >= h) return;
+    const int yend = min(ybeg + ry, h);
+    const bool owns = 4 * lane >= 8 && 4 * lane < 248 && x0 < w && x0 >= 0;
+    const int xl = min(max(x0, 0), w - 4);
+    const __amdgpu_buffer_rsrc_t r = hak_buf_rsrc(D);
+    const unsigned col = owns ? (unsigned)x0 * 4u : HAK_BUF_OOB;
+    float4 q[3];
+    const int t0 = max(ybeg - warm, 0);
+#pragma unroll
+    for (int i = 0; i < 3; i++) q[i] = hak_load_stream(reinterpret_cast<const float4*>(L + (long)min(t0 + i, h - 1) * p + xl));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = t0; t < yend; t += 3) {
+#pragma unroll
+        for (int u = 0; u < 3; u++) {
+            const int row = t + u;
+            const float4 c = q[u];
+            q[u] = hak_load_stream(reinterpret_cast<const float4*>(L + (long)min(row + 3, h - 1) * p + xl));
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;                 // (keeps the warm-up loads alive)
+            const unsigned off = (row >= ybeg && row < yend) ? col + (unsigned)row * (unsigned)p * 4u : HAK_BUF_OOB;
+#pragma unroll
+            for (int k = 0; k < NW; k++) hak_buf_store_nt(r, off + (unsigned)k * (unsigned)(plane * 4), k ? acc : c);
+        }
+    }
+}
+
 static int probe_time(hipEvent_t a, hipEvent_t b, int iters, double* ms)
 {
     float t = 0;
@@ -138,5 +179,39 @@ int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, dou
     const int rc = probe_time(a, b, iters, ms_per_launch) || hipGetLastError() != hipSuccess;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(s); (void)hipFree(sink);
+    return rc;
+}
+
+// `nimg` images of w x h (pitch = w rounded up to 64): one read stream and `nwrite` (1..3) write streams with the streaming kernels'
+// launch geometry (hak_stream_rows) and `warm` warm-up rows per segment; *ms = average kernel time, bytes = compulsory (no halo)
+int hak_launch_stream_probe(int w, int h, int nimg, int nwrite, int warm, int iters, double* ms, double* bytes)
+{
+    if ((w & 3) || w < 16 || h < 8 || nimg < 1 || nwrite < 1 || nwrite > 3 || iters < 1) return 1;
+    const int p = (w + 63) / 64 * 64;
+    const long plane = (long)h * p;
+    if ((long)nwrite * plane * 4 >= (long)HAK_BUF_OOB) return 1;
+    float *s = nullptr, *d = nullptr;
+    if (hipMalloc((void**)&s, sizeof(float) * (size_t)plane * nimg) != hipSuccess) return 1;
+    if (hipMalloc((void**)&d, sizeof(float) * (size_t)plane * nimg * nwrite) != hipSuccess) { (void)hipFree(s); return 1; }
+    (void)hipMemset(s, 0, sizeof(float) * (size_t)plane * nimg);
+    const int gx = (w + 239) / 240;
+    const int ry = hak_stream_rows(h, (long)gx * nimg, 8);
+    const int gy = (h + 4 * ry - 1) / (4 * ry);
+    const unsigned grid = hak_xcd_grid(gx, gy, nimg);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    auto launch = [&]() {
+        if (nwrite == 1) k_stream_probe<1><<<grid, 256>>>(s, d, plane, plane, w, h, p, ry, warm, gx, gy, nimg);
+        else if (nwrite == 2) k_stream_probe<2><<<grid, 256>>>(s, d, plane, plane, w, h, p, ry, warm, gx, gy, nimg);
+        else k_stream_probe<3><<<grid, 256>>>(s, d, plane, plane, w, h, p, ry, warm, gx, gy, nimg);
+    };
+    launch();
+    (void)hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters; i++) launch();
+    (void)hipEventRecord(b, nullptr);
+    const int rc = probe_time(a, b, iters, ms) || hipGetLastError() != hipSuccess;
+    *bytes = (1.0 + nwrite) * 4.0 * (double)w * h * nimg;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(s); (void)hipFree(d);
     return rc;
 }

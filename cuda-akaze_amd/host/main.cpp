@@ -11,6 +11,7 @@
 //               an AkazeData smaller and larger than the default capacity, and an image size other than init()'s.
 #include "akaze.h"
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <iostream>
@@ -70,6 +71,9 @@ static void dumpPoints(std::ofstream& f, const akaze::AkazeData& a, const akaze:
 
 int main(int argc, char** argv)
 {
+    // One image per call keeps four launch chains in flight: ask the HIP runtime for more than its default of four
+    // hardware queues -- before its first call, and only if the user has not chosen a value ("Hardware queues")
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     std::cout << "===== Registration by HIP-AKAZE (MI355X) =====" << std::endl;
     std::string dumpPath;
     bool apiChecks = false;

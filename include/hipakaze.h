@@ -272,6 +272,11 @@ int hak_op_copy_probe(long bytes, int iters, double* gbytes_per_s);
  * loads in flight per lane l {2, 4, 8}; then the read-only and the write-only stream.  Returns the number of entries (26). */
 int hak_op_copy_probe_shapes(long bytes, int iters, double* gbytes_per_s, int n);
 int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
+/* hak_op_stream_probe: the FED family's access shape with the arithmetic taken out -- `nimg` planes of w x h read once (16 B per lane
+ * and row, 256-lane strips with 8-column halos, row segments as the streaming kernels cut them, `warm_rows` warm-up rows per
+ * segment) and `nwrite` (1..3) planes written with nt buffer stores; *gbytes_per_s = compulsory bytes (1 + nwrite) x 4 x w x h x nimg /
+ * average kernel time: the data-movement floor of k_fed_sf / k_fed_multi at that launch geometry. */
+int hak_op_stream_probe(int w, int h, int nimg, int nwrite, int warm_rows, int iters, double* ms_per_launch, double* gbytes_per_s);
 
 #ifdef __cplusplus
 }

@@ -110,15 +110,19 @@ def test_reference_images_and_match(ah, torch, synth, golden):
         det.close()
 
 
-@pytest.mark.parametrize("w,h,kw", [(1920, 1080, {}), (1280, 720, {}), (3840, 2160, dict(noctaves=5, upright=True))],
-                         ids=["1080p", "720p", "4k_5oct_upright"])
-def test_full_size_vs_oracle(ah, okz, torch, synth, w, h, kw):
+@pytest.mark.parametrize("w,h,kw,nshapes", [(1920, 1080, {}, None), (1280, 720, {}, None),
+                                            (3840, 2160, dict(noctaves=5, upright=True), None),     # dense scene: the 10 000-point clamp
+                                            (3840, 2160, dict(noctaves=5, upright=True), 330)],     # configs[2]'s ~8 k keypoints, unclamped
+                         ids=["1080p", "720p", "4k_5oct_upright_clamped", "4k_5oct_upright_8k"])
+def test_full_size_vs_oracle(ah, okz, torch, synth, w, h, kw, nshapes):
     """BASELINE.json configs 2-4 at full size, against the oracle run live on the same seeded scene"""
-    u8 = synth.scene(w, h, 1)
+    u8 = synth.scene(w, h, 2 if nshapes else 1, nshapes)
     pts = gpu_detect(ah, torch, synth, u8, **kw)
     okw = {k: int(v) for k, v in kw.items()}
     r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
     assert len(r.points) > 500
+    if nshapes:
+        assert 7000 < len(r.points) < 9500                     # (bench.py's 4K scene: 8 194 keypoints)
     assert_points_equal(pts, r.points)
 
 

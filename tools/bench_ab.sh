@@ -1,7 +1,9 @@
-# A/B of the pipelined headline under env variants on ONE box: pairs/s (3 runs each)
-run() { local tag="$1"; shift; local v=""; for i in 1 2; do v="$v $(env "$@" python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-roofline --no-configs --no-verify 2>/dev/null | tail -1 | python3 -c 'import sys,json; print(json.loads(sys.stdin.read())["value"])')"; done; echo "$tag: $v"; }
-run "default" A=1
-run "HAK_TAIL_FORK=0" HAK_TAIL_FORK=0
-run "Q=4" GPU_MAX_HW_QUEUES=4
-run "Q=4 TAIL_FORK=0" GPU_MAX_HW_QUEUES=4 HAK_TAIL_FORK=0
-run "HAK_GRAPH=0" HAK_GRAPH=0
+# A/B of library builds on ONE box: serial per-class ms (bench roofline leg) and pipelined pairs/s.  usage: bench_ab.sh lib1.so lib2.so ...
+for lib in "$@"; do
+  for i in 1 2; do
+    HAK_LIB=$PWD/$lib python3 bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-configs --no-verify 2>/dev/null | tail -1 | python3 -c "
+import sys,json
+d=json.loads(sys.stdin.read()); r=d['roofline']
+print('$lib', d['value'], 'pairs/s;', ' '.join(f\"{c['class']} {c['ms']:.2f}\" for c in r['classes']), 'copy', r['copy_ceiling_GBs'])"
+  done
+done

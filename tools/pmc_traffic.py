@@ -5,7 +5,8 @@ Usage (on the GPU box, two separate passes as MI355X_MICROARCH.md prescribes -- 
 WRITE_SIZE do not fit one pass):
     rocprofv3 --pmc FETCH_SIZE --output-format csv -d gpurun_out/pmcF -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
     rocprofv3 --pmc WRITE_SIZE --output-format csv -d gpurun_out/pmcW -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline
-    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW profiles/r01_pmc_traffic
+    python tools/pmc_traffic.py gpurun_out/pmcF gpurun_out/pmcW profiles/r03_pmc_traffic gpurun_out/pmcF.log
+(the 4th argument is the stdout of the FETCH_SIZE pass: pairs per launch sequence and the number of sequences come from its JSON line)
 
 Units / corrections (MI355X_MICROARCH.md, HBM): the counters are in KiB; on gfx950 FETCH_SIZE reports
 exactly half of the bytes of a wide (16 B/lane) coalesced streaming read, so reads are doubled for
@@ -32,8 +33,24 @@ def load(dirname, counter):
     return tot, n
 
 
+def run_shape(log_path):
+    """(pairs per launch sequence, launch sequences) of the profiled bench run, from the JSON line it printed"""
+    try:
+        for ln in open(log_path):
+            if ln.startswith("{") and '"metric"' in ln:
+                d = json.loads(ln)
+                return int(d["config"]["pairs_per_launch_sequence"]), int(d["steps"]) + int(d["warmup"])
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     fdir, wdir, out = sys.argv[1:4]
+    shape = run_shape(sys.argv[4]) if len(sys.argv) > 4 else None
+    if shape is None:
+        sys.exit("pmc_traffic.py needs the stdout log of the profiled bench run (4th argument): the pairs per launch sequence "
+                 "and the number of sequences are read from its JSON line, not assumed")
     fetch, nf = load(fdir, "FETCH_SIZE")
     write, nw = load(wdir, "WRITE_SIZE")
     rows = []
@@ -48,14 +65,14 @@ def main():
         fed_launches=launches,
         fed_hbm_bytes_per_launch=(2.0 * fed_fetch + fed_write) / max(1, launches),
         fed_fetch_size_bytes=fed_fetch, fed_write_size_bytes=fed_write, per_kernel=rows,
-        pairs_per_launch_sequence=int(os.environ.get("HAK_PMC_PAIRS", "192")))
+        pairs_per_launch_sequence=shape[0])
     # per kernel class (bench.py CLASS_KERNELS): bytes per launch sequence + the hash of the sources the pass ran on, so that
     # bench.py refuses the figure once a kernel of the class has changed.  FETCH_SIZE is doubled only for the classes whose
     # loads are 16 B/lane streams (the case MI355X_MICROARCH.md calibrates); 4-byte gathers (describe / orient, NMS,
     # matcher staging) are taken as reported -- tools/pmc_gather_calib.py measures that case.
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from bench import CLASS_KERNELS, class_source_hash
-    nseq = int(os.environ.get("HAK_PMC_SEQUENCES", "2"))          # launch sequences in the profiled run (warmup 1 + steps 1)
+    nseq = shape[1]                                               # launch sequences in the profiled run (warmup + steps)
     classes = {}
     for k, names in CLASS_KERNELS.items():
         rs = [r for r in rows if any(n in r["kernel"] for n in names)]

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on the GPU box (run via gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r02_c
+#   bash tools/refresh_profiles.sh r03_a
 # Every profiler run is wrapped in `timeout`; PMC passes are separate runs without any trace option.
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
@@ -13,9 +13,10 @@ B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -o d -- $B > $OUT/default.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o s -- $B --serial --no-pipeline > $OUT/serial.log 2>&1
 P="python3 $R/bench.py --steps 1 --warmup 1 --serial --no-pipeline --no-cpu-baseline --no-roofline --no-configs --no-verify"
+# (the PMC passes need the roofline leg off -- its copy probe would be counted -- so the bench line of these runs carries no roofline)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcF -- $P > $OUT/pmcF.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcW -- $P > $OUT/pmcW.log 2>&1
-python3 $R/tools/pmc_traffic.py $OUT/pmcF $OUT/pmcW $OUT/pmc_traffic > $OUT/pmc_traffic.log 2>&1
+python3 $R/tools/pmc_traffic.py $OUT/pmcF $OUT/pmcW $OUT/pmc_traffic $OUT/pmcF.log > $OUT/pmc_traffic.log 2>&1
 # SQ counters (two passes of 8): wave cycles / waits / active instruction classes, then instruction counts
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT \
     --output-format csv -d $OUT/sqA -- $P > $OUT/sqA.log 2>&1
