@@ -283,10 +283,14 @@ static inline bool hak_stream_pays(int mode, int w, int h, int nimg)
 // fill the chip.  1080 rows: 4 x 270, 2160: 8 x 270, 540: 4 x 135, 720: 4 x 180.  Measured on 256 x 1080p (FED / Hessian class,
 // ms): 9 segments of 128 rows, the ninth 56 rows tall in a block of its own (the rule this replaces): 9.70 / 9.14; 8 x 135:
 // 9.16 / 8.32; 4 x 270: 9.08 / 8.31; 12 x 90: 9.43 / 8.49; 16 x 68: 9.63 / 8.84.
+// Segments are halved only while the launch has fewer than 2048 waves (round 3; 4096 before; env HAK_STREAM_MIN_WAVES): at 384
+// images octave 2 then keeps 4 x 68 rows and octave 3 gets 8 x 17 instead of 16 x 9 -- a 9-row segment spends half its rows
+// on warm-up.  FED class per 384 x 1080p images, A/B on one box: 8192: 13.68 ms, 4096: 13.18, 2048: 12.75-12.92, 1536: 12.78-12.85.
 static inline int hak_stream_rows(int h, long strips_times_images, int min_rows)
 {
+    static const long want = [] { const char* e = getenv("HAK_STREAM_MIN_WAVES"); const long v = e ? atol(e) : 2048; return v < 1 ? 1 : v; }();
     int nseg = 4 * ((h + 512) / 1024 > 1 ? (h + 512) / 1024 : 1);
-    while (strips_times_images * nseg < 4096 && (h + 2 * nseg - 1) / (2 * nseg) >= min_rows) nseg *= 2;
+    while (strips_times_images * nseg < want && (h + 2 * nseg - 1) / (2 * nseg) >= min_rows) nseg *= 2;
     const int ry = (h + nseg - 1) / nseg;
     return ry > min_rows ? ry : min_rows;                    // (small images: fewer, not shorter, segments)
 }

@@ -372,17 +372,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void k_
                 if (lane + 64 * i < n4) a4[lane + 64 * i] = make_float4(0.f, 0.f, 0.f, 0.f);
         };
         // rows 0..11 2x2, 12..38 3x3, 39..86 4x4 (three per cell); a cell never straddles two rounds (30 and 60 are cell starts)
-        clear(RUN_ROWS);
+        // (wave_barrier: no instruction -- it keeps the compiler from moving one phase's LDS accesses across the next one's, which
+        // touch other lanes' words; the hardware runs a wave's LDS operations in order)
+#define HAK_WB() __builtin_amdgcn_wave_barrier()
+        clear(RUN_ROWS); HAK_WB();
         runs(0, 0, RUN_ROWS);
-        runs(1, 0, RUN_ROWS);
-        reduce_rows(acc, vals, RUN_ROWS, 0, lane);
-        clear(RUN_ROWS);
+        runs(1, 0, RUN_ROWS); HAK_WB();
+        reduce_rows(acc, vals, RUN_ROWS, 0, lane); HAK_WB();
+        clear(RUN_ROWS); HAK_WB();
         runs(1, RUN_ROWS, RUN_ROWS);
-        runs(2, RUN_ROWS, RUN_ROWS);
-        reduce_rows(acc, vals, RUN_ROWS, RUN_ROWS, lane);
-        clear(87 - 2 * RUN_ROWS);
-        runs(2, 2 * RUN_ROWS, 87 - 2 * RUN_ROWS);
+        runs(2, RUN_ROWS, RUN_ROWS); HAK_WB();
+        reduce_rows(acc, vals, RUN_ROWS, RUN_ROWS, lane); HAK_WB();
+        clear(87 - 2 * RUN_ROWS); HAK_WB();
+        runs(2, 2 * RUN_ROWS, 87 - 2 * RUN_ROWS); HAK_WB();
         reduce_rows(acc, vals, 87 - 2 * RUN_ROWS, 2 * RUN_ROWS, lane);
+#undef HAK_WB
         hak_lds_barrier();
         if (lane < HAK_FLEN) {                                      // akazed.cu:1987-1999
             unsigned int desc_r = 0;

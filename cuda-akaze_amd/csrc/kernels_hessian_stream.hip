@@ -226,7 +226,9 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
             // Unconditional buffer stores; rows outside the segment and pixel pairs the strip does not own carry the
             // out-of-range bit.
             using V2 = typename HsV2<V>::T;
+            __builtin_amdgcn_wave_barrier();                        // (no instruction: orders the cross-lane hand-over for the compiler)
             T.XS[lane] = vx;
+            __builtin_amdgcn_wave_barrier();
             const V2* xs2 = reinterpret_cast<const V2*>(T.XS);
             const V2* ys2 = reinterpret_cast<const V2*>(T.Y + pmod(U, R) * 64);
             const V2 xa = xs2[lane], ya = ys2[lane], xb2 = xs2[64 + lane], yb2 = ys2[64 + lane];

@@ -120,7 +120,9 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
         unsigned int pre[MT / 16];
         if (jbeg < jend) fetch_train(pts2, jbeg, n2, pre, c, lane & 15);
         for (int j0 = jbeg; j0 < jend; j0 += MT) {
-            put_train(pre, wt, lane);
+            __builtin_amdgcn_wave_barrier();                        // (no instruction: the other lanes' reads of the previous tile stay
+            put_train(pre, wt, lane);                               //  in front of these writes, and the reads below behind them --
+            __builtin_amdgcn_wave_barrier();                        //  the hardware runs a wave's LDS operations in order anyway)
             if (j0 + MT < jend) fetch_train(pts2, j0 + MT, n2, pre, c, lane & 15);   // next tile: lands during the compares below
             const int jn = min(MT, n2 - j0);
             const unsigned int* mine = wt + (lane >> 4) * 16;       // this lane's class within the wave's tile
