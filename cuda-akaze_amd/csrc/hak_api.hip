@@ -5,6 +5,7 @@
 // (kcontrast, point counts), one launch sequence per BATCH of images
 // (blockIdx.z = image) and no host synchronisation inside the sequence.
 #include "hak_internal.h"
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -482,6 +483,8 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
 
+    bool hess_fused[HAK_MAX_OCTAVES * HAK_MAX_SCALES] = {};
+    static const bool level_hess_on = [] { const char* e = getenv("HAK_LEVEL_HESS"); return !e || atoi(e) != 0; }();
     // ---- part A of level (o, s): build Lt(o, s) and the sigma=1 low-pass `smooth` the level's Hessian reads (akaze.cpp:325-421)
     auto build_level = [&](int o, int s, hipStream_t st) {
         const HakOct oc = L.oct[o];
@@ -503,8 +506,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         // schedule; shorter cycles keep k_smooth_flow + k_fed_multi, which spend less GPU time per pixel)
         if (level_tile_pays(c, oc, nimg) && (s == 0 || n >= c->level_min_steps || c->knobs.level_tile == 2)) {
             ProfScope ps(c, HAK_PROF_FED, st);
+            // (the level's Hessian rides along when the cycle is long enough: hess_fused tells hessian_level below)
             const int nl = hak_launch_level_tile(st, s == 0 ? A + L.lt(o - 1, 0) : A + L.lt(o, s - 1), s == 0 ? L.oct[o - 1] : oc, s == 0, smooth, Lt, tmp, S,
-                                                 oc, nimg, c->taps1, cfg.diffusivity, lp.tau.data(), n, c->state, o, 0.f);
+                                                 oc, nimg, c->taps1, cfg.diffusivity, lp.tau.data(), n, c->state, o, 0.f,
+                                                 level_hess_on ? A + L.dxy(o, s) : nullptr, lp.sigma_size, &b, &L, &c->htab, s, cfg.dthreshold,
+                                                 &hess_fused[o * HAK_MAX_SCALES + s]);
             c->fed_launches += nl;
             c->fed_fused_bytes += (s == 0 ? 1.0 * L.oct[o - 1].w * L.oct[o - 1].h : 4.0 * oc.w * oc.h) + 8.0 * oc.w * oc.h + (nl - 1) * 12.0 * oc.w * oc.h;
             return;
@@ -578,6 +584,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     // Lt itself, every other level the low-pass of its predecessor (D13).  (The determinant goes to HBM only in the dilation > 4
     // fallback: `flow` is free at every call.)
     auto hessian_level = [&](int o, int s, hipStream_t st) {
+        if (hess_fused[o * HAK_MAX_SCALES + s]) return;              // done inside k_level_tile
         const HakOct oc = L.oct[o];
         const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
         const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : A + L.smooth_off[o];
@@ -726,9 +733,12 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
             }
             const int n = lp.nsteps;
             if (level_tile_pays(c, oc, nimg)) {
+                bool hess_done = false;
+                static const bool level_hess_on = [] { const char* e = getenv("HAK_LEVEL_HESS"); return !e || atoi(e) != 0; }();
                 hakf_launch_level_tile(st, s == 0 ? A + L.lt(o - 1, 0) : A + L.lt(o, s - 1), s == 0 ? L.oct[o - 1] : oc, s == 0, smooth, Lt, tmp, S, oc,
-                                       nimg, c->itaps1, cfg.diffusivity, lp.tau.data(), n, c->state, o);
-                if (!hakf_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
+                                       nimg, c->itaps1, cfg.diffusivity, lp.tau.data(), n, c->state, o,
+                                       level_hess_on ? A + L.dxy(o, s) : nullptr, lp.sigma_size, &b, &L, &c->htab, s, idthreshold, &hess_done);
+                if (!hess_done && !hakf_launch_hessian_level(st, smooth, A + L.dxy(o, s), flow, false, S, oc.w, oc.h, oc.p, nimg,
                                                lp.sigma_size, &b, &L, &c->htab, o, s, idthreshold)) {
                     hakf_launch_hessian(st, smooth, A + L.dxy(o, s), flow, S, oc.w, oc.h, oc.p, nimg, lp.sigma_size);
                     hakf_launch_extrema(st, b, L, c->dtab, o, s, idthreshold, L.flow_off[o]);
@@ -892,10 +902,21 @@ extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitc
     // A pinned h_points (hak_host_alloc: what initAkazeData of the C++ layer hands out) is filled by the launch sequence itself,
     // count included: one synchronisation and the results are there.  A pageable one takes the reference's route
     // (akaze.cpp:134-139): count first, then a copy of the valid records.
+    // HAK_TIMING=1: host-side split of the call (submission vs waiting), printed every 100 calls -- diagnosis only
+    static const bool timing = [] { const char* e = getenv("HAK_TIMING"); return e && atoi(e) != 0; }();
+    static double t_sub = 0, t_wait = 0; static int t_n = 0;
+    const auto t0 = std::chrono::steady_clock::now();
     hak_point* h_pinned = host_pinned(h_points) ? h_points : nullptr;
     if (run_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts, h_pinned)) return 1;
     if (!h_pinned) HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->sync_stream));
+    const auto t1 = std::chrono::steady_clock::now();
     HIP_TRY(hipStreamSynchronize(c->sync_stream));
+    if (timing) {
+        const auto t2 = std::chrono::steady_clock::now();
+        t_sub += std::chrono::duration<double, std::micro>(t1 - t0).count();
+        t_wait += std::chrono::duration<double, std::micro>(t2 - t1).count();
+        if (++t_n % 100 == 0) { fprintf(stderr, "hak timing: submit %.1f us, wait %.1f us per call\n", t_sub / 100, t_wait / 100); t_sub = t_wait = 0; }
+    }
     *num_pts = c->h_num[0];
     if (h_points && !h_pinned && *num_pts > 0)                                    // akaze.cpp:134-139
         HIP_TRY(hipMemcpy(h_points, d_points, sizeof(hak_point) * (size_t)*num_pts, hipMemcpyDeviceToHost));

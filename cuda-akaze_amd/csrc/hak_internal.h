@@ -327,12 +327,19 @@ void hak_launch_smooth_flow(hipStream_t st, const float* src, float* smooth, flo
 // one whole sublevel (low-pass | decimation, conductivity, every FED step) per launch out of LDS tiles, for launches too small
 // to fill the chip (kernels_level.hip).  Returns the number of launches (1 up to 36 steps).
 #define HAK_LEVEL_TILE_MAX_PX (1920L * 1088L)      // by-size rule: at most one 1080p plane's worth of pixels per launch
+// dxy / step / b / L / htab / sub / threshold: the level's Hessian inside the same launch where the cycle is long enough
+// (first launch has >= 2 * step steps); *hess_done tells the caller whether it still has to launch the Hessian kernel
+struct HakBatch;
 int hak_launch_level_tile(hipStream_t st, const float* src, HakOct so, bool head, float* smooth, float* dst, float* tmp, long stride,
                           HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int n,
-                          const HakImgState* state, int octave, float fixed_ikc);
+                          const HakImgState* state, int octave, float fixed_ikc,
+                          float* dxy = nullptr, int step = 0, const HakBatch* b = nullptr, const HakLayout* L = nullptr,
+                          const HakTables* htab = nullptr, int sub = 0, float dthreshold = 0.f, bool* hess_done = nullptr);
 int hakf_launch_level_tile(hipStream_t st, const int* src, HakOct so, bool head, int* smooth, int* dst, int* tmp, long stride,
                            HakOct dd, int nimg, const int* itaps, int diffusivity, const float* tau, int n,
-                           const HakImgState* state, int octave);
+                           const HakImgState* state, int octave,
+                           int* dxy = nullptr, int step = 0, const HakBatch* b = nullptr, const HakLayout* L = nullptr,
+                           const HakTables* htab = nullptr, int sub = 0, int idthreshold = 0, bool* hess_done = nullptr);
 // fused FED groups (kernels_fed.hip)
 #define HAK_FED_MAX_FUSE 4
 bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_stride, int sp, int* lt, int* grad_scratch, long stride,

@@ -26,6 +26,20 @@
 
 template <typename V> struct LvFacs { V f[LV_MAX_STEPS]; };
 
+// The level's Hessian inside the same launch (hHessianDeterminant akazed.cu:2531 + gCalcExtremaMap 1334): the low-pass the
+// derivatives are taken of sits in LDS anyway.  maps == nullptr: not fused (the caller launches the Hessian kernel).
+template <typename V> struct LvHess {
+    V* dxy;                         // the level's interleaved {Lx, Ly} plane of image 0
+    V fac1, fac2;
+    int S;                          // dilation (sigma_size)
+    unsigned long long* maps; long map_stride;
+    unsigned long long* cand; long cand_cap;
+    HakImgState* state;
+    int p0, octave, layer, psz;
+    float border;
+    V threshold;
+};
+
 namespace {
 
 // source index of decimated coordinate d (tile coordinates may lie outside the image): 2d mirrored on the SOURCE extent
@@ -76,7 +90,7 @@ template <typename V, bool HEAD, bool FIRST>
 __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src, V* __restrict__ smooth, V* __restrict__ dst,
                                                       long stride, int sw, int sh, int sp, int w, int h, int p,
                                                       SfTaps<V> t, int type, const HakImgState* __restrict__ state, int octave,
-                                                      float fixed_ikc, LvFacs<V> fac, int ns, int T, int nbx, int nby, int nimg)
+                                                      float fixed_ikc, LvFacs<V> fac, int ns, int T, int nbx, int nby, int nimg, LvHess<V> hs)
 {
     using V4 = typename FedV<V>::V4;
     extern __shared__ __align__(16) unsigned char lv_lds_raw[];
@@ -90,6 +104,12 @@ __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src,
     V* A = reinterpret_cast<V*>(lv_lds_raw);                 // raw = L0, then L ping
     V* B = A + EW * EH;                                      // row pass, then g
     V* C = B + EW * EH;                                      // smooth, then L pong
+    // Hessian scratch behind the three planes: Lx, Ly on core +- (S + 1), the determinant on core +- 1
+    const bool hess = FIRST && hs.maps != nullptr;           // (uniform)
+    const int XW = T + 2 * (hs.S + 1), DW = T + 2;
+    V* HX_ = C + EW * EH;
+    V* HY_ = HX_ + XW * XW;
+    V* DT = HY_ + XW * XW;
     const V* s = src + (long)img * stride;
     V* osm = smooth + (long)img * stride;
     V* od = dst + (long)img * stride;
@@ -160,6 +180,32 @@ __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src,
         }
     }
     hak_lds_barrier();
+    if (hess) {
+        // ---- Lx, Ly (gDerivate akazed.cu:1267-1296) of the low-pass on core +- (S + 1), taps at reflect-101 indices; the core goes
+        // to the interleaved derivative plane: element (y, x) = {Lx, Ly} at 2 * (y * p + x)
+        const int S = hs.S;
+        V* oxy = hs.dxy + (long)img * stride;
+        const unsigned MX = 0xFFFFFFFFu / (unsigned)XW + 1u;
+        for (int idx = tid; idx < XW * XW; idx += LV_NT) {
+            const int r = (int)__umulhi((unsigned)idx, MX), c = idx - r * XW;
+            const int x = bx * T - S - 1 + c, y = by * T - S - 1 + r;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int c0 = hak_refl(x - S, w) - X0, c1 = x - X0, c2 = hak_refl(x + S, w) - X0;
+            const int r0 = (hak_refl(y - S, h) - Y0) * EW, r1 = (y - Y0) * EW, r2 = (hak_refl(y + S, h) - Y0) * EW;
+            const V ul = C[r0 + c0], uc = C[r0 + c1], ur = C[r0 + c2];
+            const V cl = C[r1 + c0], cr = C[r1 + c2];
+            const V ll = C[r2 + c0], lc = C[r2 + c1], lr = C[r2 + c2];
+            const V vx = hs_d(hs.fac1, hs.fac2, ur + lr - ul - ll, cr - cl);          // akazed.cu:1294
+            const V vy = hs_d(hs.fac1, hs.fac2, lr + ll - ur - ul, lc - uc);          // akazed.cu:1295
+            HX_[idx] = vx;
+            HY_[idx] = vy;
+            if (r > S && r <= S + T && c > S && c <= S + T) {
+                V* o = oxy + 2 * ((long)y * p + x);
+                o[0] = vx;
+                o[1] = vy;
+            }
+        }
+    }
     // ---- conductivity (akazed.cu:1078-1106) into B on core +- H (whole groups), neighbours at reflect-101 indices.
     // (pixels outside the image or outside core +- H get values nobody reads)
     for (int idx = tid; idx < nitems; idx += LV_NT) {
@@ -186,6 +232,27 @@ __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src,
     // ---- ns explicit steps (akazed.cu:1241-1264), ping-pong A <-> C; step k is valid on core +- (ns - k).  A step works on the
     // whole groups that cover its window: the few pixels beyond it are computed from values that are no longer valid and
     // written where no valid pixel of a later step looks (window k+1 +- 1 lies inside window k).
+    if (hess) {
+        // ---- determinant (gHessianDeterminant akazed.cu:1299-1331) on core +- 1 from the Lx / Ly scratch
+        const int S = hs.S;
+        const unsigned MD = 0xFFFFFFFFu / (unsigned)DW + 1u;
+        for (int idx = tid; idx < DW * DW; idx += LV_NT) {
+            const int r = (int)__umulhi((unsigned)idx, MD), c = idx - r * DW;
+            const int x = bx * T - 1 + c, y = by * T - 1 + r;
+            if (x < 0 || x >= w || y < 0 || y >= h) continue;
+            const int xo = bx * T - S - 1, yo = by * T - S - 1;                       // image coordinates of scratch element (0, 0)
+            const int c0 = hak_refl(x - S, w) - xo, c1 = x - xo, c2 = hak_refl(x + S, w) - xo;
+            const int r0 = (hak_refl(y - S, h) - yo) * XW, r1 = (y - yo) * XW, r2 = (hak_refl(y + S, h) - yo) * XW;
+            const V xul = HX_[r0 + c0], xuc = HX_[r0 + c1], xur = HX_[r0 + c2], xcl = HX_[r1 + c0], xcr = HX_[r1 + c2];
+            const V xll = HX_[r2 + c0], xlc = HX_[r2 + c1], xlr = HX_[r2 + c2];
+            const V yul = HY_[r0 + c0], yuc = HY_[r0 + c1], yur = HY_[r0 + c2];
+            const V yll = HY_[r2 + c0], ylc = HY_[r2 + c1], ylr = HY_[r2 + c2];
+            const V dxx = hs_d(hs.fac1, hs.fac2, xur + xlr - xul - xll, xcr - xcl);   // akazed.cu:1326-1328
+            const V dxy_ = hs_d(hs.fac1, hs.fac2, xlr + xll - xur - xul, xlc - xuc);
+            const V dyy = hs_d(hs.fac1, hs.fac2, ylr + yll - yur - yul, ylc - yuc);
+            DT[idx] = hs_det(dxx, dyy, dxy_);                                          // akazed.cu:1330
+        }
+    }
     V* cur = A;
     V* nxt = C;
     for (int k = 1; k <= ns; k++) {
@@ -218,6 +285,40 @@ __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src,
         }
         hak_lds_barrier();
         V* tmp = cur; cur = nxt; nxt = tmp;
+        if (k == 1 && hess) {
+            // ---- extrema of the level on the core (gCalcExtremaMap akazed.cu:1346-1373): border filter, threshold, strict 3 x 3
+            // maximum; winners raise the full-resolution key map and join the image's candidate list (as k_extrema does)
+            const int lane = tid & 63;
+            for (int base = 0; base < T * T; base += LV_NT) {                         // (uniform trip count: ballots inside)
+                const int idx = base + tid;
+                const int r = idx / T, c = idx - r * T;
+                const int x = bx * T + c, y = by * T + r;
+                bool hit = false;
+                V v = V(0);
+                if (idx < T * T && x >= hs.psz && x < w && y >= hs.psz && y < h &&
+                    (int)(x - hs.border + 0.5f) - 1 >= 0 && (int)(x + hs.border + 0.5f) + 1 < w &&
+                    (int)(y - hs.border + 0.5f) - 1 >= 0 && (int)(y + hs.border + 0.5f) + 1 < h) {
+                    const V* vp = DT + (r + 1) * DW + c + 1;
+                    v = *vp;
+                    hit = v > hs.threshold && v > vp[-DW] && v > vp[DW] && v > vp[-1] && v > vp[1] &&
+                          v > vp[-DW - 1] && v > vp[-DW + 1] && v > vp[DW - 1] && v > vp[DW + 1];
+                }
+                const unsigned long long m = __ballot(hit);
+                if (m) {
+                    int cbase = 0;
+                    if (lane == 0) cbase = atomicAdd(&hs.state[img].ncand, __popcll(m));
+                    cbase = __builtin_amdgcn_readfirstlane(cbase);
+                    if (hit) {
+                        const int fx = x << hs.octave, fy = y << hs.octave;
+                        const unsigned long long key = ((unsigned long long)hs_key_bits(v) << 32) | (0xFFFFFFFFu - (unsigned)hs.layer);
+                        atomicMax(&hs.maps[(long)img * hs.map_stride + (long)fy * hs.p0 + fx], key);
+                        const long slot = cbase + __popcll(m & ((1ull << lane) - 1ull));
+                        if (slot < hs.cand_cap)
+                            hs.cand[(long)img * hs.cand_cap + slot] = ((unsigned long long)hs.layer << 32) | ((unsigned)fy << 16) | (unsigned)fx;
+                    }
+                }
+            }
+        }
     }
     // ---- the core of the last step -> HBM
     const int tg = T >> 2;
@@ -239,7 +340,8 @@ __global__ __launch_bounds__(LV_NT) void k_level_tile(const V* __restrict__ src,
 
 template <typename V, bool HEAD, bool FIRST>
 void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, HakOct so, int w, int h, int p, int nimg,
-                  SfTaps<V> t, int diffusivity, const HakImgState* state, int octave, float fixed_ikc, const float* tau, int ns)
+                  SfTaps<V> t, int diffusivity, const HakImgState* state, int octave, float fixed_ikc, const float* tau, int ns,
+                  const LvHess<V>& hs)
 {
     LvFacs<V> fac;
     for (int k = 0; k < LV_MAX_STEPS; k++) {
@@ -249,13 +351,15 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
     }
     // the largest tile (multiple of 8, at most 64) whose three planes fit the LDS budget
     const int HX = (ns + 5 + 3) & ~3;                      // (as in the kernel)
+    const bool hess = FIRST && hs.maps != nullptr;
     auto plane = [&](int t) { return (long)(t + 2 * HX) * (t + 2 * (ns + 3)); };
+    auto total = [&](int t) { return 3L * plane(t) + (hess ? 2L * (t + 2 * hs.S + 2) * (t + 2 * hs.S + 2) + (long)(t + 2) * (t + 2) : 0L); };
     int T = 64;
-    while (T > 8 && 3L * plane(T) > LV_LDS_FLOATS) T -= 8;
+    while (T > 8 && total(T) > LV_LDS_FLOATS) T -= 8;
     // ... but not so large that a small plane runs on a handful of CUs.  Smaller tiles mean more halo work in total (the planes are
     // (T + 2 ns + 6)^2): ~100 blocks keep a block short without multiplying the work of the octaves that run beside the critical chain
     while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 96) T -= 8;
-    const size_t lds = sizeof(V) * 3 * (size_t)plane(T);
+    const size_t lds = sizeof(V) * (size_t)total(T);
     static bool attr_done = false;                           // (per instantiation: each has its own static)
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_tile<V, HEAD, FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -264,12 +368,13 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
     }
     const int nbx = (w + T - 1) / T, nby = (h + T - 1) / T;
     k_level_tile<V, HEAD, FIRST><<<hak_xcd_grid(nbx, nby, nimg), LV_NT, lds, st>>>(src, smooth, dst, stride, so.w, so.h, so.p, w, h, p, t, diffusivity,
-                                                                                 state, octave, fixed_ikc, fac, ns, T, nbx, nby, nimg);
+                                                                                 state, octave, fixed_ikc, fac, ns, T, nbx, nby, nimg, hs);
 }
 
 template <typename V>
 int level_steps(hipStream_t st, const V* src, HakOct so, bool head, V* smooth, V* dst, V* tmp, long stride, HakOct dd, int nimg,
-                const V* taps, int diffusivity, const float* tau, int n, const HakImgState* state, int octave, float fixed_ikc)
+                const V* taps, int diffusivity, const float* tau, int n, const HakImgState* state, int octave, float fixed_ikc,
+                const LvHess<V>& hs)
 {
     const SfTaps<V> t{taps[0], taps[1], taps[2]};
     const int G = (n + LV_MAX_STEPS - 1) / LV_MAX_STEPS;     // launches of this cycle (1 for every BASELINE configuration but 4K octave 4)
@@ -278,30 +383,63 @@ int level_steps(hipStream_t st, const V* src, HakOct so, bool head, V* smooth, V
     for (int g = 0; g < G; g++) {
         const int ns = hak_fed_group_size(n, G, g);
         V* out = ((G - g) % 2 == 1) ? dst : tmp;             // ping-pong so that the last launch lands in dst
-        if (g == 0 && head) launch_level<V, true, true>(st, cur, smooth, out, stride, so, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau, ns);
-        else if (g == 0) launch_level<V, false, true>(st, cur, smooth, out, stride, dd, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau, ns);
-        else launch_level<V, false, false>(st, cur, smooth, out, stride, dd, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau + done, ns);
+        if (g == 0 && head) launch_level<V, true, true>(st, cur, smooth, out, stride, so, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau, ns, hs);
+        else if (g == 0) launch_level<V, false, true>(st, cur, smooth, out, stride, dd, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau, ns, hs);
+        else launch_level<V, false, false>(st, cur, smooth, out, stride, dd, dd.w, dd.h, dd.p, nimg, t, diffusivity, state, octave, fixed_ikc, tau + done, ns, hs);
         done += ns;
         cur = out;
     }
     return G;
 }
 
+
+template <typename V>
+LvHess<V> level_hess(V* dxy, int step, int first_ns, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold, bool* fused)
+{
+    LvHess<V> hs{};
+    // the derivatives reach 2 S + 1 pixels beyond the core, the low-pass in LDS ns + 1: longer cycles only (every level the
+    // size rule sends here, at the demo schedule); the caller launches the Hessian kernel otherwise
+    *fused = b != nullptr && dxy != nullptr && step >= 1 && first_ns >= 2 * step;
+    if (!*fused) return hs;
+    float f1, f2;
+    hak_deriv_factors(&f1, &f2);
+    if constexpr (std::is_same<V, float>::value) { hs.fac1 = f1; hs.fac2 = f2; }
+    else { hs.fac1 = (int)(f1 * 65536 + 0.5f); hs.fac2 = (int)(f2 * 65536 + 0.5f); }     // akazed.cu:4183-4184
+    const int layer = octave * L->ms + sub;
+    hs.dxy = dxy; hs.S = step;
+    hs.maps = b->maps; hs.map_stride = b->map_stride; hs.cand = b->cand; hs.cand_cap = b->cand_cap; hs.state = b->state;
+    hs.p0 = L->oct[0].p; hs.octave = octave; hs.layer = layer;
+    hs.psz = (int)htab->borders[octave * L->ms]; hs.border = htab->borders[layer]; hs.threshold = threshold;
+    return hs;
+}
+
 } // namespace
 
 // One sublevel in ceil(n / 36) launches.  src: L(o, s-1), or (head) L(o-1, 0) with extents `so`.  dst receives L(o, s);
 // `tmp` is a scratch plane of the octave (used only when the cycle needs more than one launch); `smooth` receives the
-// sigma=1 low-pass (the Hessian's input).  Returns the number of launches.
+// sigma=1 low-pass (the Hessian's input).  With b != nullptr the level's Hessian (derivative plane dxy, extrema into the batch's
+// key map and candidate list) runs inside the first launch when the cycle is long enough; *hess_done says whether it did.
+// Returns the number of launches.
 int hak_launch_level_tile(hipStream_t st, const float* src, HakOct so, bool head, float* smooth, float* dst, float* tmp, long stride,
                           HakOct dd, int nimg, const float* taps, int diffusivity, const float* tau, int n,
-                          const HakImgState* state, int octave, float fixed_ikc)
+                          const HakImgState* state, int octave, float fixed_ikc,
+                          float* dxy, int step, const HakBatch* b, const HakLayout* L, const HakTables* htab, int sub, float dthreshold, bool* hess_done)
 {
-    return level_steps<float>(st, src, so, head, smooth, dst, tmp, stride, dd, nimg, taps, diffusivity, tau, n, state, octave, fixed_ikc);
+    const int G = (n + LV_MAX_STEPS - 1) / LV_MAX_STEPS;
+    bool fused = false;
+    const LvHess<float> hs = level_hess<float>(dxy, step, hak_fed_group_size(n, G, 0), b, L, htab, octave, sub, dthreshold, &fused);
+    if (hess_done) *hess_done = fused;
+    return level_steps<float>(st, src, so, head, smooth, dst, tmp, stride, dd, nimg, taps, diffusivity, tau, n, state, octave, fixed_ikc, hs);
 }
 
 int hakf_launch_level_tile(hipStream_t st, const int* src, HakOct so, bool head, int* smooth, int* dst, int* tmp, long stride,
                            HakOct dd, int nimg, const int* itaps, int diffusivity, const float* tau, int n,
-                           const HakImgState* state, int octave)
+                           const HakImgState* state, int octave,
+                           int* dxy, int step, const HakBatch* b, const HakLayout* L, const HakTables* htab, int sub, int idthreshold, bool* hess_done)
 {
-    return level_steps<int>(st, src, so, head, smooth, dst, tmp, stride, dd, nimg, itaps, diffusivity, tau, n, state, octave, 0.f);
+    const int G = (n + LV_MAX_STEPS - 1) / LV_MAX_STEPS;
+    bool fused = false;
+    const LvHess<int> hs = level_hess<int>(dxy, step, hak_fed_group_size(n, G, 0), b, L, htab, octave, sub, idthreshold, &fused);
+    if (hess_done) *hess_done = fused;
+    return level_steps<int>(st, src, so, head, smooth, dst, tmp, stride, dd, nimg, itaps, diffusivity, tau, n, state, octave, 0.f, hs);
 }

@@ -143,9 +143,12 @@ def test_no_descriptors(ah, okz, torch, synth):
     assert (pts["features"] == 0).all() and (pts["angle"] == 0).all()
 
 
-@pytest.mark.parametrize("B", [5, 11, 16])         # below / across / exactly on the XCD groups of 8 images (hak_xcd_decode)
-def test_batch_equals_single(ah, torch, synth, B):
-    """batching: B different images in one launch sequence == B single calls"""
+@pytest.mark.parametrize("B,level_tile", [(5, "1"), (11, "1"), (16, "1"), (3, "2"), (9, "2")],
+                         ids=["5", "11", "16", "3 k_level_tile", "9 k_level_tile"])
+def test_batch_equals_single(ah, torch, synth, monkeypatch, B, level_tile):
+    """batching: B different images in one launch sequence == B single calls (B below / across / exactly on the XCD groups of 8
+    images of hak_xcd_decode; also through the one-launch-per-sublevel kernel with its fused Hessian and the spine order)"""
+    monkeypatch.setenv("HAK_LEVEL_TILE", level_tile)
     w, h, mp = 400, 300, 2000
     p = ah.iAlignUp(w, 128)
     imgs = [_mg().case_scene(w, h, 100 + i) for i in range(B)]

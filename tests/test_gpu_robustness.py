@@ -235,7 +235,9 @@ def _alt_oracle(okz, synth, ah, u8, w, h, mp):
                                  {"HAK_DESC_PLAN": "0"}, {"HAK_DESC_ORDER": "0"}, {"HAK_DESC_ORDER": "3", "HAK_DESC_PLAN": "0"},
                                  # one launch per sublevel out of LDS tiles (kernels_level.hip): what a single-image call uses by default
                                  {"HAK_LEVEL_TILE": "2"}, {"HAK_LEVEL_TILE": "2", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0"},
-                                 {"HAK_LEVEL_TILE": "0", "HAK_FUSE_SF": "1"}],
+                                 {"HAK_LEVEL_TILE": "0", "HAK_FUSE_SF": "1"},
+                                 # ... with the level's Hessian as a launch of its own instead of inside k_level_tile
+                                 {"HAK_LEVEL_TILE": "2", "HAK_LEVEL_HESS": "0"}, {"HAK_LEVEL_HESS": "0", "HAK_FUSE_SF": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_alternatives_are_bit_identical(ah, okz, torch, synth, env):
     """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
