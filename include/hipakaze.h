@@ -78,8 +78,13 @@ void hak_default_config(hak_config* cfg);
  * Geometry is fixed at creation (w x h pixels); the arena for `batch` images,
  * the FED schedule and all tables live in the context. */
 int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out);
+/* Waits for the context's last launch sequence (an event recorded behind it, so a caller-provided stream that has been destroyed
+ * meanwhile is never touched), then releases everything.  Kernel-selection knobs are read from the environment by
+ * hak_create INTO the context: two contexts of one process may differ. */
 void hak_destroy(hak_ctx* ctx);
-/* run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own */
+/* Run on a caller-provided hipStream_t (e.g. torch's current stream); NULL = the context's own.  The stream must stay valid while
+ * calls are made with it; switching streams does not synchronise -- order work across the two yourself (hak_sync before switching
+ * is enough).  Launch-bound single-image sequences and batched ones both start and end on this stream. */
 int hak_set_stream(hak_ctx* ctx, void* hip_stream);
 int hak_sync(hak_ctx* ctx);
 /* 1 (default): octaves run on their own HIP streams (octave o+1 depends only on Lt(o,0), akaze.cpp:371-375);

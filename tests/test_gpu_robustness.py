@@ -288,6 +288,34 @@ def test_kernel_alternatives_are_bit_identical(ah, okz, torch, synth, env):
     assert_points_equal(alt_both[1], want[1])
 
 
+def test_two_contexts_keep_their_own_knobs(ah, torch, synth, monkeypatch):
+    """the kernel-selection knobs are read by hak_create INTO the context (round 2 kept them in process globals, so the second
+    context silently changed the first): two contexts built under different environments, used alternately, agree byte for byte"""
+    w, h, mp = 640, 480, 3000
+    p = ah.iAlignUp(w, 128)
+    img = torch.from_numpy(synth.to_float(synth.scene(w, h, 77), p)).cuda()
+    dets = []
+    for env in ({"HAK_HESS_STREAM": "0", "HAK_FUSE_SF": "0", "HAK_BASE_STREAM": "0", "HAK_DESC_PLAN": "0", "HAK_LEVEL_TILE": "0"},
+                {"HAK_HESS_STREAM": "2", "HAK_FUSE_SF": "2", "HAK_BASE_STREAM": "2", "HAK_DESC_PLAN": "1", "HAK_LEVEL_TILE": "0"},
+                {"HAK_LEVEL_TILE": "2", "HAK_HESS_CBUF": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        d = ah.Akazer()
+        d.init((w, h, p), max_pts=mp)
+        dets.append(d)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, mp, True, True)
+    out = []
+    for rep in range(2):
+        for d in dets:                                              # alternately: a global would now hold the LAST context's modes
+            d.detectAndCompute(img.data_ptr(), data, (w, h, p), True)
+            out.append(data.h_data[:data.num_pts].tobytes())
+    assert len(out[0]) > 104 * 200 and all(o == out[0] for o in out)
+    ah.freeAkazeData(data)
+    for d in dets:
+        d.close()
+
+
 def test_download_batch_pinned_and_pageable(ah, torch, synth):
     """hak_download_batch: pinned destinations take the one-kernel zero-copy path, pageable ones the per-image copies;
     both must deliver every image's count and the valid prefix of its records"""
