@@ -551,10 +551,19 @@ def main():
         d_u8s = [torch.empty_like(h_u8, device="cuda") for _ in range(NCTX)]
         d_imgs_k = [d_imgs] + [torch.empty_like(d_imgs) for _ in range(NCTX - 1)]
 
+        # H2D on a copy stream of its own; the context waits for the copy's event on the device (hak_wait_event), the host for nothing:
+        # the upload of step i+1 runs beside the kernels of step i.  (d_u8s[k] is free again when step i-2's results have been
+        # downloaded, which Pipeline.run does before it calls pre() for this context.)
+        copy_stream = torch.cuda.Stream()
+
         def up(k):
-            d_u8s[k].copy_(h_u8, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            with torch.cuda.stream(copy_stream):
+                d_u8s[k].copy_(h_u8, non_blocking=True)
+                ev = copy_stream.record_event()
+            ah.check(ah.lib.hak_wait_event(pipe.dets[k].ctx, C.c_void_p(ev.cuda_event)))
+            up.events[k] = ev                                   # keep the event alive until the next upload into this buffer
             ah.check(ah.lib.hak_ingest_u8(pipe.dets[k].ctx, d_u8s[k].data_ptr(), h * w, w, d_imgs_k[k].data_ptr(), h * p, p, w, h, nimg))
+        up.events = {}
 
         def up_jobs(n):                                      # job i runs on context i % NCTX (Pipeline.run)
             return [(d_imgs_k[i % NCTX], c) for i, c in enumerate(chunks * n)]

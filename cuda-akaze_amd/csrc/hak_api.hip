@@ -430,6 +430,13 @@ extern "C" int hak_set_concurrency(hak_ctx* c, int on)
     return 0;
 }
 
+extern "C" int hak_wait_event(hak_ctx* c, void* ev)
+{
+    if (!c || !ev) return fail("null argument");
+    HIP_TRY(hipStreamWaitEvent(c->stream, (hipEvent_t)ev, 0));
+    return 0;
+}
+
 extern "C" int hak_sync(hak_ctx* c)
 {
     if (!c) return fail("null context");

@@ -87,6 +87,9 @@ void hak_destroy(hak_ctx* ctx);
  * is enough).  Launch-bound single-image sequences and batched ones both start and end on this stream. */
 int hak_set_stream(hak_ctx* ctx, void* hip_stream);
 int hak_sync(hak_ctx* ctx);
+/* make the context's stream wait for a hipEvent_t recorded elsewhere (e.g. the end of an upload on a copy stream) without
+ * blocking the host: everything enqueued on the context afterwards runs behind the event */
+int hak_wait_event(hak_ctx* ctx, void* hip_event);
 /* 1 (default): octaves run on their own HIP streams (octave o+1 depends only on Lt(o,0), akaze.cpp:371-375);
  * 0: one stream, strictly serial launches (used for per-kernel timing). Env HAK_SERIAL=1 presets 0. */
 int hak_set_concurrency(hak_ctx* ctx, int on);
