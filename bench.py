@@ -551,19 +551,19 @@ def main():
         d_u8s = [torch.empty_like(h_u8, device="cuda") for _ in range(NCTX)]
         d_imgs_k = [d_imgs] + [torch.empty_like(d_imgs) for _ in range(NCTX - 1)]
 
-        # H2D on a copy stream of its own; the context waits for the copy's event on the device (hak_wait_event), the host for nothing:
-        # the upload of step i+1 runs beside the kernels of step i.  (d_u8s[k] is free again when step i-2's results have been
-        # downloaded, which Pipeline.run does before it calls pre() for this context.)
-        copy_stream = torch.cuda.Stream()
+        # H2D on the context's own stream, in front of its ingest and launch sequence: the upload of step i+1 runs beside the other
+        # context's kernels of step i and the host waits for nothing.  (A copy stream of the caller's + hak_wait_event does the
+        # same with one more stream; measured 8 % slower here, because the HIP runtime multiplexes all streams of the process
+        # onto 4 hardware queues and the marker behind a 14 ms copy holds up whichever launch chain shares its queue -- DESIGN 7.)
+        # d_u8s[k] is free again when step i-2's results have been downloaded, which Pipeline.run does before pre(k).
+        up_streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NCTX - 1)]
+        for k in range(1, NCTX):
+            ah.check(ah.lib.hak_set_stream(pipe.dets[k].ctx, C.c_void_p(up_streams[k].cuda_stream)))
 
         def up(k):
-            with torch.cuda.stream(copy_stream):
+            with torch.cuda.stream(up_streams[k]):
                 d_u8s[k].copy_(h_u8, non_blocking=True)
-                ev = copy_stream.record_event()
-            ah.check(ah.lib.hak_wait_event(pipe.dets[k].ctx, C.c_void_p(ev.cuda_event)))
-            up.events[k] = ev                                   # keep the event alive until the next upload into this buffer
             ah.check(ah.lib.hak_ingest_u8(pipe.dets[k].ctx, d_u8s[k].data_ptr(), h * w, w, d_imgs_k[k].data_ptr(), h * p, p, w, h, nimg))
-        up.events = {}
 
         def up_jobs(n):                                      # job i runs on context i % NCTX (Pipeline.run)
             return [(d_imgs_k[i % NCTX], c) for i, c in enumerate(chunks * n)]
@@ -574,7 +574,10 @@ def main():
         fence(use_dist)
         el_u = max_over_ranks(time.perf_counter() - tu, "cuda", use_dist)
         upload_rate = (args.total_pairs if strong else world * B) * args.steps / el_u
-        del h_u8, d_u8s, d_imgs_k
+        torch.cuda.synchronize()
+        for k in range(1, NCTX):                              # back to the contexts' own streams before the torch streams go away
+            ah.check(ah.lib.hak_set_stream(pipe.dets[k].ctx, None))
+        del h_u8, d_u8s, d_imgs_k, up_streams
 
     # ---- optional: the integer FAST path on the same pairs (secondary figure, never `value`)
     fast_rate = None

@@ -351,28 +351,40 @@ void hak_launch_deinterleave(hipStream_t st, const float* ab, float* a, float* b
 }
 
 // ------------------------------------------------------------------ ingest
-// uint8 -> float32 [0,1] as main.cpp:149: (float)(v * (1.0 / 255.0)); 4 pixels per thread
+// uint8 -> float32 [0,1] as main.cpp:149: (float)(v * (1.0 / 255.0)).  One thread converts 16 pixels of a row (one 16-byte load,
+// four 16-byte stores) when the row starts and pitches allow it, else pixel by pixel; the threads of an image are a flat
+// index over (row, 16-px chunk), so a 1920-px row does not leave a partly idle block at its right end.
 __global__ __launch_bounds__(256) void k_ingest_u8(const unsigned char* __restrict__ src, long src_stride, int sp,
-                                                   float* __restrict__ dst, long dst_stride, int dp, int w, int h)
+                                                   float* __restrict__ dst, long dst_stride, int dp, int w, int h, int cpr, int vec)
 {
-    const unsigned char* s = src + (long)blockIdx.z * src_stride;
-    float* d = dst + (long)blockIdx.z * dst_stride;
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y;
-    if (x >= w) return;
+    const unsigned char* s = src + (long)blockIdx.y * src_stride;
+    float* d = dst + (long)blockIdx.y * dst_stride;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const int y = (int)(idx / cpr), x = (int)(idx - (long)y * cpr) * 16;
+    if (y >= h) return;
     const unsigned char* q = s + (long)y * sp + x;
     float* o = d + (long)y * dp + x;
-    if (x + 3 < w && (sp & 3) == 0 && (dp & 3) == 0) {
-        const uchar4 v = *reinterpret_cast<const uchar4*>(q);
-        *reinterpret_cast<float4*>(o) = make_float4((float)(v.x * (1.0 / 255.0)), (float)(v.y * (1.0 / 255.0)),
-                                                    (float)(v.z * (1.0 / 255.0)), (float)(v.w * (1.0 / 255.0)));
+    if (vec && x + 15 < w) {
+        const uint4 v = *reinterpret_cast<const uint4*>(q);
+        const unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned u = wds[k];
+            *reinterpret_cast<float4*>(o + 4 * k) =
+                make_float4((float)((u & 255u) * (1.0 / 255.0)), (float)(((u >> 8) & 255u) * (1.0 / 255.0)),
+                            (float)(((u >> 16) & 255u) * (1.0 / 255.0)), (float)((u >> 24) * (1.0 / 255.0)));
+        }
     } else {
-        for (int e = 0; e < 4 && x + e < w; e++) o[e] = (float)(q[e] * (1.0 / 255.0));
+        for (int e = 0; e < 16 && x + e < w; e++) o[e] = (float)(q[e] * (1.0 / 255.0));
     }
 }
 
 void hak_launch_ingest_u8(hipStream_t st, const unsigned char* src, long src_stride, int sp, float* dst, long dst_stride,
                           int dp, int w, int h, int nimg)
 {
-    dim3 grid((w + 1023) / 1024, h, nimg);
-    k_ingest_u8<<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, dp, w, h);
+    const int cpr = (w + 15) / 16;                                  // 16-px chunks per row
+    const int vec = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0) && sp % 16 == 0 && src_stride % 16 == 0 &&
+                    dp % 4 == 0 && dst_stride % 4 == 0;
+    dim3 grid((unsigned)(((long)cpr * h + 255) / 256), nimg);
+    k_ingest_u8<<<grid, 256, 0, st>>>(src, src_stride, sp, dst, dst_stride, dp, w, h, cpr, vec);
 }

@@ -486,7 +486,7 @@ def test_serial_equals_concurrent_streams(ah, torch, synth):
 
 def test_ingest_u8_matches_host_conversion(ah, torch, synth):
     """on-device uint8 -> float32 equals main.cpp:149's host conversion bit for bit"""
-    for (w, h, sp, dp) in ((640, 33, 640, 640), (211, 17, 211, 256), (1920, 8, 2048, 1920)):
+    for (w, h, sp, dp) in ((640, 33, 640, 640), (211, 17, 211, 256), (1920, 8, 2048, 1920), (650, 9, 656, 768), (30, 5, 32, 32)):
         rng = np.random.default_rng(w)
         u8 = rng.integers(0, 256, size=(3, h, sp), dtype=np.uint8)
         d_src = torch.from_numpy(u8).cuda()
