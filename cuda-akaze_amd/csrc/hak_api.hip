@@ -212,6 +212,7 @@ HakKnobs hak_knobs_from_env()
     if (const char* e = getenv("HAK_DESC_ORDER")) { const int v = atoi(e); k.desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
     if (const char* e = getenv("HAK_DESC_PLAN")) k.desc_plan = atoi(e);
     if (const char* e = getenv("HAK_LEVEL_TILE")) k.level_tile = atoi(e);
+    if (const char* e = getenv("HAK_HESS_LP")) k.hess_lp = atoi(e);
     return k;
 }
 
@@ -491,6 +492,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     c->fed_fused_bytes = 0;
 
     bool hess_fused[HAK_MAX_OCTAVES * HAK_MAX_SCALES] = {};
+    bool hess_lp[HAK_MAX_OCTAVES * HAK_MAX_SCALES] = {};     // the level's Hessian low-passes Lt(o,s-1) itself: `smooth` was not written
     static const bool level_hess_on = [] { const char* e = getenv("HAK_LEVEL_HESS"); return !e || atoi(e) != 0; }();
     // ---- part A of level (o, s): build Lt(o, s) and the sigma=1 low-pass `smooth` the level's Hessian reads (akaze.cpp:325-421)
     auto build_level = [&](int o, int s, hipStream_t st) {
@@ -558,12 +560,17 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                    oc.h >= 8) {
             const int ns0 = hak_fed_group_size(n, G, 0);
             float* dst0 = (G % 2 == 1) ? Lt : tmp;
+            // the low-pass has one reader, the level's Hessian: when that runs as the streaming kernel it low-passes Lt(o,s-1)
+            // itself (LP variant) and the plane is not written at all
+            const bool lp_hess = c->knobs.hess_lp != 0 && hak_stream_pays(c->knobs.hess_stream, oc.w, oc.h, nimg) &&
+                                 hak_hessian_stream_covers(oc.w, oc.h, lp.sigma_size, true);
             ProfScope ps(c, HAK_PROF_FED, st);
             fused_first = hak_launch_fed_sf(st, fsrc, smooth, flow, dst0, S, oc.w, oc.h, oc.p, nimg, c->taps1, cfg.diffusivity,
-                                            lp.tau.data(), ns0, c->state, o, 0.f, G > 1);
+                                            lp.tau.data(), ns0, c->state, o, 0.f, G > 1, !lp_hess);
             if (fused_first) {
-                c->fed_launches++;               // reads L, writes smooth, L' (+ g for later launches)
-                c->fed_fused_bytes += (G > 1 ? 16.0 : 12.0) * oc.w * oc.h;
+                hess_lp[o * HAK_MAX_SCALES + s] = lp_hess;
+                c->fed_launches++;               // reads L, writes L' (+ smooth unless the Hessian is LP, + g for later launches)
+                c->fed_fused_bytes += ((G > 1 ? 16.0 : 12.0) - (lp_hess ? 4.0 : 0.0)) * oc.w * oc.h;
             }
         }
         if (s != 0 && !fused_first) {                                             // akaze.cpp:403-404 in one pass
@@ -594,10 +601,11 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         if (hess_fused[o * HAK_MAX_SCALES + s]) return;              // done inside k_level_tile
         const HakOct oc = L.oct[o];
         const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
-        const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : A + L.smooth_off[o];
+        const bool lph = hess_lp[o * HAK_MAX_SCALES + s];
+        const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : lph ? A + L.lt(o, s - 1) : A + L.smooth_off[o];
         ProfScope ps(c, HAK_PROF_HESSIAN, st);
         if (!hak_launch_hessian_level(st, hsrc, A + L.dxy(o, s), A + L.flow_off[o], false, S, oc.w, oc.h, oc.p, nimg,
-                                      lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold))
+                                      lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold, lph ? c->taps1 : nullptr))
             hak_launch_extrema_level(st, b, L, c->dtab, o, s, cfg.dthreshold, L.flow_off[o]);
     };
 

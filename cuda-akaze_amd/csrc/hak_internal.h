@@ -236,6 +236,8 @@ struct HakKnobs {
     int hess_cbuf = 256;          // HAK_HESS_CBUF: staged candidates per block of the tile kernel (1..256; tests drive the overflow path)
     int desc_order = 4;           // HAK_DESC_ORDER: image group size of the describe kernels' block order
     int desc_plan = 1;            // HAK_DESC_PLAN: planned MLDB kernel (k_describe_runs) on / off
+    int hess_lp = 0;              // HAK_HESS_LP=1: the streaming Hessian low-passes Lt(o,s-1) itself and k_fed_sf stops storing `smooth`.
+                                  // Off by default: measured 0.6 ms per 384 x 1080p SLOWER (FED -1.2 ms, Hessian +1.9 ms)
     int level_tile = 1;           // HAK_LEVEL_TILE: one launch per sublevel out of LDS tiles (k_level_tile) 0 never / 1 for launches of at
                                   // most HAK_LEVEL_TILE_MAX_PX pixels unless the streaming kernels are forced / 2 always
 };
@@ -296,9 +298,16 @@ static inline int hak_stream_rows(int h, long strips_times_images, int min_rows)
 }
 // dxy: interleaved {Lx, Ly} plane (2 * h * p elements).  det: where the determinant goes -- the fused kernels write it only
 // when store_det is set (stage tests); the launch sequence passes a scratch plane that only the dilation > 4 fallback fills.
+// lp_taps != nullptr: `src` is Lt(o,s-1) and the kernel applies the sigma=1 low-pass (taps k0, k1, k2) on the way in.
+// hak_hessian_stream_covers: the cases the streaming kernel takes (the launch sequence asks before it lets k_fed_sf drop `smooth`)
+static inline bool hak_hessian_stream_covers(int w, int h, int step, bool lp)
+{
+    return step >= 1 && step <= 4 && (w & 3) == 0 && w >= 16 && h >= 2 * step + 2 && (!lp || h >= 8);
+}
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
+                               const float* lp_taps = nullptr);
 bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
                                 const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
@@ -307,7 +316,8 @@ bool hakf_launch_hessian_level(hipStream_t st, const int* src, int* dxy, int* de
                                const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold);
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
-                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold);
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
+                              const float* lp_taps = nullptr);
 // octave-0 prologue fused (kernels_base.hip): Lt(0,0) + contrast factors, sigma=1 plane never written
 // register-streaming pass A of the octave-0 prologue (kernels_base_stream.hip); false: not covered / does not pay
 bool hak_launch_base_stream(hipStream_t st, const float* img, long img_stride, int sp, float* lt, float* grad, long stride, int w, int h,
@@ -355,9 +365,10 @@ bool hakf_launch_fed_sf_head(hipStream_t st, const int* src, HakOct so, int* smo
 bool hakf_launch_fed_sf(hipStream_t st, const int* src, int* smooth, int* flow, int* dst, long stride,
                         int w, int h, int p, int nimg, const int* itaps, int diffusivity, const float* tau, int ns,
                         const HakImgState* state, int octave, bool write_g);
+// store_smooth = false: the low-pass is not written (its only reader, the level's Hessian, runs in the LP variant)
 bool hak_launch_fed_sf(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride,
                        int w, int h, int p, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
-                       const HakImgState* state, int octave, float fixed_ikc, bool write_g);
+                       const HakImgState* state, int octave, float fixed_ikc, bool write_g, bool store_smooth = true);
 void hakf_launch_fed_group(hipStream_t st, const int* src, const int* flow, int* dst, long stride,
                            int w, int h, int p, int nimg, const float* tau, int ns);
 int hak_fed_groups(int n, int max_fuse, int w);

@@ -66,7 +66,7 @@ __device__ __forceinline__ V4 fs_fetch(const V* __restrict__ L, const int row, c
 struct FsOut { __amdgpu_buffer_rsrc_t r; unsigned smo, go; };
 
 // lp / sh: pitch and row count of the plane L points to (= p, h unless DEC)
-template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G, bool DEC>
+template <typename V, int NS, int U, bool YEDGE, bool XE, bool WRITE_G, bool DEC, bool WRITE_SM>
 __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V* __restrict__ L, V* __restrict__ SMO,
                                         V* __restrict__ GO, V* __restrict__ D, const int p, const int xl,
                                         const int x0, const int w, const int h, const int ybeg, const int yend,
@@ -134,7 +134,8 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
         sm.y = sf_conv(c.y, u1.y, d1.y, u2.y, d2.y, kk);
         sm.z = sf_conv(c.z, u1.z, d1.z, u2.z, d2.z, kk);
         sm.w = sf_conv(c.w, u1.w, d1.w, u2.w, d2.w, kk);
-        hak_buf_store_nt(O.r, O.smo + (a >= ybeg && a < yend ? (unsigned)(a * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), sm);
+        if constexpr (WRITE_SM)
+            hak_buf_store_nt(O.r, O.smo + (a >= ybeg && a < yend ? (unsigned)(a * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), sm);
         V sl = wave_shr1(sm.w), sr = wave_shl1(sm.x);
         if (XE) {
             sl = le ? sm.y : sl;                            // abs(x-1) = 1
@@ -206,21 +207,22 @@ __device__ __forceinline__ void fs_iter(FsState<V, NS>& S, const int t, const V*
     }
 }
 
-template <typename V, int NS, bool XE, bool WRITE_G, bool DEC>
+template <typename V, int NS, bool XE, bool WRITE_G, bool DEC, bool WRITE_SM>
 __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict__ SMO, V* __restrict__ GO,
                                          V* __restrict__ D, int w, int h, int p, const FedFacs<V, NS>& fac,
                                          const SfTaps<V> kk, const float ikc, int x0, int ybeg, int yend, bool owns,
                                          const int lp, const int sh)
 {
+    // WRITE_SM = false (SMO == nullptr): the low-pass has no reader -- the level's Hessian low-passes Lt itself -- and is not stored
     using V4 = typename FedV<V>::V4;
     const int xl = min(max(x0, 0), p - 4);                  // keep every lane's loads inside the plane
     FsOut O;
     {
-        V* lo = SMO;
-        if (WRITE_G) lo = GO < lo ? GO : lo;
+        V* lo = SMO ? SMO : GO;
+        if (WRITE_G && SMO) lo = GO < lo ? GO : lo;
         O.r = hak_buf_rsrc(lo);
         const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
-        O.smo = owns ? xb + (unsigned)((SMO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+        O.smo = owns && SMO ? xb + (unsigned)((SMO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
         O.go = WRITE_G && owns ? xb + (unsigned)((GO - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
     }
     const int t0 = max(0, ybeg - NS - 4);                   // rp from t0, smooth from t0+2, g from t0+3, level k from t0+3+k
@@ -246,19 +248,19 @@ __device__ __forceinline__ void fs_strip(const V* __restrict__ L, V* __restrict_
     for (int tb = t0; tb <= tend; tb += 6) {
         // reflect injections fire while some stage is at rows 1..2 (t <= NS + 4) or at the virtual rows past h-1
         if (tb <= NS + 4 || tb + 5 >= h) {
-            fs_iter<V, NS, 0, true, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 1, true, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 2, true, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 3, true, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 4, true, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 5, true, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 0, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 1, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 2, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 3, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 4, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 5, true, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
         } else {
-            fs_iter<V, NS, 0, false, XE, WRITE_G, DEC>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 1, false, XE, WRITE_G, DEC>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 2, false, XE, WRITE_G, DEC>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 3, false, XE, WRITE_G, DEC>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 4, false, XE, WRITE_G, DEC>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
-            fs_iter<V, NS, 5, false, XE, WRITE_G, DEC>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 0, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 0, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 1, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 1, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 2, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 2, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 3, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 3, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 4, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 4, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
+            fs_iter<V, NS, 5, false, XE, WRITE_G, DEC, WRITE_SM>(S, tb + 5, L, SMO, GO, D, p, xl, x0, w, h, ybeg, yend, owns, fac, kk, ikc, lp, sh, O);
         }
     }
 }
@@ -267,7 +269,7 @@ constexpr int FS_HX = 8;                                    // x halo: 2 (Gaussi
 constexpr int FS_XV = 256 - 2 * FS_HX;
 
 // grid: hak_xcd_grid(strips, strip-row groups, images); a block's four waves take four consecutive row segments
-template <typename V, int NS, bool WRITE_G, bool DEC>
+template <typename V, int NS, bool WRITE_G, bool DEC, bool WRITE_SM>
 __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __restrict__ smooth, V* __restrict__ flow,
                                                 V* __restrict__ dst, long stride, int w, int h, int p,
                                                 FedFacs<V, NS> fac, SfTaps<V> kk, const HakImgState* __restrict__ state, int octave,
@@ -276,7 +278,7 @@ __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __
     int bx, by, img;
     if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
     const V* L = src + (long)img * stride;
-    V* SMO = smooth + (long)img * stride;
+    V* SMO = smooth ? smooth + (long)img * stride : nullptr;
     V* GO = flow + (long)img * stride;
     V* D = dst + (long)img * stride;
     const float ikc = state ? state[img].ikc[octave] : fixed_ikc;
@@ -287,8 +289,8 @@ __global__ __launch_bounds__(256) void k_fed_sf(const V* __restrict__ src, V* __
     if (ybeg >= h) return;                                  // wave-uniform
     const int yend = min(ybeg + ry, h);
     const bool owns = 4 * lane >= FS_HX && 4 * lane < FS_HX + FS_XV && x0 < w && x0 >= 0;
-    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<V, NS, true, WRITE_G, DEC>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
-    else fs_strip<V, NS, false, WRITE_G, DEC>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
+    if (bx == 0 || (bx + 1) * FS_XV + FS_HX >= w) fs_strip<V, NS, true, WRITE_G, DEC, WRITE_SM>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
+    else fs_strip<V, NS, false, WRITE_G, DEC, WRITE_SM>(L, SMO, GO, D, w, h, p, fac, kk, ikc, x0, ybeg, yend, owns, lp, sh);
 }
 
 // sp > 0: octave head -- `src` is Lt(o-1,0) with pitch sp and sh rows, the kernel's input is its 2x decimation
@@ -307,12 +309,17 @@ void launch_fs(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, long st
     const int ry = hak_stream_rows(h, (long)gx * nimg, 8);
     const int gy = (h + 4 * ry - 1) / (4 * ry);
     const unsigned grid = hak_xcd_grid(gx, gy, nimg);
-    if (sp > 0) {
-        if (write_g) k_fed_sf<V, NS, true, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
-        else k_fed_sf<V, NS, false, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
+    if (!smooth) {                                          // (sublevels only; float only: launch_fs_any)
+        if constexpr (std::is_same<V, float>::value) {
+            if (write_g) k_fed_sf<V, NS, true, false, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+            else k_fed_sf<V, NS, false, false, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+        }
+    } else if (sp > 0) {
+        if (write_g) k_fed_sf<V, NS, true, true, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
+        else k_fed_sf<V, NS, false, true, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, sp, sh);
     } else {
-        if (write_g) k_fed_sf<V, NS, true, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
-        else k_fed_sf<V, NS, false, false><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+        if (write_g) k_fed_sf<V, NS, true, false, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
+        else k_fed_sf<V, NS, false, false, true><<<grid, 256, 0, st>>>(src, smooth, flow, dst, stride, w, h, p, fac, kk, state, octave, fixed_ikc, ry, gx, gy, nimg, p, h);
     }
 }
 
@@ -322,8 +329,9 @@ bool launch_fs_any(hipStream_t st, const V* src, V* smooth, V* flow, V* dst, lon
                    bool write_g, int sp = 0, int sh = 0)
 {
     if (diffusivity != HAK_PM_G2 || (w & 3) || w < 16 || h < 8 || ns < 1 || ns > 4) return false;
+    if (!smooth && (sp > 0 || !std::is_same<V, float>::value)) return false;       // not stored: float sublevels only
     // smooth and g are addressed as 32-bit byte offsets from the lower of them: plane offset + plane size < the marker
-    if ((write_g ? (flow < smooth ? smooth - flow : flow - smooth) : 0L) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
+    if ((write_g && smooth ? (flow < smooth ? smooth - flow : flow - smooth) : 0L) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
     switch (ns) {
     case 1: launch_fs<V, 1>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
     case 2: launch_fs<V, 2>(st, src, smooth, flow, dst, stride, w, h, p, nimg, kk, tau, state, octave, fixed_ikc, write_g, sp, sh); break;
@@ -357,9 +365,9 @@ int hak_launch_rcp_check(unsigned lo, unsigned hi, unsigned long long* d_bad)
 // Returns false when the case is not covered (caller: hak_launch_smooth_flow + hak_launch_fed_group).
 bool hak_launch_fed_sf(hipStream_t st, const float* src, float* smooth, float* flow, float* dst, long stride,
                        int w, int h, int p, int nimg, const float* taps, int diffusivity, const float* tau, int ns,
-                       const HakImgState* state, int octave, float fixed_ikc, bool write_g)
+                       const HakImgState* state, int octave, float fixed_ikc, bool write_g, bool store_smooth)
 {
-    return launch_fs_any<float>(st, src, smooth, flow, dst, stride, w, h, p, nimg, SfTaps<float>{taps[0], taps[1], taps[2]},
+    return launch_fs_any<float>(st, src, store_smooth ? smooth : nullptr, flow, dst, stride, w, h, p, nimg, SfTaps<float>{taps[0], taps[1], taps[2]},
                                 diffusivity, tau, ns, state, octave, fixed_ikc, write_g);
 }
 

@@ -370,15 +370,21 @@ static HakExtremaArgs<V> extrema_args(const HakBatch* b, const HakLayout* L, con
 // The fused kernels write `det` only when store_det is set; the dilation > 4 fallback always fills it.
 bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                               int w, int h, int p, int nimg, int step,
-                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+                              const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
+                              const float* lp_taps)
 {
     // register-streaming kernel (kernels_hessian_stream.hip) when it covers the case; HAK_HESS_STREAM=0 forces the tile kernel
     const HakKnobs kn = knobs_of(b);
-    if (hak_stream_pays(kn.hess_stream, w, h, nimg)) {
+    if (lp_taps || hak_stream_pays(kn.hess_stream, w, h, nimg)) {
         float f1, f2;
         deriv_factors(f1, f2);
-        if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold))
+        if (hak_launch_hessian_stream(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, f1, f2, b, L, htab, octave, sub, dthreshold,
+                                      lp_taps))
             return true;
+    }
+    if (lp_taps) {                                          // (the caller asked hak_hessian_stream_covers first: not reached)
+        fprintf(stderr, "hipakaze: LP Hessian not covered for %d x %d step %d\n", w, h, step);
+        abort();
     }
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     float* od = store_det ? det : nullptr;

@@ -25,20 +25,27 @@
 // rows h-2..h-1-S, for each of the three rings.  Per-pixel expressions and their order are those of the tile kernel
 // (kernels_hessian.hip) and the reference.
 //
+// LP variant (round 3): the kernel's input is Lt(o,s-1) itself and the sigma=1 low-pass the level differentiates
+// (hLowPass akaze.cpp:403, akazed.cu:2336/204) is evaluated on the way in -- row pass of raw row t+2 by DPP shifts, column pass
+// over the five newest row-pass rows -> smooth row t, exactly as k_fed_sf does it (same expressions, same reflect rules).  The
+// `smooth` plane then has no reader left and k_fed_sf stops writing it: one 4 B/px store per sublevel less.
+//
 // Requires w % 4 == 0 and 1 <= S <= 4; everything else takes the LDS tile kernel.
 #include "fed_common.h"
 #include <utility>
 
 namespace {
 
-template <int S> struct HsGeo {
+template <int S, bool LP> struct HsGeo {
     static constexpr int PD = 2;                                    // input rows in flight ahead of the current one
     static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
-    static constexpr int M = S == 1 ? 4 : S == 4 ? 12 : 8;          // strip margin: multiple of 4, >= 2S+1
+    // strip margin: multiple of 4, >= 2S+1 (+2 for the low-pass taps of the LP variant)
+    static constexpr int M = LP ? (S <= 2 ? 8 : 12) : (S == 1 ? 4 : S == 4 ? 12 : 8);
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
     // waves per SIMD the register allocator must make room for.  S = 3 needs ~187 VGPRs (2 waves); capping it at 168 for a
     // third wave spills 26 dwords and measured 3 % SLOWER (A/B on one box), so S >= 3 stays at two waves
-    static constexpr int MINW = S <= 3 ? 3 : 2;
+    // (LP: the row-pass ring adds ~24 VGPRs)
+    static constexpr int MINW = LP ? (S <= 1 ? 3 : 2) : (S <= 3 ? 3 : 2);
 };
 
 template <typename V> struct HsV2;
@@ -48,9 +55,13 @@ template <> struct HsV2<int> { using T = int2; };
 #define HS_CBUF 256
 struct HsCand { unsigned long long* buf; int n; };      // staged candidates: this wave's HS_CBUF LDS entries; n: wave-uniform fill count
 
-template <typename V, int S> struct HsState {
+template <typename V, int S, bool LP> struct HsState {
     using V4 = typename FedV<V>::V4;
-    V4 A[HsGeo<S>::R], X[HsGeo<S>::R];                              // slot = iteration index mod R
+    static constexpr int R = HsGeo<S, LP>::R;
+    V4 A[R], X[R];                                                  // slot = iteration index mod R
+    // LP only (static slots: the allocator keeps just the live ones): raw rows in flight, row t+2 in slot (U+2) mod R; row-pass
+    // rows t-2 .. t+2
+    V4 W[LP ? R : 1], Rp[LP ? R : 1];
     V4* Y;                                                      // Ly ring: this wave's private LDS rows [R][64] (written once, read back once)
     V4* XS;                                                     // one staging row for Lx (interleaved store below)
     V4 Dm, Dc, Dp;                                                  // det rows e-1, e, e+1 (rotated by moves)
@@ -114,6 +125,7 @@ __device__ __forceinline__ int hs_max3(int a, int b, int c) { return max(max(a, 
 
 template <typename V> struct HsArgs {
     const V* src; V* dxy; V* det;
+    SfTaps<V> kk;                                   // LP: the sigma=1 taps (float) / their 16.16 values (int)
     V* obase; unsigned off_dxy, off_det;            // dxy / det as byte offsets from the lower of the two (buffer stores); off_det =
                                                     // HAK_BUF_OOB: the determinant is not stored (the hardware drops the store)
     int w, h, p;
@@ -173,21 +185,65 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
     }
 }
 
-template <typename V, int S, int U, bool XEDGE, bool YEDGE>
-__device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
+template <typename V, int S, int U, bool XEDGE, bool YEDGE, bool LP>
+__device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
                                         const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3], const int er0, const int er1,
                                         const HsCold* cold)
 {
     using V4 = typename FedV<V>::V4;
-    constexpr int R = HsGeo<S>::R;
+    constexpr int R = HsGeo<S, LP>::R;
+    constexpr int PD = HsGeo<S, LP>::PD;
     const V fac1 = a.fac1, fac2 = a.fac2;
     const int w = a.w, h = a.h, p = a.p;
     const bool le = x0 == 0, re = x0 + 3 == w - 1;
     // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
     // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
     // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
-    T.A[pmod(U + HsGeo<S>::PD, R)] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + HsGeo<S>::PD, h - 1) * p + xl)));
+    if constexpr (!LP) {
+        T.A[pmod(U + PD, R)] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t + PD, h - 1) * p + xl)));
+    } else {
+        // ---- LP: raw row r = t + 2 arrived in W[(U+2) mod R]; request row r + PD into the slot it will be consumed from
+        const int r = t + 2;
+        T.W[pmod(U + 2 + PD, R)] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(r + PD, h - 1) * p + xl)));
+        const SfTaps<V> kk = a.kk;
+        {   // row pass of the Gaussian on raw row r (akazed.cu:227-239; kernels_fedsf.hip fs_iter)
+            const V4 c = T.W[pmod(U + 2, R)];
+            const V sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
+            V4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
+            V4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
+            if (XEDGE) {
+                l1.x = le ? c.y : l1.x;                         // column -1 -> 1
+                l2.x = le ? c.z : l2.x;                         // column -2 -> 2
+                l2.y = le ? c.y : l2.y;                         // column -1 -> 1
+                r1.w = re ? c.z : r1.w;                         // column w   -> w-2
+                r2.z = re ? c.z : r2.z;                         // column w   -> w-2
+                r2.w = re ? c.y : r2.w;                         // column w+1 -> w-3
+            }
+            V4 rp;
+            rp.x = sf_conv(c.x, l1.x, r1.x, l2.x, r2.x, kk);
+            rp.y = sf_conv(c.y, l1.y, r1.y, l2.y, r2.y, kk);
+            rp.z = sf_conv(c.z, l1.z, r1.z, l2.z, r2.z, kk);
+            rp.w = sf_conv(c.w, l1.w, r1.w, l2.w, r2.w, kk);
+            T.Rp[pmod(U + 2, R)] = rp;
+            if (YEDGE) {                                        // (selects on values: see kernels_fedsf.hip)
+                T.Rp[pmod(U, R)] = vsel4(r == 1, rp, T.Rp[pmod(U, R)]);                              // row -1 := row 1
+                T.Rp[pmod(U - 2, R)] = vsel4(r == 2, rp, T.Rp[pmod(U - 2, R)]);                      // row -2 := row 2
+                T.Rp[pmod(U + 2, R)] = vsel4(r == h, T.Rp[pmod(U, R)], T.Rp[pmod(U + 2, R)]);        // row h   := row h-2
+                T.Rp[pmod(U + 2, R)] = vsel4(r == h + 1, T.Rp[pmod(U - 2, R)], T.Rp[pmod(U + 2, R)]);// row h+1 := row h-3
+            }
+        }
+        {   // column pass -> smooth row t (akazed.cu:283-288)
+            const V4 c = T.Rp[pmod(U, R)], u1 = T.Rp[pmod(U - 1, R)], d1 = T.Rp[pmod(U + 1, R)];
+            const V4 u2 = T.Rp[pmod(U - 2, R)], d2 = T.Rp[pmod(U + 2, R)];
+            V4 sm;
+            sm.x = sf_conv(c.x, u1.x, d1.x, u2.x, d2.x, kk);
+            sm.y = sf_conv(c.y, u1.y, d1.y, u2.y, d2.y, kk);
+            sm.z = sf_conv(c.z, u1.z, d1.z, u2.z, d2.z, kk);
+            sm.w = sf_conv(c.w, u1.w, d1.w, u2.w, d2.w, kk);
+            T.A[pmod(U, R)] = sm;
+        }
+    }
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -313,25 +369,27 @@ __device__ __forceinline__ void hs_iter(HsState<V, S>& T, const int t, const HsA
     }
 }
 
-template <typename V, int S, bool XEDGE, bool YEDGE, int... U>
-__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S>& T, const int tb, const HsArgs<V>& a,
+template <typename V, int S, bool XEDGE, bool YEDGE, bool LP, int... U>
+__device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S, LP>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
                                          const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3],
                                          const int er0, const int er1, const HsCold* cold)
 {
-    (hs_iter<V, S, U, XEDGE, YEDGE>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold), ...);
+    (hs_iter<V, S, U, XEDGE, YEDGE, LP>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold), ...);
 }
 
-template <typename V, int S, bool XEDGE>
+template <typename V, int S, bool XEDGE, bool LP>
 __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
                                          const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf,
                                          const HsCold* cold)
 {
-    using G = HsGeo<S>;
+    using G = HsGeo<S, LP>;
     using V4 = typename FedV<V>::V4;
     const int h = a.h, w = a.w;
     const int xl = min(max(x0, 0), a.p - 4);                    // keep every lane's loads inside the plane
-    const int t0 = max(0, ybeg - 1 - 2 * S);                    // first input row
+    // first input row of the derivative pipeline.  LP: its smooth row needs row-pass rows t0-2 .. t0+2, i.e. four more
+    // iterations in front (raw row t+2 enters at iteration t; rows -2, -1 are written when rows 2, 1 arrive: from t = -2)
+    const int t0 = LP ? max(max(0, ybeg - 1 - 2 * S) - 4, -2) : max(0, ybeg - 1 - 2 * S);
     const int tend = yend + 2 * S;                              // iteration that tests the segment's last row for extrema
     // per-component x range of the extrema test (akazed.cu:1351-1356), constant along the strip
     unsigned xok = 0;
@@ -359,7 +417,7 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
         return q >= G::M && q < G::M + G::XV && x >= 0 && x < w ? (unsigned)x * 2u * (unsigned)sizeof(V) + a.off_dxy : HAK_BUF_OOB;
     };
     const unsigned ovoff[3] = {pair_off(2 * lane), owns && a.off_det != HAK_BUF_OOB ? xb + a.off_det : HAK_BUF_OOB, pair_off(128 + 2 * lane)};
-    HsState<V, S> T;
+    HsState<V, S, LP> T;
     T.Y = yring;
     T.XS = xstage;
     T.cb.buf = cbuf;
@@ -369,23 +427,32 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
 #pragma unroll
     for (int i = 0; i < G::R; i++) { T.A[i] = T.X[i] = z4; T.Y[i * 64 + lane] = z4; }
     T.Dm = T.Dc = T.Dp = z4;
+    if constexpr (LP) {
 #pragma unroll
-    for (int i = 0; i < G::PD; i++) T.A[i] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl)));
+        for (int i = 0; i < G::R; i++) T.W[i] = T.Rp[i] = z4;
+#pragma unroll
+        for (int i = 0; i < G::PD; i++)                         // raw rows t0+2 .. : consumed from slot (U+2) mod R at U = i
+            T.W[pmod(2 + i, G::R)] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + 2 + i, h - 1) * a.p + xl)));
+    } else {
+#pragma unroll
+        for (int i = 0; i < G::PD; i++) T.A[i] = hak_load_stream(reinterpret_cast<const V4*>(a.src + (unsigned)(min(t0 + i, h - 1) * a.p + xl)));
+    }
     for (int tb = t0; tb <= tend; tb += G::R) {
-        // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1
-        if (tb <= 2 * S || tb + G::R - 1 >= h)
-            hs_group<V, S, XEDGE, true>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
+        // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1 (LP: the raw row of
+        // iteration t is t+2)
+        if (tb <= 2 * S || tb + G::R - 1 >= h - (LP ? 2 : 0))
+            hs_group<V, S, XEDGE, true, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
         else
-            hs_group<V, S, XEDGE, false>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
+            hs_group<V, S, XEDGE, false, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
     }
     if (a.maps != nullptr) hs_flush(T.cb, cold, lane);
 }
 
 // grid: hak_xcd_grid(strips, segment groups of 4, images); wave wv of a block takes segment by*4 + wv
-template <typename V, int S>
-__global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
+template <typename V, int S, bool LP>
+__global__ __launch_bounds__(256, (HsGeo<S, LP>::MINW)) void k_hessian_stream(HsArgs<V> a, long stride, long map_stride, int ry, int nbx, int nby, int nimg)
 {
-    using G = HsGeo<S>;
+    using G = HsGeo<S, LP>;
     __shared__ typename FedV<V>::V4 yring[4 * G::R * 64];                     // per-wave private Ly rings: no barrier ever needed
     __shared__ typename FedV<V>::V4 xstage[4 * 64];                           // per-wave Lx staging row of the interleaved store
     __shared__ unsigned long long cbuf[4 * HS_CBUF];            // per-wave candidate staging
@@ -406,28 +473,30 @@ __global__ __launch_bounds__(256, HsGeo<S>::MINW) void k_hessian_stream(HsArgs<V
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
     // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
-    else hs_strip<V, S, false>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
+    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
+    else hs_strip<V, S, false, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
 }
 
-template <typename V, int S>
+template <typename V, int S, bool LP>
 void launch_stream(hipStream_t st, HsArgs<V> a, long stride, long map_stride, int nimg)
 {
-    using G = HsGeo<S>;
+    using G = HsGeo<S, LP>;
     const int gx = (a.w + G::XV - 1) / G::XV;
     // rows per wave: tall segments amortise the 4S+2 warm-up rows; shrink while the grid cannot fill the chip
     const int ry = hak_stream_rows(a.h, (long)gx * nimg, 16);
     const int gy = (a.h + 4 * ry - 1) / (4 * ry);
-    k_hessian_stream<V, S><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
+    k_hessian_stream<V, S, LP><<<hak_xcd_grid(gx, gy, nimg), 256, 0, st>>>(a, stride, map_stride, ry, gx, gy, nimg);
 }
 
 
 template <typename V>
 bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_det, long stride, int w, int h, int p, int nimg, int step,
-                       V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold)
+                       V fac1, V fac2, const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, V threshold,
+                       const SfTaps<V>* lp)
 {
-    if (step < 1 || step > 4 || (w & 3) || w < 16 || h < 2 * step + 2) return false;
+    if (!hak_hessian_stream_covers(w, h, step, lp != nullptr)) return false;
     HsArgs<V> a{};
+    if (lp) a.kk = *lp;
     V* lo = dxy;
     if (store_det && det < lo) lo = det;
     {   // plane offset + plane size must stay below the out-of-range marker
@@ -444,11 +513,20 @@ bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_
         a.p0 = L->oct[0].p; a.octave = octave; a.layer = layer;
         a.psz = (int)htab->borders[octave * L->ms]; a.border = htab->borders[layer]; a.threshold = threshold;
     }
+    if (lp) {
+        switch (step) {
+        case 1: launch_stream<V, 1, true>(st, a, stride, map_stride, nimg); break;
+        case 2: launch_stream<V, 2, true>(st, a, stride, map_stride, nimg); break;
+        case 3: launch_stream<V, 3, true>(st, a, stride, map_stride, nimg); break;
+        default: launch_stream<V, 4, true>(st, a, stride, map_stride, nimg); break;
+        }
+        return true;
+    }
     switch (step) {
-    case 1: launch_stream<V, 1>(st, a, stride, map_stride, nimg); break;
-    case 2: launch_stream<V, 2>(st, a, stride, map_stride, nimg); break;
-    case 3: launch_stream<V, 3>(st, a, stride, map_stride, nimg); break;
-    default: launch_stream<V, 4>(st, a, stride, map_stride, nimg); break;
+    case 1: launch_stream<V, 1, false>(st, a, stride, map_stride, nimg); break;
+    case 2: launch_stream<V, 2, false>(st, a, stride, map_stride, nimg); break;
+    case 3: launch_stream<V, 3, false>(st, a, stride, map_stride, nimg); break;
+    default: launch_stream<V, 4, false>(st, a, stride, map_stride, nimg); break;
     }
     return true;
 }
@@ -458,14 +536,18 @@ bool launch_stream_any(hipStream_t st, const V* src, V* dxy, V* det, bool store_
 // return false when this kernel does not cover the case (caller falls back to the LDS tile kernel)
 bool hak_launch_hessian_stream(hipStream_t st, const float* src, float* dxy, float* det, bool store_det, long stride,
                                int w, int h, int p, int nimg, int step, float fac1, float fac2,
-                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold)
+                               const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, float dthreshold,
+                               const float* lp_taps)
 {
-    return launch_stream_any<float>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold);
+    const SfTaps<float> kk = lp_taps ? SfTaps<float>{lp_taps[0], lp_taps[1], lp_taps[2]} : SfTaps<float>{};
+    return launch_stream_any<float>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, dthreshold,
+                                    lp_taps ? &kk : nullptr);
 }
 
 bool hakf_launch_hessian_stream(hipStream_t st, const int* src, int* dxy, int* det, bool store_det, long stride,
                                 int w, int h, int p, int nimg, int step, int fac1, int fac2,
                                 const HakBatch* b, const HakLayout* L, const HakTables* htab, int octave, int sub, int idthreshold)
 {
-    return launch_stream_any<int>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold);
+    return launch_stream_any<int>(st, src, dxy, det, store_det, stride, w, h, p, nimg, step, fac1, fac2, b, L, htab, octave, sub, idthreshold,
+                                  nullptr);
 }

@@ -442,6 +442,21 @@ def test_level_tile_vs_oracle(ah, okz, torch, synth, monkeypatch, w, h, seed, kw
     det.close()
 
 
+@pytest.mark.parametrize("w,h,seed,kw", [(640, 480, 31, {}), (324, 200, 32, {}), (1280, 720, 33, dict(noctaves=3)),
+                                         (512, 96, 34, dict(noctaves=3)), (960, 540, 35, dict(derivative_factor=1.0, soffset=1.2)),
+                                         (256, 256, 36, dict(noctaves=2, upright=True))], ids=lambda v: str(v))
+def test_hessian_lp_vs_oracle(ah, okz, torch, synth, monkeypatch, w, h, seed, kw):
+    """HAK_HESS_LP=1: k_hessian_stream<., ., LP> low-passes Lt(o,s-1) on the way in and k_fed_sf leaves `smooth` unwritten --
+    keypoints and descriptors against the oracle (image edges, short segments, dilations 1..4 through the parameter sets)"""
+    monkeypatch.setenv("HAK_HESS_LP", "1")
+    u8 = _mg().case_scene(w, h, seed)
+    pts = gpu_detect(ah, torch, synth, u8, **kw)
+    okw = {k: (int(v) if isinstance(v, bool) else v) for k, v in kw.items()}
+    r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(w, 128)), w, okz.default_params(**okw))
+    assert len(r.points) > 10
+    assert_points_equal(pts, r.points)
+
+
 def test_pinned_results_equal_pageable(ah, torch, synth):
     """h_data in pinned host memory (what the C++ layer's initAkazeData hands out): records and count are written by the launch
     sequence itself; they must equal the pageable route's, call after call, for both images of a pair and for an empty image"""

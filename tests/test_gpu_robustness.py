@@ -237,7 +237,9 @@ def _alt_oracle(okz, synth, ah, u8, w, h, mp):
                                  {"HAK_LEVEL_TILE": "2"}, {"HAK_LEVEL_TILE": "2", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0"},
                                  {"HAK_LEVEL_TILE": "0", "HAK_FUSE_SF": "1"},
                                  # ... with the level's Hessian as a launch of its own instead of inside k_level_tile
-                                 {"HAK_LEVEL_TILE": "2", "HAK_LEVEL_HESS": "0"}, {"HAK_LEVEL_HESS": "0", "HAK_FUSE_SF": "1"}],
+                                 {"HAK_LEVEL_TILE": "2", "HAK_LEVEL_HESS": "0"}, {"HAK_LEVEL_HESS": "0", "HAK_FUSE_SF": "1"},
+                                 # the streaming Hessian low-passes Lt(o,s-1) itself (LP variant) and k_fed_sf does not store `smooth`
+                                 {"HAK_HESS_LP": "1"}, {"HAK_HESS_LP": "1", "HAK_FED_MAX_FUSE": "2"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()))
 def test_kernel_alternatives_are_bit_identical(ah, okz, torch, synth, env):
     """every kernel-selection knob read by hak_create must give byte-identical keypoints, descriptors and
