@@ -32,6 +32,13 @@
 // image border (mirroring level-0 rows instead would swap the S and N terms and change roundings).
 #include "fed_common.h"
 
+#ifndef HAK_FM_PD
+#define HAK_FM_PD 3
+#endif
+#ifndef HAK_FM_PD_MAXNS
+#define HAK_FM_PD_MAXNS 4
+#endif
+
 template <typename V, int NS>
 struct FedState {
     using V4 = typename FedV<V>::V4;
@@ -41,7 +48,7 @@ struct FedState {
     GHrow<V> GH[GS];                    // ring: horizontal sums of g row r        at slot (r - origin) mod GS
     V4 GV[GS];                          // ring: g[r] + g[r+1]                     at slot (r - origin) mod GS
     V4 gprev;                           // g row t-1
-    static constexpr int PD = 3;        // prefetch distance in rows (divides the unroll factor 6)
+    static constexpr int PD = NS <= HAK_FM_PD_MAXNS ? HAK_FM_PD : 3;        // prefetch distance in rows (divides the unroll factor 6)
     V4 Lq[PD], Gq[PD];                  // software prefetch ring: rows t .. t+PD-1 in flight
 };
 

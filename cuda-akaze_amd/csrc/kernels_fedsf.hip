@@ -28,13 +28,20 @@
 // k_smooth_flow + k_fed_multi.
 #include "fed_common.h"
 
+#ifndef HAK_FS_PD
+#define HAK_FS_PD 3
+#endif
+#ifndef HAK_FS_PD_MAXNS
+#define HAK_FS_PD_MAXNS 4
+#endif
+
 namespace {
 
 template <typename V, int NS>
 struct FsState {
     using V4 = typename FedV<V>::V4;
     static constexpr int GS = 6;
-    static constexpr int PD = 3;
+    static constexpr int PD = NS <= HAK_FS_PD_MAXNS ? HAK_FS_PD : 3;     // input rows in flight (divides the unroll factor 6)
     V4 Lr[6];                           // L rows t-5 .. t                      slot = iteration mod 6
     V4 Rp[6];                           // row-pass rows t-5 .. t
     V4 Sm[3];                           // smooth rows a-2 .. a (a = t-2)       slot = iteration mod 3
