@@ -162,6 +162,7 @@ struct hak_ctx {
     unsigned long long* bitmap = nullptr;
     int* rowcount = nullptr;
     unsigned long long* cand = nullptr;
+    int* perm = nullptr;            // [batch][cfg.max_pts] visiting order of the keypoint kernels (HakBatch::perm)
     long cand_cap = 0;
     HakImgState* state = nullptr;
     int* d_num = nullptr;           // [batch] counts for the synchronous entry points
@@ -213,6 +214,7 @@ HakKnobs hak_knobs_from_env()
     if (const char* e = getenv("HAK_DESC_PLAN")) k.desc_plan = atoi(e);
     if (const char* e = getenv("HAK_LEVEL_TILE")) k.level_tile = atoi(e);
     if (const char* e = getenv("HAK_HESS_LP")) k.hess_lp = atoi(e);
+    if (const char* e = getenv("HAK_DESC_SORT")) k.desc_sort = atoi(e);
     return k;
 }
 
@@ -361,6 +363,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     c->cand_cap = 0;
     for (int o = 0; o < L.noct; o++) c->cand_cap += (long)L.ms * ((L.oct[o].w + 1) / 2) * ((L.oct[o].h + 1) / 2);
     A((void**)&c->cand, sizeof(unsigned long long) * (size_t)c->cand_cap * B);
+    A((void**)&c->perm, sizeof(int) * (size_t)c->cfg.max_pts * B);
     A((void**)&c->state, sizeof(HakImgState) * (size_t)B);
     A((void**)&c->d_num, sizeof(int) * (size_t)B);
     A((void**)&c->dtab, sizeof(HakTables));
@@ -409,7 +412,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt, c->match_keys};
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt, c->match_keys, c->perm};
     for (void* b : bufs) (void)hipFree(b);
     if (c->h_num) (void)hipHostFree(c->h_num);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -486,7 +489,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     c->sync_stream = c->stream;
     float* A = c->arena;
     const long S = L.arena;
-    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
+    HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs, c->perm, cfg.max_pts};
     c->last_fast = false;
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
@@ -718,7 +721,7 @@ static int enqueue_fast_detect(hak_ctx* c, const unsigned char* d_images, long i
     hipStream_t st = c->stream;
     int* A = reinterpret_cast<int*>(c->arena);
     const long S = L.arena;
-    HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs};
+    HakBatch b{c->arena, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs, c->perm, cfg.max_pts};
     const int idthreshold = 65;                                                   // akaze.cpp:559
     c->last_fast = true;
     c->sync_stream = c->stream;

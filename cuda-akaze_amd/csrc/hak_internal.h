@@ -236,6 +236,8 @@ struct HakKnobs {
     int hess_cbuf = 256;          // HAK_HESS_CBUF: staged candidates per block of the tile kernel (1..256; tests drive the overflow path)
     int desc_order = 4;           // HAK_DESC_ORDER: image group size of the describe kernels' block order
     int desc_plan = 1;            // HAK_DESC_PLAN: planned MLDB kernel (k_describe_runs) on / off
+    int desc_sort = 1;            // HAK_DESC_SORT: the keypoint kernels visit an image's keypoints level by level (raster order within a
+                                  // level) instead of in output order: 0 never / 1 in batches of 8 images and more / 2 always
     int hess_lp = 0;              // HAK_HESS_LP=1: the streaming Hessian low-passes Lt(o,s-1) itself and k_fed_sf stops storing `smooth`.
                                   // Off by default: measured 0.6 ms per 384 x 1080p SLOWER (FED -1.2 ms, Hessian +1.9 ms)
     int level_tile = 1;           // HAK_LEVEL_TILE: one launch per sublevel out of LDS tiles (k_level_tile) 0 never / 1 for launches of at
@@ -255,6 +257,8 @@ struct HakBatch {
     unsigned long long* cand;     // [nimg][cand_cap] extrema candidates: layer<<32 | y<<16 | x (full-res)
     long cand_cap;
     const HakKnobs* knobs = nullptr;   // the owning context's; nullptr (stage operators): hak_knobs_from_env()
+    int* perm = nullptr;          // [nimg][perm_cap] visiting order of the keypoint kernels (k_desc_perm), or nullptr: output order
+    int perm_cap = 0;
 };
 
 // scale space (kernels_scalespace.hip)

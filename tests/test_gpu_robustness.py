@@ -233,6 +233,8 @@ def _alt_oracle(okz, synth, ah, u8, w, h, mp):
                                  {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "4"}, {"HAK_HESS_STREAM": "0", "HAK_HESS_CBUF": "1"},
                                  # MLDB: the generic kernel instead of the planned one; block orders of the keypoint kernels
                                  {"HAK_DESC_PLAN": "0"}, {"HAK_DESC_ORDER": "0"}, {"HAK_DESC_ORDER": "3", "HAK_DESC_PLAN": "0"},
+                                 # ... visiting the keypoints level by level (k_desc_perm; the default only in batches of 8 and more)
+                                 {"HAK_DESC_SORT": "2"}, {"HAK_DESC_SORT": "2", "HAK_DESC_ORDER": "0"}, {"HAK_DESC_SORT": "0"},
                                  # one launch per sublevel out of LDS tiles (kernels_level.hip): what a single-image call uses by default
                                  {"HAK_LEVEL_TILE": "2"}, {"HAK_LEVEL_TILE": "2", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0"},
                                  {"HAK_LEVEL_TILE": "0", "HAK_FUSE_SF": "1"},
