@@ -285,6 +285,12 @@ class Pipeline:
             self.h_pts.append(hp)
             self.h_num.append(hn)
         self.nctx = nctx
+        self.phase_lock = os.environ.get("HAK_BENCH_PHASE_LOCK", "1") != "0"
+        self.phase_ev = []
+        for k in range(nctx):
+            ev = C.c_void_p()
+            ah.check(ah.lib.hak_phase_event(self.dets[k].ctx, C.byref(ev)))
+            self.phase_ev.append(ev)
 
     def enqueue(self, k, d_imgs, npairs=None, fast=False):
         """detect + describe on 2*npairs images + match of the npairs pairs (default: the whole batch)"""
@@ -305,6 +311,9 @@ class Pipeline:
         for i, (imgs, npairs) in enumerate(jobs):
             if pre:
                 pre(i % N)
+            if self.phase_lock and N == 2:
+                # start this context's scale space when the other context's reaches its keypoint stages (hak_phase_event)
+                self.ah.check(self.ah.lib.hak_wait_event(self.dets[i % N].ctx, self.phase_ev[(i + 1) % N]))
             self.enqueue(i % N, imgs, npairs)
             if i >= N - 1:
                 j = i - (N - 1)

@@ -197,6 +197,7 @@ struct hak_ctx {
     HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
     hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
     hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
+    hipEvent_t ev_phase = nullptr;  // recorded in every detect sequence between the scale space and the keypoint stages (hak_phase_event)
     hipStream_t sync_stream = nullptr;                            // where the last detect sequence ends (c->stream unless it was left on the chain)
     bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
     bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
@@ -374,6 +375,7 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming);
     // ... and so must the survivor bitmap and the row counts (hak_launch_clear_maps restores all three)
     if (e == hipSuccess) e = hipMemset(c->bitmap, 0, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
@@ -402,6 +404,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     // event recorded after the context's last enqueue instead of touching that stream
     if (c->ev_last) { (void)hipEventSynchronize(c->ev_last); (void)hipEventDestroy(c->ev_last); }
     if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
+    if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
     if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
@@ -431,6 +434,13 @@ extern "C" int hak_set_concurrency(hak_ctx* c, int on)
     if (!c) return fail("null context");
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->concurrent = on != 0;
+    return 0;
+}
+
+extern "C" int hak_phase_event(hak_ctx* c, void** ev)
+{
+    if (!c || !ev) return fail("null argument");
+    *ev = (void*)c->ev_phase;
     return 0;
 }
 
@@ -689,6 +699,24 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         if (c->concurrent)
             for (int o = 1; o < L.noct; o++)
                 if (hipStreamWaitEvent(main_st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
+    }
+    // the scale space (bound by HBM stores) is done, the keypoint stages (bound by gathers and integer work) begin: a caller that
+    // runs two contexts lets the other one start its scale space here (hak_phase_event)
+    {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        hipGraph_t g = nullptr;
+        const hipGraphNode_t* deps = nullptr;
+        size_t ndeps = 0;
+        if (hipStreamGetCaptureInfo_v2(main_st, &cs, nullptr, &g, &deps, &ndeps) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        hipError_t pe;
+        if (cs == hipStreamCaptureStatusActive) {
+            // inside a capture a plain record would be a capture-internal dependency: the record becomes an event-record NODE behind
+            // the stream's current frontier, and the frontier moves to it
+            hipGraphNode_t node = nullptr;
+            pe = hipGraphAddEventRecordNode(&node, g, deps, ndeps, c->ev_phase);
+            if (pe == hipSuccess) pe = hipStreamUpdateCaptureDependencies(main_st, &node, 1, hipStreamSetCaptureDependencies);
+        } else pe = hipEventRecord(c->ev_phase, main_st);
+        if (pe != hipSuccess) { fprintf(stderr, "hipakaze: phase event record: %s\n", hipGetErrorString(pe)); (void)hipGetLastError(); }
     }
     bool tail_fork = false;
     { ProfScope ps(c, HAK_PROF_NMS);                                              // akaze.cpp:449-455

@@ -90,6 +90,11 @@ int hak_sync(hak_ctx* ctx);
 /* make the context's stream wait for a hipEvent_t recorded elsewhere (e.g. the end of an upload on a copy stream) without
  * blocking the host: everything enqueued on the context afterwards runs behind the event */
 int hak_wait_event(hak_ctx* ctx, void* hip_event);
+/* the context's phase event (a hipEvent_t owned by the context): every float detect sequence records it where its scale space
+ * (FED / Hessian kernels: bound by HBM stores) ends and its keypoint stages (NMS, orientation, MLDB, then the caller's match:
+ * bound by gathers and integer work) begin.  A caller that keeps two contexts busy makes each one's next sequence wait for the
+ * OTHER one's phase event (hak_wait_event): the two kinds of work then run beside each other instead of in lockstep. */
+int hak_phase_event(hak_ctx* ctx, void** hip_event);
 /* 1 (default): octaves run on their own HIP streams (octave o+1 depends only on Lt(o,0), akaze.cpp:371-375);
  * 0: one stream, strictly serial launches (used for per-kernel timing). Env HAK_SERIAL=1 presets 0. */
 int hak_set_concurrency(hak_ctx* ctx, int on);

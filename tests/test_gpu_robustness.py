@@ -354,6 +354,41 @@ def test_wait_event_orders_context_behind_copy_stream(ah, torch, synth):
     det.close()
 
 
+def test_phase_event_interlocks_two_contexts(ah, torch, synth):
+    """hak_phase_event: each of two batch contexts starts its sequence behind the OTHER one's phase event (what bench.py's
+    pipeline does): replayed graphs record the event as a node of their own, results equal the un-interlocked run's"""
+    w, h, mp, B = 480, 360, 1500, 4
+    p = ah.iAlignUp(w, 128)
+    host = np.stack([synth.to_float(_mg().case_scene(w, h, 700 + i), p) for i in range(B)])
+    d_in = torch.from_numpy(host).cuda()
+    dets, evs, pts, num = [], [], [], []
+    for k in range(2):
+        d = ah.Akazer()
+        d.init((w, h, p), max_pts=mp, batch=B)
+        ev = C.c_void_p()
+        ah.check(ah.lib.hak_phase_event(d.ctx, C.byref(ev)))
+        assert ev.value
+        dets.append(d)
+        evs.append(ev)
+        pts.append(torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda"))
+        num.append(torch.zeros(B, dtype=torch.int32, device="cuda"))
+    outs = []
+    for lock in (False, True, True):
+        for i in range(6):                                          # (the second and later rounds replay captured graphs)
+            k = i % 2
+            if lock:
+                ah.check(ah.lib.hak_wait_event(dets[k].ctx, evs[1 - k]))
+            ah.check(ah.lib.hak_detect_and_compute_batch(dets[k].ctx, d_in.data_ptr(), h * p, p, B, pts[k].data_ptr(), num[k].data_ptr(), 1))
+        for k in range(2):
+            ah.check(ah.lib.hak_sync(dets[k].ctx))
+            outs.append((num[k].cpu().numpy().copy(), pts[k].cpu().numpy().copy()))
+    assert outs[0][0].min() > 20
+    for n, q in outs[1:]:
+        assert np.array_equal(n, outs[0][0]) and np.array_equal(q, outs[0][1])
+    for d in dets:
+        d.close()
+
+
 def test_download_batch_pinned_and_pageable(ah, torch, synth):
     """hak_download_batch: pinned destinations take the one-kernel zero-copy path, pageable ones the per-image copies;
     both must deliver every image's count and the valid prefix of its records"""
