@@ -285,7 +285,8 @@ class Pipeline:
             self.h_pts.append(hp)
             self.h_num.append(hn)
         self.nctx = nctx
-        self.phase_lock = os.environ.get("HAK_BENCH_PHASE_LOCK", "1") != "0"
+        # off by default: +1.4 % at 1080p in one A/B, nothing in the next, -3 % at 720p
+        self.phase_lock = os.environ.get("HAK_BENCH_PHASE_LOCK", "0") != "0"
         self.phase_ev = []
         for k in range(nctx):
             ev = C.c_void_p()
