@@ -632,32 +632,46 @@ static HakKnobs knobs_of(const HakBatch& b) { return b.knobs ? *b.knobs : hak_kn
 // with all levels mixed (the reference's order: the output keeps it), so consecutive blocks gather from sixteen different plane
 // pairs.  perm = the stable counting sort of the indices by level: consecutive blocks then work on neighbouring patches of ONE
 // pair of planes, whose lines they share in L2 (describe class 5.08 -> 4.99 ms per 384 x 1080p images: the kernels are bound by
-// the texture addresser, not by L2 misses, so the gain is small).  One wave per image; lane l keeps level l's running offset.
-__global__ __launch_bounds__(64) void k_desc_perm(const HakImgState* __restrict__ state, const hak_point* __restrict__ points, int max_pts,
-                                                  int* __restrict__ perm, int nlayers)
+// the texture addresser, not by L2 misses, so the gain is small).  One block per image; in every wave lane l keeps level l's
+// running offset.
+#define PERM_WAVES 16
+__global__ __launch_bounds__(64 * PERM_WAVES) void k_desc_perm(const HakImgState* __restrict__ state, const hak_point* __restrict__ points,
+                                                              int max_pts, int* __restrict__ perm, int nlayers)
 {
-    const int img = blockIdx.x, lane = threadIdx.x;
+    // wave w takes the w-th contiguous slice of the image's keypoints (the sort is stable: slices in order, indices in order)
+    __shared__ int cnts[PERM_WAVES][64];
+    const int img = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int npts = min(state[img].num_pts, max_pts);
     const hak_point* pts = points + (long)img * max_pts;
     int* pm = perm + (long)img * max_pts;
+    const int per = ((npts + PERM_WAVES - 1) / PERM_WAVES + 63) & ~63;
+    const int i_beg = min(wv * per, npts), i_end = min(i_beg + per, npts);
     int cnt = 0;
-    for (int i0 = 0; i0 < npts; i0 += 64) {
+    for (int i0 = i_beg; i0 < i_end; i0 += 64) {
         const int i = i0 + lane;
-        const int layer = i < npts ? pts[i].octave : -1;
+        const int layer = i < i_end ? pts[i].octave : -1;
         for (int l = 0; l < nlayers; l++) {
             const unsigned long long m = __ballot(layer == l);
             if (lane == l) cnt += __popcll(m);
         }
     }
-    int run = cnt;
+    cnts[wv][lane] = cnt;
+    __syncthreads();
+    int total = 0, before = 0;                                      // level `lane`: keypoints in the whole image / in earlier slices
+    for (int w = 0; w < PERM_WAVES; w++) {
+        const int c = cnts[w][lane];
+        total += c;
+        if (w < wv) before += c;
+    }
+    int run = total;
     for (int d = 1; d < 64; d <<= 1) {
         const int v = __shfl_up(run, d);
         if (lane >= d) run += v;
     }
-    run -= cnt;                                                     // exclusive: where level `lane` starts
-    for (int i0 = 0; i0 < npts; i0 += 64) {
+    run += before - total;                                          // where this slice's part of level `lane` starts
+    for (int i0 = i_beg; i0 < i_end; i0 += 64) {
         const int i = i0 + lane;
-        const int layer = i < npts ? pts[i].octave : -1;
+        const int layer = i < i_end ? pts[i].octave : -1;
         for (int l = 0; l < nlayers; l++) {
             const unsigned long long m = __ballot(layer == l);
             const int base = __shfl(run, l);
@@ -672,7 +686,7 @@ static const int* launch_perm(hipStream_t st, const HakBatch& b, const HakLayout
     // mode 1: batches only -- a single image's call is launch-bound and would pay ~15 us for the extra kernel
     if (!kn.desc_sort || (kn.desc_sort == 1 && b.nimg < 8) || !b.perm || max_pts > b.perm_cap || nlayers > 64) return nullptr;
     // (row stride of perm = the call's max_pts, which is at most perm_cap)
-    k_desc_perm<<<b.nimg, 64, 0, st>>>(b.state, points, max_pts, b.perm, nlayers);
+    k_desc_perm<<<b.nimg, 64 * PERM_WAVES, 0, st>>>(b.state, points, max_pts, b.perm, nlayers);
     return b.perm;
 }
 
