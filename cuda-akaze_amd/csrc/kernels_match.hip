@@ -184,6 +184,178 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
     }
 }
 
+// ---- matrix-core variant.  Hamming distances are integer dot products: |a ^ b| = sum_k a_k (1 - 2 b_k) + |b|.  The train side
+// supplies x_k = a_k, the query side y_k = 1 - 2 b_k (+1 / -1), and |b| rides along in spare positions of the padded K = 512 (four
+// int8 chunks of |b| against constants), so sixteen v_mfma_i32_32x32x32_i8 leave the exact distances of 32 train x 32 query
+// descriptors in the accumulator: 1 024 distances for 16 x 32 cycles of the matrix pipe instead of 1 024 x 32 VALU
+// lane-operations (v_bcnt_u32_b32 is a slow-rate instruction on this part: the VALU kernel k_match above already sits near what
+// the vector pipe can do with it).  To make the train side's bit -> int8 expansion ONE v_and_b32 per four k, bit t of a nibble
+// stays where it is: x_k = a_k 2^t (mask 0x01010101 << t), y_k = (1 - 2 b_k) 2^(3-t), every product is +-8 a_k and the
+// accumulator holds 8 x the distance (the |b| chunks meet the constant 8).
+//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h, AND-ed with
+//                      0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
+//   B (query, cols n): the same bits of query q0 + r as +-2^(3-t); expanded ONCE per wave into 64 VGPRs
+//   C/D: lane (n = l & 31, h) holds train rows (i & 3) + 8 (i >> 2) + 4 h, i < 16, of query n (cdna_hip_programming.md 158)
+// Any assignment of descriptor bits to k positions is fine as long as A and B agree: both come from mm_* below.  Per accumulator
+// element the epilogue is one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32 into the running minimum of
+// ITS register slot -- all rows a slot ever sees are congruent mod 16, i.e. one residue class -- so the reference's "first strict
+// minimum per class" survives as the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set;
+// no LDS, no barriers.
+typedef int mm_v4i __attribute__((ext_vector_type(4)));
+typedef int mm_v16i __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ unsigned mm_chunks3(unsigned p, unsigned& c3)     // p <= 488 as four int8 <= 127: three in bytes 1..3, the fourth in c3
+{
+    const unsigned c0 = min(p, 127u), c1 = min(p - c0, 127u), c2 = min(p - c0 - c1, 127u);
+    c3 = p - c0 - c1 - c2;
+    return (c0 << 8) | (c1 << 16) | (c2 << 24);
+}
+// train fragment of one descriptor dword: x = a 2^t
+__device__ __forceinline__ mm_v4i mm_frag_a(unsigned dword, int h)
+{
+    const unsigned w = dword >> (4 * h);
+    mm_v4i f;
+    f.x = (int)(w & 0x01010101u); f.y = (int)(w & 0x02020202u); f.z = (int)(w & 0x04040404u); f.w = (int)(w & 0x08080808u);
+    return f;
+}
+// query fragment: y = (1 - 2 b) 2^(3-t) per byte = S ^ (b * (S ^ (256 - S))), S = 2^(3-t) (no carries between the bytes)
+__device__ __forceinline__ mm_v4i mm_frag_b(unsigned dword, int h)
+{
+    const unsigned w = dword >> (4 * h);
+    mm_v4i f;
+    f.x = (int)(0x08080808u ^ ((w & 0x01010101u) * 0xF0u));
+    f.y = (int)(0x04040404u ^ (((w >> 1) & 0x01010101u) * 0xF8u));
+    f.z = (int)(0x02020202u ^ (((w >> 2) & 0x01010101u) * 0xFCu));
+    f.w = (int)(0x01010101u ^ (((w >> 3) & 0x01010101u) * 0xFEu));
+    return f;
+}
+__device__ __forceinline__ void mm_load(const hak_point* __restrict__ pts, int j, int jend, unsigned int (&d)[16])
+{
+    if (j < jend) {
+        // features start at byte 24 of the 104-byte record: 8-byte aligned
+        const uint2* f = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts + j) + offsetof(hak_point, features));
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint2 v = f[i]; d[2 * i] = v.x; d[2 * i + 1] = v.y; }
+        d[15] &= 0xFFu;                         // byte 60 only; bytes 61..63 are struct padding
+    } else {
+#pragma unroll
+        for (int i = 0; i < 16; i++) d[i] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
+                                                       const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
+                                                       int n1_host, int n2_host, long stride1, long stride2, int count_stride,
+                                                       unsigned* __restrict__ gkey, int tiles_per_slice)
+{
+    const int pair = gkey ? 0 : blockIdx.y;
+    const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
+    const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
+    hak_point* pts1 = pts1_base + (long)pair * stride1;
+    const hak_point* __restrict__ pts2 = pts2_base + (long)pair * stride2;
+    const int jbeg = gkey ? (int)blockIdx.y * tiles_per_slice * MT : 0;      // (multiples of 32: rows keep their residue class)
+    const int jend = gkey ? min(n2, jbeg + tiles_per_slice * MT) : n2;
+    const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // dword 15 holds byte 60 only, so bytes 1..3 of its fragments are spare k positions: the first four of lane half 0 carry |b|
+    // (train side: the constant 8 = the scale of every other product; query side: four chunks of |b|)
+    const unsigned a15x = h ? 0u : 0x08080800u, a15y = h ? 0u : 0x00000800u;
+    for (int q0 = (blockIdx.x * 4 + wv) * 32; q0 < n1; q0 += gridDim.x * 4 * 32) {      // wave-uniform
+        mm_v4i B[16];
+        {
+            unsigned int qd[16];
+            mm_load(pts1, q0 + r, n1, qd);
+            unsigned pb = 0;
+#pragma unroll
+            for (int i = 0; i < 16; i++) pb = bcnt_acc(qd[i], pb);
+#pragma unroll
+            for (int s = 0; s < 16; s++) B[s] = mm_frag_b(qd[s], h);
+            unsigned c3;
+            const unsigned c012 = mm_chunks3(pb, c3);
+            // (the spare bytes of B[15] hold +2^(3-t) from the zero bits there: replaced where the train side is non-zero)
+            if (h == 0) { B[15].x = (int)(((unsigned)B[15].x & 0xFFu) | c012); B[15].y = (int)(((unsigned)B[15].y & 0xFFFF00FFu) | (c3 << 8)); }
+        }
+        unsigned best[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) best[i] = 0xFFFFFFFFu;
+        // one tile: 32 train descriptors j0 .. j0 + 31 from CUR; NXT is loaded for the tile after it
+#define MM_TILE(CUR, NXT, J0)                                                                               \
+        {                                                                                                   \
+            mm_load(pts2, (J0) + 32 + r, jend, NXT);                                                        \
+            mm_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                 \
+            _Pragma("unroll") for (int s = 0; s < 15; s++)                                                  \
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(mm_frag_a(CUR[s], h), B[s], acc, 0, 0, 0);      \
+            {                                                                                               \
+                mm_v4i last = mm_frag_a(CUR[15], h);                                                        \
+                last.x |= (int)a15x; last.y |= (int)a15y;                                                   \
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(last, B[15], acc, 0, 0, 0);                     \
+            }                                                                                               \
+            const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
+            if ((J0) + 32 <= jend) {                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 16; i++) best[i] = min(best[i], ((unsigned)acc[i] << 17) + jb); \
+            } else {                        /* last, partial tile: rows past jend do not exist */            \
+                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
+                    const int row = (i & 3) + 8 * (i >> 2);                                                 \
+                    const unsigned key = ((unsigned)acc[i] << 17) + jb;                                     \
+                    best[i] = min(best[i], (int)jb + row < jend ? key : 0xFFFFFFFFu);                       \
+                }                                                                                           \
+            }                                                                                               \
+        }
+        unsigned int ta[16], tb[16];
+        mm_load(pts2, jbeg + r, jend, ta);
+        for (int j0 = jbeg; j0 < jend; j0 += 64) {                  // two tiles per round: the buffers swap roles without copies
+            MM_TILE(ta, tb, j0)
+            if (j0 + 32 < jend) MM_TILE(tb, ta, j0 + 32)
+        }
+#undef MM_TILE
+        // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset, then slots i and i + 8 (rows 16
+        // apart) are one residue class: cls[k], k < 8 = class (k & 3) + 8 (k >> 2) + 4 h
+        unsigned cls[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned lo = best[k] == 0xFFFFFFFFu ? best[k] : best[k] + (unsigned)((k & 3) + 8 * (k >> 2));
+            const unsigned hi = best[k + 8] == 0xFFFFFFFFu ? best[k + 8] : best[k + 8] + (unsigned)((k & 3) + 8 * (k >> 2) + 16);
+            cls[k] = min(lo, hi);
+        }
+        const int qi = q0 + r;
+        if (gkey) {                                                 // (uniform) sliced search: merge, k_match_finish decides
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (qi < n1 && cls[k] != 0xFFFFFFFFu) atomicMin(&gkey[(long)qi * MC + (k & 3) + 8 * (k >> 2) + 4 * h], cls[k]);
+            continue;
+        }
+        // the other half of the query's classes sits in lane ^ 32; distances only decide (key >> 20): the accept rule compares
+        // class minima, not indices (akazed.cu:2190-2223)
+        unsigned all[16];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { all[k] = cls[k]; all[8 + k] = (unsigned)__shfl_xor((int)cls[k], 32); }
+        unsigned kmin = all[0];
+#pragma unroll
+        for (int t = 1; t < 16; t++) {
+            // ties between classes never matter for the result (nflag below rejects them), any deterministic pick will do
+            if ((all[t] >> 20) < (kmin >> 20)) kmin = all[t];
+        }
+        const int dmin = (int)(kmin >> 20);
+        int nflag = 0;
+#pragma unroll
+        for (int t = 0; t < 16; t++) nflag += (unsigned)dmin < (all[t] >> 20) ? 1 : 0;                    // akazed.cu:2206
+        if (h == 0 && qi < n1) {
+            hak_point* p1 = pts1 + qi;
+            const int bi = (int)(kmin & 0xFFFFFu);
+            if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {                         // akazed.cu:2223
+                p1->match = bi;
+                p1->distance = dmin;
+                p1->match_x = pts2[bi].x;
+                p1->match_y = pts2[bi].y;
+            } else {
+                p1->match = -1;
+                p1->distance = -1;
+                p1->match_x = -1.f;
+                p1->match_y = -1.f;
+            }
+        }
+    }
+}
+
 // accept rule of gHammingMatch (akazed.cu:2190-2223) on the merged class minima of the sliced search; one thread per query
 __global__ __launch_bounds__(256) void k_match_finish(hak_point* pts1, const hak_point* pts2, int n1, const unsigned* __restrict__ gkey)
 {
@@ -351,18 +523,20 @@ void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pt
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, unsigned** scratch, long* cap)
 {
-    // two queries per thread halve the LDS traffic per distance but also the number of blocks: only when the grid still
-    // covers the chip a few times (batched pairs); one big pair (10k x 10k) keeps one query per thread
+    // k_match_mfma: a wave = 32 queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
+    static const bool valu = [] { const char* e = getenv("HAK_MATCH_VALU"); return e && atoi(e) != 0; }();
     const int nq = n1_dev ? 0 : n1_host;
-    const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;
-    const int qb = two ? 2 * MQ : MQ;
-    int gx = n1_dev ? (two ? 320 : 640) : (nq + qb - 1) / qb;
+    const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;    // (k_match only: queries per thread)
+    const int qb = valu ? (two ? 2 * MQ : MQ) : 128;                // queries per block
+    // device-side counts: k_match loops over the queries; k_match_mfma gets blocks for 10 240 queries (waves past n1 leave at once)
+    int gx = n1_dev ? (valu ? (two ? 320 : 640) : 80) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
     // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well
     const int tiles = (n2_host + MT - 1) / MT;
-    if (!n1_dev && npairs == 1 && !two && gx < 2048 && tiles >= 4) {
-        int slices = (2048 + gx - 1) / gx;
+    const int want = valu ? 2048 : 1536;                            // blocks
+    if (!n1_dev && npairs == 1 && !(valu && two) && gx < want && tiles >= 4) {
+        int slices = (want + gx - 1) / gx;
         if (slices > tiles / 2) slices = tiles / 2;
         const int tps = (tiles + slices - 1) / slices;
         slices = (tiles + tps - 1) / tps;
@@ -384,7 +558,8 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
             }
             if (keys) {
                 (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
-                k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
+                if (valu) k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
+                else k_match_mfma<<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
                 k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, keys);
                 if (transient) (void)hipFreeAsync(keys, st);
                 return;
@@ -392,6 +567,7 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
         }
     }
     dim3 grid(gx, npairs);
-    if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
+    if (!valu) k_match_mfma<<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
+    else if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
     else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
 }
