@@ -380,7 +380,7 @@ def other_configs(ah, synth, args, rank):
     pipe = Pipeline(ah, w, h, p, 128, max_pts, 2, torch_stream=False)
     out["pairs_per_s_720p_batch64"] = round(timed_throughput(pipe, d, 64, 6, 2), 1)
     pipe.close(); del d, pipe
-    # ---- configs[4]: 10k x 10k brute-force Hamming (k_match), HIP events around 20 launches
+    # ---- configs[4]: 10k x 10k brute-force Hamming (hak_match -> k_match_mfma + k_match_finish), 20 synchronous calls
     n = 10000
     q = synth.random_descriptors(n, 7, ah.POINT_DTYPE)
     t = synth.random_descriptors(n, 8, ah.POINT_DTYPE, planted_from=q, nplanted=4000)
@@ -398,6 +398,9 @@ def other_configs(ah, synth, args, rank):
     out["match_10k_ms"] = round(ms, 4)
     out["match_10k_valu_floor_ms"] = round(floor_ms, 4)
     out["match_10k_frac_of_floor"] = round(floor_ms / ms, 4)
+    # the kernel is k_match_mfma since round 3: 1e8 / 1024 tiles of 32 x 32 distances x 16 v_mfma_i32_32x32x32_i8 x 32 cycles on
+    # 1024 SIMDs at 2.4 GHz (the synchronous call also carries a memset, the finish kernel and the host's launch + wait)
+    out["match_10k_mfma_floor_ms"] = round(1e8 / 1024 * 16 * 32 / (1024 * 2.4e9) * 1e3, 4)
     return out
 
 

@@ -8,7 +8,11 @@
 // Distances are over exactly the 61 descriptor bytes (D9: the reference reads
 // 3 bytes past them); n2 < 16 and n2 == 0 are handled (D10).
 //
-// Mapping: a 256-thread block owns 32 queries x 16 residue classes.  Thread
+// Two kernels with identical results: k_match_mfma (the default, below: Hamming distances as int8 dot products on the matrix
+// cores) and k_match (HAK_MATCH_VALU=1: v_xor / v_bcnt on the vector pipe, kept for A/B runs and as the second reader of the
+// accept rule -- the tests run both).
+//
+// k_match mapping: a 256-thread block owns 32 queries x 16 residue classes.  Thread
 // (q, c) keeps the 64-byte descriptors of two queries in 32 VGPRs and walks class c with
 // 16 x (v_xor, v_bcnt) per distance; the train descriptors are staged through LDS
 // in tiles of 128 (coalesced, once per block, the next tile's loads in flight during the compares) and read back with broadcast
@@ -192,27 +196,33 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 // the vector pipe can do with it).  To make the train side's bit -> int8 expansion ONE v_and_b32 per four k, bit t of a nibble
 // stays where it is: x_k = a_k 2^t (mask 0x01010101 << t), y_k = (1 - 2 b_k) 2^(3-t), every product is +-8 a_k and the
 // accumulator holds 8 x the distance (the |b| chunks meet the constant 8).
-//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h, AND-ed with
-//                      0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
+//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h (by the thread
+//                      that stages the tile), AND-ed with 0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
 //   B (query, cols n): the same bits of query q0 + r as +-2^(3-t); expanded ONCE per wave into 64 VGPRs
 //   C/D: lane (n = l & 31, h) holds train rows (i & 3) + 8 (i >> 2) + 4 h, i < 16, of query n (cdna_hip_programming.md 158)
 // Any assignment of descriptor bits to k positions is fine as long as A and B agree: both come from mm_* below.  Per accumulator
 // element the epilogue is one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32 into the running minimum of
 // ITS register slot -- all rows a slot ever sees are congruent mod 16, i.e. one residue class -- so the reference's "first strict
 // minimum per class" survives as the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set;
-// no LDS, no barriers.
+// the four waves of a block share every train tile through LDS: one coalesced 8-byte load and one ds_write_b64 per thread and
+// tile (a lane fetching ITS descriptor row straight from the 104-byte records touches 32 different lines per load instruction:
+// that version ran at a third of the matrix pipe's rate, bound by the texture addresser), rows padded to 80 bytes so that the
+// four ds_read_b128 per lane and tile are conflict-free, double-buffered with one barrier per tile.
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
+#define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
+#define MM_FRAG(TD, s) mm_frag_a(TD[s])
+#define MM_ROW 36       // dwords per staged train row: the 16 descriptor dwords, the same 16 shifted right by 4 (lane half 1 reads
+                        // those: no shift in the tile loop), 4 of padding (144-byte rows make the ds_read_b128 conflict-free)
 __device__ __forceinline__ unsigned mm_chunks3(unsigned p, unsigned& c3)     // p <= 488 as four int8 <= 127: three in bytes 1..3, the fourth in c3
 {
     const unsigned c0 = min(p, 127u), c1 = min(p - c0, 127u), c2 = min(p - c0 - c1, 127u);
     c3 = p - c0 - c1 - c2;
     return (c0 << 8) | (c1 << 16) | (c2 << 24);
 }
-// train fragment of one descriptor dword: x = a 2^t
-__device__ __forceinline__ mm_v4i mm_frag_a(unsigned dword, int h)
+// train fragment of one descriptor dword (already shifted right by 4 h): x = a 2^t
+__device__ __forceinline__ mm_v4i mm_frag_a(unsigned w)
 {
-    const unsigned w = dword >> (4 * h);
     mm_v4i f;
     f.x = (int)(w & 0x01010101u); f.y = (int)(w & 0x02020202u); f.z = (int)(w & 0x04040404u); f.w = (int)(w & 0x08080808u);
     return f;
@@ -242,7 +252,7 @@ __device__ __forceinline__ void mm_load(const hak_point* __restrict__ pts, int j
     }
 }
 
-__global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
+__global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
                                                        unsigned* __restrict__ gkey, int tiles_per_slice)
@@ -259,7 +269,9 @@ __global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ p
     // dword 15 holds byte 60 only, so bytes 1..3 of its fragments are spare k positions: the first four of lane half 0 carry |b|
     // (train side: the constant 8 = the scale of every other product; query side: four chunks of |b|)
     const unsigned a15x = h ? 0u : 0x08080800u, a15y = h ? 0u : 0x00000800u;
-    for (int q0 = (blockIdx.x * 4 + wv) * 32; q0 < n1; q0 += gridDim.x * 4 * 32) {      // wave-uniform
+    __shared__ __attribute__((aligned(16))) unsigned int tile[2][32 * MM_ROW];
+    for (int qb = blockIdx.x * 128; qb < n1; qb += gridDim.x * 128) {                   // block-uniform: every wave takes part in the staging
+        const int q0 = qb + 32 * wv;                                                    // (a wave past n1 computes on zeros and stores nothing)
         mm_v4i B[16];
         {
             unsigned int qd[16];
@@ -277,17 +289,25 @@ __global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ p
         unsigned best[16];
 #pragma unroll
         for (int i = 0; i < 16; i++) best[i] = 0xFFFFFFFFu;
-        // one tile: 32 train descriptors j0 .. j0 + 31 from CUR; NXT is loaded for the tile after it
-#define MM_TILE(CUR, NXT, J0)                                                                               \
+        // the lane's 16 dwords of tile BUF (row r, half h) -> TD
+#define MM_READ(BUF, TD)                                                                                    \
         {                                                                                                   \
-            mm_load(pts2, (J0) + 32 + r, jend, NXT);                                                        \
+            const uint4* row = reinterpret_cast<const uint4*>(tile[BUF] + r * MM_ROW + 16 * h);             \
+            _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                 \
+                const uint4 v = row[c];                                                                     \
+                TD[4 * c] = v.x; TD[4 * c + 1] = v.y; TD[4 * c + 2] = v.z; TD[4 * c + 3] = v.w;             \
+            }                                                                                               \
+        }
+        // one tile: 32 train descriptors j0 .. j0 + 31 from registers TD
+#define MM_TILE(TD, J0)                                                                                     \
+        {                                                                                                   \
             mm_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                 \
             _Pragma("unroll") for (int s = 0; s < 15; s++)                                                  \
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(mm_frag_a(CUR[s], h), B[s], acc, 0, 0, 0);      \
+                acc = MM_MFMA(MM_FRAG(TD, s), B[s], acc);                                                   \
             {                                                                                               \
-                mm_v4i last = mm_frag_a(CUR[15], h);                                                        \
+                mm_v4i last = mm_frag_a(TD[15]);                                                            \
                 last.x |= (int)a15x; last.y |= (int)a15y;                                                   \
-                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(last, B[15], acc, 0, 0, 0);                     \
+                acc = MM_MFMA(last, B[15], acc);                                                            \
             }                                                                                               \
             const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
             if ((J0) + 32 <= jend) {                                                                        \
@@ -300,13 +320,50 @@ __global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ p
                 }                                                                                           \
             }                                                                                               \
         }
+        // thread t stages dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptor j0 + (t >> 3)
+        auto fetch = [&](int j0) -> uint2 {
+            const int j = j0 + (int)(threadIdx.x >> 3);
+            uint2 v = make_uint2(0u, 0u);
+            if (j < jend) {
+                v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2 + j) + offsetof(hak_point, features) + 8 * (threadIdx.x & 7));
+                if ((threadIdx.x & 7) == 7) v.y &= 0xFFu;           // byte 60 only; bytes 61..63 are struct padding
+            }
+            return v;
+        };
+        auto stage = [&](int buf, const uint2 v) {
+            unsigned int* row = tile[buf] + (threadIdx.x >> 3) * MM_ROW + 2 * (threadIdx.x & 7);
+            *reinterpret_cast<uint2*>(row) = v;
+            *reinterpret_cast<uint2*>(row + 16) = make_uint2(v.x >> 4, v.y >> 4);
+        };
+        // Pipeline, one barrier per tile: while tile t is multiplied out of registers, tile t+1 travels LDS -> registers and
+        // tile t+2 global -> registers -> LDS (into the buffer tile t was read from an iteration ago).
+        __syncthreads();                                            // (the previous query group's tiles have been read)
+        stage(0, fetch(jbeg));
+        stage(1, fetch(jbeg + 32));
+        __syncthreads();
         unsigned int ta[16], tb[16];
-        mm_load(pts2, jbeg + r, jend, ta);
-        for (int j0 = jbeg; j0 < jend; j0 += 64) {                  // two tiles per round: the buffers swap roles without copies
-            MM_TILE(ta, tb, j0)
-            if (j0 + 32 < jend) MM_TILE(tb, ta, j0 + 32)
+        MM_READ(0, ta)
+        __syncthreads();                                            // (buffer 0 is free again)
+        for (int j0 = jbeg; j0 < jend; j0 += 64) {
+            {
+                const uint2 nx = fetch(j0 + 64);
+                MM_READ(1, tb)
+                __builtin_amdgcn_sched_barrier(0);                  // (the LDS reads are issued here, not sunk to their uses)
+                MM_TILE(ta, j0)
+                stage(0, nx);
+                __syncthreads();
+            }
+            if (j0 + 32 < jend) {                                   // (uniform)
+                const uint2 nx = fetch(j0 + 96);
+                MM_READ(0, ta)
+                __builtin_amdgcn_sched_barrier(0);
+                MM_TILE(tb, j0 + 32)
+                stage(1, nx);
+                __syncthreads();
+            }
         }
 #undef MM_TILE
+#undef MM_READ
         // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset, then slots i and i + 8 (rows 16
         // apart) are one residue class: cls[k], k < 8 = class (k & 3) + 8 (k >> 2) + 4 h
         unsigned cls[8];
@@ -340,7 +397,7 @@ __global__ __launch_bounds__(256, 3) void k_match_mfma(hak_point* __restrict__ p
         for (int t = 0; t < 16; t++) nflag += (unsigned)dmin < (all[t] >> 20) ? 1 : 0;                    // akazed.cu:2206
         if (h == 0 && qi < n1) {
             hak_point* p1 = pts1 + qi;
-            const int bi = (int)(kmin & 0xFFFFFu);
+            const int bi = min((int)(kmin & 0xFFFFFu), max(n2 - 1, 0));       // (always the index itself: belt and braces for the gather below)
             if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {                         // akazed.cu:2223
                 p1->match = bi;
                 p1->distance = dmin;
@@ -524,12 +581,15 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, unsigned** scratch, long* cap)
 {
     // k_match_mfma: a wave = 32 queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
-    static const bool valu = [] { const char* e = getenv("HAK_MATCH_VALU"); return e && atoi(e) != 0; }();
+    const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call: the tests run both kernels in one process)
+    const bool valu = env_valu && atoi(env_valu) != 0;
     const int nq = n1_dev ? 0 : n1_host;
     const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;    // (k_match only: queries per thread)
     const int qb = valu ? (two ? 2 * MQ : MQ) : 128;                // queries per block
     // device-side counts: k_match loops over the queries; k_match_mfma gets blocks for 10 240 queries (waves past n1 leave at once)
-    int gx = n1_dev ? (valu ? (two ? 320 : 640) : 80) : (nq + qb - 1) / qb;
+    // (83, not 80: blocks go to the eight XCDs by linear index mod 8, and with a multiple of 8 per pair the ~18 blocks of every pair
+    // that find queries would land on the same XCDs pair after pair -- two XCDs with three of them, six with two: 1.33 x the mean)
+    int gx = n1_dev ? (valu ? (two ? 320 : 640) : 83) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
     // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well

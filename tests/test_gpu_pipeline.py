@@ -316,9 +316,18 @@ def gpu_match(ah, torch, p1, p2):
     return out
 
 
+@pytest.fixture(params=["0", "1"], ids=["k_match_mfma", "k_match (VALU)"])
+def match_kernel(request, monkeypatch):
+    """both matcher kernels: the matrix-core one (default) and the vector-pipe one (HAK_MATCH_VALU=1, read per call)"""
+    monkeypatch.setenv("HAK_MATCH_VALU", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("n1,n2", [(1000, 1000), (37, 5), (5, 37), (16, 16), (300, 0), (1, 1), (2205, 2382),
-                                   (300, 5000), (3000, 7777), (40, 1023), (40, 1025), (5000, 600)])   # sliced / unsliced train sets
-def test_match_vs_oracle(ah, okz, torch, synth, n1, n2):
+                                   (300, 5000), (3000, 7777), (40, 1023), (40, 1025), (5000, 600),     # sliced / unsliced train sets
+                                   # around the 32 x 32 tiles, the 128-query blocks and the 64-row rounds of k_match_mfma
+                                   (33, 31), (129, 33), (31, 64), (65, 65), (200, 96), (128, 2047), (127, 97), (256, 32)])
+def test_match_vs_oracle(ah, okz, torch, synth, match_kernel, n1, n2):
     base = synth.random_descriptors(max(n2, 1), 7, ah.POINT_DTYPE)[:n2]
     q = synth.random_descriptors(n1, 8, ah.POINT_DTYPE, planted_from=base if n2 else None,
                                  nplanted=min(n1, n2) // 2, maxflip=60)
@@ -332,7 +341,7 @@ def test_match_vs_oracle(ah, okz, torch, synth, n1, n2):
         assert (got["match"] >= 0).sum() > 0
 
 
-def test_match_ties_across_tiles_and_slices(ah, okz, torch, synth):
+def test_match_ties_across_tiles_and_slices(ah, okz, torch, synth, match_kernel):
     """the accept rule counts the residue classes that attain the minimum (akazed.cu:2206) and every class keeps its FIRST minimum:
     a train set made of repeated descriptors puts equal distances into different LDS tiles, different classes and -- for the big
     pair -- different train slices, whose packed keys are merged with atomicMin"""
@@ -357,7 +366,7 @@ def test_match_ties_across_tiles_and_slices(ah, okz, torch, synth):
         assert 0 < (got["match"] >= 0).sum() < n1               # both outcomes of the rule occur
 
 
-def test_match_10k_x_10k(ah, okz, torch, synth):
+def test_match_10k_x_10k(ah, okz, torch, synth, match_kernel):
     """BASELINE.json config 5, full size: oracle equality + size-independent properties"""
     train = synth.random_descriptors(10000, 7, ah.POINT_DTYPE)
     query = synth.random_descriptors(10000, 9, ah.POINT_DTYPE, planted_from=train, nplanted=2000, maxflip=40)
