@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_extrema(const float* __restrict__ base,
 }
 
 // ---------------------------------------------------------------- NMS: mark
-// Candidate-driven disc NMS (akazed.cu:1554-1613): one thread per candidate of the image's list.
+// Candidate-driven disc NMS (akazed.cu:1554-1613): sixteen lanes per candidate of the image's list.
 // A candidate proceeds only if it still owns its pixel of the key map (several levels can hit the
 // same full-resolution pixel; exactly one key wins).  Survivors set their bit in the bitmap and
 // bump the per-row count; order is restored by k_row_scan + k_emit.
@@ -79,42 +79,61 @@ __global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __re
     const unsigned long long* map = maps + (long)img * map_stride;
     long n = state[img].ncand;
     n = n < cand_cap ? n : cand_cap;
-    for (long i = blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-        const unsigned long long e = cand[(long)img * cand_cap + i];
+    // Sixteen lanes per candidate: lane c looks at column x + c - isz of every row of the disc, so one load instruction covers a
+    // 36..72-byte piece of one row per candidate (1-2 lines) instead of 64 unrelated lines (one thread per candidate spent the
+    // kernel in the texture addresser: 81 line look-ups per candidate).  The group's verdict is the OR over its lanes (ballot).
+    const int grp = threadIdx.x >> 4, c = threadIdx.x & 15;
+    const int gsh = (threadIdx.x & 48);                             // the group's first bit in the wave's ballot
+    for (long i0 = (long)blockIdx.x * 16; i0 < n; i0 += (long)gridDim.x * 16) {        // (block-uniform)
+        const long i = i0 + grp;
+        bool live = i < n;
+        const unsigned long long e = live ? cand[(long)img * cand_cap + i] : 0ull;
         const int x = (int)(e & 0xFFFFu), y = (int)((e >> 16) & 0xFFFFu), layer = (int)(e >> 32);
-        if (!(x >= psz && x + psz < w && y >= psz && y + psz < h)) continue;
-        const unsigned long long kc = map[(long)y * p + x];
-        if (key_layer(kc) != layer) continue;                       // another level won this pixel
-        const unsigned rc = (unsigned)(kc >> 32);           // response word: unsigned order == order of positive floats / ints
-        const float fsz = tab->sizes[layer];
+        live = live && x >= psz && x + psz < w && y >= psz && y + psz < h;
+        const float fsz = live ? tab->sizes[layer] : 0.f;
         const int isz = (int)(fsz + 0.5f);
         const int sqsz = (int)(fsz * fsz);
-        // a thread walks its candidate's disc row by row; the row's response words are fetched eight at a time before any is
-        // looked at (the one-load-one-test loop spent 80 % of the kernel waiting for one sector after the other)
-        bool to_nms = false;
-        for (int di = -isz; di <= isz && !to_nms; di++) {
-            const unsigned* row = reinterpret_cast<const unsigned*>(map + (long)(y + di) * p + x) + 1;   // high words: row[2 * dj]
-            for (int dj0 = -isz; dj0 <= isz; dj0 += 8) {
-                unsigned rn[8];
+        // the candidate's own key (does it still own its pixel?) and the disc's rows are fetched together: one memory round trip
+        // per candidate instead of one for the key and one per row
+        const unsigned long long kc = live ? map[(long)y * p + x] : 0ull;
+        bool hit = false;
+        unsigned rc;
+        if (__ballot(isz > 4) == 0ull) {                            // (wave-uniform) discs of radius <= 4: nine rows, one column per lane
+            const int dj = c - isz;
+            unsigned rn[9];
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int dj = dj0 + u;
-                    const bool in = dj <= isz && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
-                    // akazed.cu:1581-1593: the reference's read cursor is not advanced by the `continue` of the centre, so on
-                    // the centre row every dj > 0 looks at column x + dj - 1 (dj == 1 at the centre itself) while the disc test
-                    // and the tie rule keep using dj -- followed literally
+            for (int k = 0; k < 9; k++) {
+                const int di = k - 4;
+                const bool in = live && di >= -isz && di <= isz && dj <= isz && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
+                // akazed.cu:1581-1593: the reference's read cursor is not advanced by the `continue` of the centre, so on
+                // the centre row every dj > 0 looks at column x + dj - 1 (dj == 1 at the centre itself) while the disc test
+                // and the tie rule keep using dj -- followed literally
+                const int col = dj - (int)(di == 0 && dj > 0);
+                rn[k] = in ? (reinterpret_cast<const unsigned*>(map + (long)(y + di) * p + x) + 1)[2 * col] : 0u;   // high words
+            }
+            rc = (unsigned)(kc >> 32);              // response word: unsigned order == order of positive floats / ints
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const int di = k - 4;
+                const bool in = live && di >= -isz && di <= isz && dj <= isz && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
+                hit = hit || (in && (rn[k] > rc || (rn[k] == rc && di <= 0 && dj <= 0)));
+            }
+        } else {                                                    // any radius: row by row
+            rc = (unsigned)(kc >> 32);
+            for (int di = -isz; di <= isz; di++) {
+                const unsigned* row = reinterpret_cast<const unsigned*>(map + (long)(y + di) * p + x) + 1;   // high words: row[2 * dj]
+                for (int dj = c - isz; dj <= isz; dj += 16) {
+                    const bool in = live && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
                     const int col = dj - (int)(di == 0 && dj > 0);
-                    rn[u] = in ? row[2 * col] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    const int dj = dj0 + u;
-                    const bool in = dj <= isz && !(di == 0 && dj == 0) && di * di + dj * dj < sqsz;
-                    if (in && (rn[u] > rc || (rn[u] == rc && di <= 0 && dj <= 0))) to_nms = true;
+                    const unsigned rn = in ? row[2 * col] : 0u;
+                    hit = hit || (in && (rn > rc || (rn == rc && di <= 0 && dj <= 0)));
                 }
             }
         }
-        if (!to_nms) {
+        live = live && key_layer(kc) == layer;                      // (else another level won this pixel)
+        const unsigned long long m = __ballot(hit);                 // (all lanes are back together here)
+        const bool to_nms = ((m >> gsh) & 0xFFFFull) != 0ull;
+        if (live && !to_nms && c == 0) {
             atomicOr(&bitmap[((long)img * h + y) * words_per_row + (x >> 6)], 1ull << (x & 63));
             atomicAdd(&rowcount[(long)img * h + y], 1);
         }
@@ -306,7 +325,7 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     const int w = L.oct[0].w, h = L.oct[0].h, p = L.oct[0].p;
     const int words = (w + 63) / 64;
     // (bitmap and rowcount are all zero here: hak_create, and every sequence's hak_launch_clear_maps)
-    dim3 g1(64, b.nimg);
+    dim3 g1(b.nimg >= 8 ? 128 : 256, b.nimg);
     k_nms_cand<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, tab, psz, w, h, p,
                                    b.bitmap, words, b.rowcount);
     k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
