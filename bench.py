@@ -267,6 +267,8 @@ class Pipeline:
     """NCTX contexts used round-robin: while batch i runs on the GPU, batch i-1 is synchronised and downloaded"""
 
     def __init__(self, ah, w, h, p, nimg, max_pts, nctx, octaves=4, upright=False, serial=False, torch_stream=True):
+        # serial = one stream per context instead of one per octave (hak_set_concurrency)
+        self.serial = bool(serial)
         self.ah, self.nimg, self.max_pts, self.h, self.p = ah, nimg, max_pts, h, p
         self.dets, self.d_pts, self.d_num, self.h_pts, self.h_num = [], [], [], [], []
         for k in range(nctx):
@@ -483,7 +485,9 @@ def main():
                     help="also time the integer FAST path (fastDetectAndCompute, uint8 inputs) on the same pairs")
     ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
     ap.add_argument("--serial", action="store_true",
-                    help="run the timed region on one stream too (default: octaves on concurrent streams)")
+                    help="one stream per context in the timed region (the default when two contexts are in flight)")
+    ap.add_argument("--concurrent", action="store_true",
+                    help="the octaves of a context on concurrent streams in the timed region (the default for --no-pipeline)")
     ap.add_argument("--single-pair-leg", action="store_true", help="internal: run only the one-pair-at-a-time leg of `configs` and print it")
     ap.add_argument("--launch", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 without a launcher always does)")
@@ -541,7 +545,12 @@ def main():
     d_imgs = torch.from_numpy(host).cuda()
     del host
 
-    pipe = Pipeline(ah, w, h, p, nimg, max_pts, NCTX, octaves=args.octaves, upright=args.upright, serial=args.serial)
+    # One stream per context when two contexts are in flight: the other context's launch sequence is what fills the small octaves'
+    # gaps then, and per-context octave streams only add event waits and contention for the runtime's four hardware queues
+    # (192 x 1080p pairs, A/B on one box: 5 947 / 5 969 vs 5 855 / 5 826 pairs/s).  A lone context wants its octaves on concurrent
+    # streams (5 647 vs 5 397), and so do the smaller launches of the 720p leg (10 850 vs 10 500): those keep the library's default.
+    pipe = Pipeline(ah, w, h, p, nimg, max_pts, NCTX, octaves=args.octaves, upright=args.upright,
+                    serial=True if args.serial else False if args.concurrent else NCTX >= 2)
     step_jobs = [(d_imgs, c) for c in chunks]
 
     pipe.run(step_jobs * args.warmup)
@@ -637,7 +646,7 @@ def main():
             ah.check(ah.lib.hak_prof_read(det.ctx, k, C.byref(m2), C.byref(n2)))
             cls_ms[name], cls_n[name] = m2.value / nprof, n2.value // nprof
         ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
-        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0 if args.serial else 1))
+        ah.check(ah.lib.hak_set_concurrency(det.ctx, 0 if pipe.serial else 1))
         tr = det.traffic(int(round(nkp / max(1, 2 * last_pairs))))
         nim = 2 * rl_pairs
         gb = C.c_double()
@@ -738,7 +747,7 @@ def main():
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
                        "pairs_per_step_per_gpu": my_pairs if strong else B, "pairs_per_launch_sequence": B,
                        "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
-                       "octave_streams": "serial" if args.serial else "concurrent", "step_pipeline": NCTX,
+                       "octave_streams": "one stream per context" if pipe.serial else "concurrent", "step_pipeline": NCTX,
                        "sharding": "independent pairs per rank, no data-path collective", "rank0_gpu_numa_node": numa_node,
                        "keypoints_per_image": round(summary[1] / max(1.0, 2.0 * summary[0]), 1),
                        "matches_per_pair": round(summary[2] / max(1.0, float(summary[0])), 1)},
