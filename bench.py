@@ -340,8 +340,8 @@ class Pipeline:
 
 def fit_batch(B, w, h, max_pts, nctx, floor=16):
     # arena = 15 float planes per octave pyramid (x 4/3) + key map 8 B/px + candidate list ~ 11 B/px ~ 100 B/px per image and
-    # context (207 MB at 1080p): 192 pairs x 2 contexts = 159 GB of the 288 GB.  Batch size is a batching choice, not part of the workload
-    # (measured, pairs/s: 96: 5665, 128: 5654, 144: 5752, 192: 5792).
+    # context (207 MB at 1080p): 256 pairs x 2 contexts = 214 GB of the 288 GB.  Batch size is a batching choice, not part of the workload
+    # (measured, pairs/s, round 2: 96: 5665, 128: 5654, 144: 5752, 192: 5792; round 3, one box: 128: 6040, 192: 6012, 240: 6123, 256: 6152).
     free_b = torch.cuda.mem_get_info()[0]
     while B > floor and 2 * B * (w * h * 100 + 2 * max_pts * 104) * nctx > 0.8 * free_b:
         B //= 2
@@ -467,7 +467,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--pairs", type=int, default=192, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
+    ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
     ap.add_argument("--total-pairs", type=int, default=0,
                     help="strong scaling: this many pairs per step over ALL ranks (rank r takes shard_pairs), in batches of --pairs")
     ap.add_argument("--width", type=int, default=1920)
@@ -636,7 +636,7 @@ def main():
         ah.check(ah.lib.hak_prof_reset(det.ctx))
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
-        rl_pairs = chunks[0]                # the per-class legs run the launch sequence of the timed region (192 pairs by default)
+        rl_pairs = chunks[0]                # the per-class legs run the launch sequence of the timed region (256 pairs by default)
         for _ in range(nprof):
             pipe.enqueue(0, d_imgs, rl_pairs)
             pipe.download(0, rl_pairs)
