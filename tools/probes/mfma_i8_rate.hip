@@ -11,9 +11,12 @@ __global__ __launch_bounds__(256) void k(const v4i* in, int* out, int n, long lo
     v16i c16 = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0};
     v4i c4 = {0,0,0,0};
     const long long t0 = __builtin_amdgcn_s_memtime();
-    for (int i = 0; i < n; i++) {
-        if (KIND == 0) c16 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c16, 0, 0, 0);
-        else c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c4, 0, 0, 0);
+    for (int i = 0; i < n; i += 16) {
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            if (KIND == 0) c16 = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c16, 0, 0, 0);
+            else c4 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c4, 0, 0, 0);
+        }
     }
     const long long t1 = __builtin_amdgcn_s_memtime();
     int s = 0;
@@ -34,12 +37,12 @@ template <int KIND> void run(const char* name, int blocks, int n)
     float ms; hipEventElapsedTime(&ms, a, b);
     long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
     const double waves_per_simd = blocks * 4.0 / 1024.0;
-    printf("%-12s blocks %5d (%.0f waves/SIMD)  n %6d  %.3f ms  -> %.1f ns per MFMA per SIMD slot;  s_memtime ticks per MFMA (block 0, 100 MHz): %.3f\n", name, blocks,
-           waves_per_simd, n, ms, ms * 1e6 / (n * waves_per_simd), (double)c / n);
+    printf("%-12s %.0f wave(s) per SIMD, one accumulation chain each, n = %d per wave: %.3f ms = %.1f ns per MFMA and SIMD = %.1f cycles at 2.4 GHz\n", name,
+           waves_per_simd, n, ms, ms * 1e6 / (n * waves_per_simd), ms * 1e6 / (n * waves_per_simd) * 2.4);
     hipFree(in); hipFree(out); hipFree(cyc);
 }
 int main()
 {
-    for (int blocks : {256, 512, 768}) { run<0>("32x32x32_i8", blocks, 20000); run<1>("16x16x64_i8", blocks, 20000); }
+    for (int blocks : {256, 512, 768}) { run<0>("32x32x32_i8", blocks, 32000); run<1>("16x16x64_i8", blocks, 32000); }
     return 0;
 }
