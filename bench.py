@@ -403,6 +403,20 @@ def other_configs(ah, synth, args, rank):
     # the kernel is k_match_mfma since round 3: 1e8 / 1024 tiles of 32 x 32 distances x 16 v_mfma_i32_32x32x32_i8 x 32 cycles on
     # 1024 SIMDs at 2.4 GHz (the synchronous call also carries a memset, the finish kernel and the host's launch + wait)
     out["match_10k_mfma_floor_ms"] = round(1e8 / 1024 * 16 * 32 / (1024 * 2.4e9) * 1e3, 4)
+    # 2-NN ratio test (4/5) + symmetric cross-check + device-side compaction on the same sets (two 10k x 10k searches)
+    d_out = torch.zeros(n * ah.MATCH_PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
+    cnt = C.c_int(0)
+
+    def knn():
+        ah.check(ah.lib.hak_match_knn2(None, dq.data_ptr(), n, dt.data_ptr(), n, 4, 5, 1, 0, None, d_out.data_ptr(), C.byref(cnt), None))
+    for _ in range(3):
+        knn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        knn()
+    out["match_knn2_10k_ms"] = round((time.perf_counter() - t0) * 1e3 / 10, 4)
+    out["match_knn2_10k_accepted"] = int(cnt.value)
     return out
 
 

@@ -252,10 +252,15 @@ __device__ __forceinline__ void mm_load(const hak_point* __restrict__ pts, int j
     }
 }
 
+// KNN = true: the 2-NN search of hak_match_knn2 on the same tiles -- per register slot the two smallest keys (min / max / min per
+// element), nearest neighbour = the smallest key of all slots (smallest index among equal distances), d2 = the smallest
+// distance of every OTHER train point; results go to knn_out[query] = {index, d1, d2, 0} instead of the point records.
+template <bool KNN>
 __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
-                                                       unsigned* __restrict__ gkey, int tiles_per_slice)
+                                                       unsigned* __restrict__ gkey, int tiles_per_slice,
+                                                       int4* __restrict__ knn_out_base, long knn_stride)
 {
     const int pair = gkey ? 0 : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
@@ -286,9 +291,11 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             // (the spare bytes of B[15] hold +2^(3-t) from the zero bits there: replaced where the train side is non-zero)
             if (h == 0) { B[15].x = (int)(((unsigned)B[15].x & 0xFFu) | c012); B[15].y = (int)(((unsigned)B[15].y & 0xFFFF00FFu) | (c3 << 8)); }
         }
-        unsigned best[16];
+        unsigned best[16], sec[KNN ? 16 : 1];
 #pragma unroll
         for (int i = 0; i < 16; i++) best[i] = 0xFFFFFFFFu;
+#pragma unroll
+        for (int i = 0; i < (KNN ? 16 : 1); i++) sec[i] = 0xFFFFFFFFu;
         // the lane's 16 dwords of tile BUF (row r, half h) -> TD
 #define MM_READ(BUF, TD)                                                                                    \
         {                                                                                                   \
@@ -311,12 +318,17 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             }                                                                                               \
             const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
             if ((J0) + 32 <= jend) {                                                                        \
-                _Pragma("unroll") for (int i = 0; i < 16; i++) best[i] = min(best[i], ((unsigned)acc[i] << 17) + jb); \
+                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
+                    const unsigned key = ((unsigned)acc[i] << 17) + jb;                                     \
+                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
+                    best[i] = min(best[i], key);                                                            \
+                }                                                                                           \
             } else {                        /* last, partial tile: rows past jend do not exist */            \
                 _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
                     const int row = (i & 3) + 8 * (i >> 2);                                                 \
-                    const unsigned key = ((unsigned)acc[i] << 17) + jb;                                     \
-                    best[i] = min(best[i], (int)jb + row < jend ? key : 0xFFFFFFFFu);                       \
+                    const unsigned key = (int)jb + row < jend ? ((unsigned)acc[i] << 17) + jb : 0xFFFFFFFFu; \
+                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
+                    best[i] = min(best[i], key);                                                            \
                 }                                                                                           \
             }                                                                                               \
         }
@@ -364,6 +376,32 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         }
 #undef MM_TILE
 #undef MM_READ
+        const int qi = q0 + r;
+        if constexpr (KNN) {
+            // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset to both of its keys; the query's
+            // other sixteen slots sit in lane ^ 32
+            unsigned b1[32], b2[32];
+#pragma unroll
+            for (int i = 0; i < 16; i++) {
+                const unsigned off = (unsigned)((i & 3) + 8 * (i >> 2));
+                b1[i] = best[i] == 0xFFFFFFFFu ? best[i] : best[i] + off;
+                b2[i] = sec[i] == 0xFFFFFFFFu ? sec[i] : sec[i] + off;
+                b1[16 + i] = (unsigned)__shfl_xor((int)b1[i], 32);
+                b2[16 + i] = (unsigned)__shfl_xor((int)b2[i], 32);
+            }
+            unsigned m1 = b1[0];
+#pragma unroll
+            for (int i = 1; i < 32; i++) m1 = min(m1, b1[i]);
+            unsigned m2 = 0xFFFFFFFFu;                              // the keys are distinct (they carry the index): one slot holds m1
+#pragma unroll
+            for (int i = 0; i < 32; i++) m2 = min(m2, b1[i] == m1 ? b2[i] : b1[i]);
+            if (h == 0 && qi < n1) {
+                int4* out = knn_out_base + (long)pair * knn_stride;
+                out[qi] = m1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
+                                            : make_int4((int)(m1 & 0xFFFFFu), (int)(m1 >> 20), m2 == 0xFFFFFFFFu ? 512 : (int)(m2 >> 20), 0);
+            }
+            continue;
+        }
         // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset, then slots i and i + 8 (rows 16
         // apart) are one residue class: cls[k], k < 8 = class (k & 3) + 8 (k >> 2) + 4 h
         unsigned cls[8];
@@ -373,7 +411,6 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             const unsigned hi = best[k + 8] == 0xFFFFFFFFu ? best[k + 8] : best[k + 8] + (unsigned)((k & 3) + 8 * (k >> 2) + 16);
             cls[k] = min(lo, hi);
         }
-        const int qi = q0 + r;
         if (gkey) {                                                 // (uniform) sliced search: merge, k_match_finish decides
 #pragma unroll
             for (int k = 0; k < 8; k++)
@@ -559,6 +596,16 @@ __global__ __launch_bounds__(1024) void k_knn2_finish(hak_point* pts1_base, cons
 void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
                      int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride)
 {
+    const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call, as in hak_launch_match)
+    if (!(env_valu && atoi(env_valu) != 0) && nB_host < (1 << 20)) {
+        // the matrix-core kernel with its 2-NN epilogue (the point records are only read: ptsA is not written)
+        int gx = nA_dev ? 83 : (nA_host + 127) / 128;
+        if (gx < 1) gx = 1;
+        if (gx > 4096) gx = 4096;
+        k_match_mfma<true><<<dim3(gx, npairs), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB,
+                                                            2, nullptr, 0, out, out_stride);
+        return;
+    }
     int gx = nA_dev ? 640 : (nA_host + MQ - 1) / MQ;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
@@ -619,7 +666,7 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
             if (keys) {
                 (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
                 if (valu) k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
-                else k_match_mfma<<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
+                else k_match_mfma<false><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps, nullptr, 0);
                 k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, keys);
                 if (transient) (void)hipFreeAsync(keys, st);
                 return;
@@ -627,7 +674,7 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
         }
     }
     dim3 grid(gx, npairs);
-    if (!valu) k_match_mfma<<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
+    if (!valu) k_match_mfma<false><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0, nullptr, 0);
     else if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
     else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
 }

@@ -622,8 +622,10 @@ def _upload_points(ah, torch, pts):
 
 @pytest.mark.parametrize("n1,n2,ratio,cross", [(260, 300, (1, 1), False), (260, 300, (1, 1), True), (1000, 1700, (4, 5), True),
                                                (1700, 1000, (3, 5), False), (5, 1, (1, 1), True), (5, 0, (1, 1), True),
-                                               (10000, 10000, (4, 5), True)])
-def test_knn2_matches_oracle(ah, okz, torch, synth, n1, n2, ratio, cross):
+                                               (10000, 10000, (4, 5), True),
+                                               # around the 32 x 32 tiles / 128-query blocks of the matrix-core kernel, 1 and 2 train points
+                                               (33, 31, (1, 1), True), (129, 65, (4, 5), True), (64, 2, (1, 1), False), (200, 97, (3, 5), True)])
+def test_knn2_matches_oracle(ah, okz, torch, synth, match_kernel, n1, n2, ratio, cross):
     p2 = synth.random_descriptors(max(n2, 1), 3, ah.POINT_DTYPE)[:n2]
     p1 = synth.random_descriptors(n1, 4, ah.POINT_DTYPE, planted_from=p2 if n2 else None, nplanted=min(n1, n2) // 2, maxflip=60)
     if n1 > 8 and n2 > 12:
@@ -646,7 +648,7 @@ def test_knn2_matches_oracle(ah, okz, torch, synth, n1, n2, ratio, cross):
         assert np.array_equal(h_pts[f], want_pts[f]), f
 
 
-def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth):
+def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth, match_kernel):
     w, h = 640, 480
     p = ah.iAlignUp(w, 128)
     pairs = [synth.pair(w, h, 5), synth.pair(w, h, 6)]
