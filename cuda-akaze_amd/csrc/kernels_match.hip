@@ -211,7 +211,6 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
 #define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
-#define MM_FRAG(TD, s) mm_frag_a(TD[s])
 #define MM_ROW 36       // dwords per staged train row: the 16 descriptor dwords, the same 16 shifted right by 4 (lane half 1 reads
                         // those: no shift in the tile loop), 4 of padding (144-byte rows make the ds_read_b128 conflict-free)
 __device__ __forceinline__ unsigned mm_chunks3(unsigned p, unsigned& c3)     // p <= 488 as four int8 <= 127: three in bytes 1..3, the fourth in c3
@@ -310,7 +309,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         {                                                                                                   \
             mm_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                 \
             _Pragma("unroll") for (int s = 0; s < 15; s++)                                                  \
-                acc = MM_MFMA(MM_FRAG(TD, s), B[s], acc);                                                   \
+                acc = MM_MFMA(mm_frag_a(TD[s]), B[s], acc);                                                 \
             {                                                                                               \
                 mm_v4i last = mm_frag_a(TD[15]);                                                            \
                 last.x |= (int)a15x; last.y |= (int)a15y;                                                   \
