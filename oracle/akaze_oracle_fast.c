@@ -46,6 +46,7 @@ typedef struct FkParams {
 
 int okz_fed_tau(float T, int M, float tau_max, int reordering, float* tau, int cap);
 void okz_compare_indices(int* idx1, int* idx2);
+extern int okz_reading_variant;   /* akaze_oracle.c: alternative readings for tools/ref_render_check.py; 0 everywhere else */
 int okz_layout(int w, int h, int p, int noctaves, int max_scale, int* owhps, int* osizes, int* offsets);
 
 static inline int fborder_add(int a, int b, int m) { int c = a + b; return c < m ? c : m + m - 2 - c; }
@@ -295,7 +296,7 @@ int fkz_nms(FkPoint* pts, int max_pts, const int* rmap, const float* smap, const
                  * row i == 0 every j > 0 reads column ix + j - 1 (Q1) */
                 int col = ix - isz;
                 for (int j = -isz; j <= isz; j++) {
-                    if (i == 0 && j == 0) continue;                                            /* :3565 */
+                    if (i == 0 && j == 0) { col += okz_reading_variant & 1; continue; }        /* :3565 */
                     int rn = rmap[(size_t)(iy + i) * p + col];
                     if (i * i + j * j < sqsz && rn > -1000000 && (rn > rmap[idx] || (rn == rmap[idx] && i <= 0 && j <= 0))) to_nms = 1;
                     col++;                                                                     /* :3577 */

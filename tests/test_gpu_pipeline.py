@@ -126,6 +126,36 @@ def test_full_size_vs_oracle(ah, okz, torch, synth, w, h, kw, nshapes):
     assert_points_equal(pts, r.points)
 
 
+def test_natural_1080p_pair_vs_oracle(ah, okz, torch, synth, golden):
+    """the natural-image 1080p fixture: img1 / img2 of BASELINE configs[0], reconstructed from the reference's own result
+    pictures (tools/ref_render_check.py; the PNGs themselves are missing from the checkout).  Float path + match and FAST
+    path against the oracle run live; the oracle's counts on it are the ones the render check compares with the
+    reference's screenshot (2154 / 2296 vs 2205 / 2382; FAST 2687 / 2831 vs 2690 / 2915)."""
+    rec = np.load(os.path.join(golden.dir, "ref_recon_1080p_u8.npz"))
+    res, ora = [], []
+    for name, n in (("img1", 2154), ("img2", 2296)):
+        u8 = rec[name]
+        pts, det, data = gpu_detect(ah, torch, synth, u8, keep=True)
+        r = okz.detect_and_compute(synth.to_float(u8, ah.iAlignUp(u8.shape[1], 128)), u8.shape[1])
+        assert len(r.points) == n
+        assert_points_equal(pts, r.points)
+        res.append((det, data))
+        ora.append(r.points)
+    ah.cuMatch(res[0][1], res[1][1])
+    okz.match(ora[0], ora[1])
+    m = res[0][1].h_data[:res[0][1].num_pts]
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(m[f], ora[0][f]), f
+    assert (m["match"] >= 0).sum() == 1357
+    for det, data in res:
+        ah.freeAkazeData(data)
+        det.close()
+    for name, n in (("img1", 2687), ("img2", 2831)):
+        r = okz.fast_detect_and_compute(rec[name])
+        assert len(r.points) == n
+        assert_points_equal(gpu_fast_detect(ah, torch, rec[name]), r.points)
+
+
 def test_max_pts_clamp_is_raster_prefix(ah, okz, torch, synth):
     u8 = _mg().case_scene(640, 480, 21)
     full = okz.detect_and_compute(synth.to_float(u8, 640), 640).points
