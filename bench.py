@@ -19,8 +19,12 @@ barrier, the max-over-ranks time and the trivial result-summary gather.
                    ("pairs/s at G = 1, 2, 4, 8 on the same 512 pairs", BASELINE configs[3])
 
 Extra objects in the line:
-  "verified"      the timed batch's download compared byte for byte with the CPU oracle on its first pairs
-                  (exit code 3 on a mismatch)
+  "verified"      the CPU oracle runs on ALL distinct pairs of the batch (8 pairs = 16 images); every slot of the last download of
+                  every pipeline context, and every pair of an untimed summary pass, is digested (sha256 over the record fields)
+                  and must equal the oracle's digest of its seed; same for the integer FAST leg (exit code 3 on a mismatch)
+  "gather"        SURVEY 8e's verification gather: per-pair 32-byte summaries {pair_id, n1, n2, n_matches, 64-bit checksum}
+                  all-gathered over RCCL; rank 0 checks equal seeds => equal checksums across ranks and against the G = 1 table
+                  committed under tests/golden/bench_pair_checksums.json
   "roofline"      the FED kernel family (dominant class): achieved = the compulsory HBM bytes of its launches AS BUILT
                   (fused: read L [+ g], write L' [+ smooth, g]) / average launch duration from HIP events on the launch
                   stream in a serial leg of this run; "traffic" = PMC bytes per launch from the rocprofv3 passes committed
@@ -48,18 +52,20 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+CHECKSUM_FILE = os.path.join(ROOT, "tests", "golden", "bench_pair_checksums.json")
+NDIST = 8                  # distinct seeded pairs; the pair with global id g is drawn from seed 1 + g % NDIST on every rank
 # kernel-name substrings and the sources whose hash ties a PMC pass to the kernels it measured (tools/pmc_traffic.py)
 CLASS_KERNELS = {
-    "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic"),
+    "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic", "k_level_tile"),
     "hessian": ("k_hessian_stream", "k_hessian_fused"),
     "prologue": ("k_base_stream", "k_base_a", "kf_base", "k_grad_hist_plane", "k_kcontrast2"),
-    "describe": ("k_describe", "k_orient"),
+    "describe": ("k_describe", "k_orient", "k_desc_perm"),
     "nms": ("k_nms_cand", "k_row_scan", "k_emit", "k_refine", "k_clear_cand_maps"),
     "match": ("k_match",),
 }
 CLASS_SOURCES = {
-    "fed": ("kernels_fed.hip", "kernels_fedsf.hip", "fed_common.h"),
+    "fed": ("kernels_fed.hip", "kernels_fedsf.hip", "kernels_level.hip", "fed_common.h"),
     "hessian": ("kernels_hessian_stream.hip", "kernels_hessian.hip", "fed_common.h"),
     "prologue": ("kernels_base_stream.hip", "kernels_base.hip", "fed_common.h"),
     "describe": ("kernels_describe.hip",),
@@ -88,12 +94,41 @@ def launcher_command(argv, ngpus, port):
             "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
 
 
+def visible_gpu_count():
+    """devices this node offers, WITHOUT touching the HIP runtime (the parent of a rank launcher must stay GPU-free: a process
+    that has initialised HIP may only spawn children, never exec).  KFD topology nodes with simd_count > 0 are GPUs (CPU nodes
+    report 0); HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow the set.  When sysfs cannot be read a
+    CHILD process is asked (torch.cuda.device_count())."""
+    import glob
+    n = None
+    try:
+        nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+        if nodes:
+            n = 0
+            for f in nodes:
+                for ln in open(f):
+                    k, _, v = ln.partition(" ")
+                    if k == "simd_count" and int(v) > 0:
+                        n += 1
+    except OSError:
+        n = None
+    if n is None:
+        import subprocess
+        r = subprocess.run([sys.executable, "-c", "import torch; print(torch.cuda.device_count())"], capture_output=True, text=True)
+        n = int(r.stdout.strip() or 0) if r.returncode == 0 else 0
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def self_launch(args, argv):
     """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start N ranks as a fresh child process tree and
-    relay rank 0's JSON line and the exit code.  This parent never touches a GPU (device_count() does not initialise HIP here), so
-    the children own the devices.  Fails loudly when the node has fewer devices than ranks were asked for."""
+    relay rank 0's JSON line and the exit code.  This parent never initialises HIP (devices are counted from sysfs), so the
+    children own the devices.  Fails loudly when the node has fewer devices than ranks were asked for."""
     import subprocess
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpu_count()
     if ndev < args.gpus:
         print(f"bench.py: {args.gpus} ranks requested, {ndev} device{'s' if ndev != 1 else ''} visible on this node", file=sys.stderr)
         sys.exit(2)
@@ -120,14 +155,64 @@ def max_over_ranks(elapsed, device, use_dist):
     return float(t.item())
 
 
-def gather_summary(pairs, keypoints, matches, device, use_dist):
-    """the trivial result gather: per-rank {pairs, keypoints, matches} summed over ranks"""
-    summary = torch.tensor([int(pairs), int(keypoints), int(matches)], dtype=torch.int64, device=device)
-    if use_dist:
-        allsum = [torch.zeros_like(summary) for _ in range(dist.get_world_size())]
-        dist.all_gather(allsum, summary)
-        summary = torch.stack(allsum).sum(0)
-    return summary.cpu().tolist()
+KP_FIELDS = ("x", "y", "octave", "response", "size", "angle", "features")
+MATCH_FIELDS = ("match", "distance", "match_x", "match_y")
+
+
+def pair_digest(p1, p2):
+    """64-bit checksum of one pair's result records: sha256 over every field the reference fills (img1: keypoint + match fields,
+    img2: keypoint fields), truncated to a signed int64"""
+    h = hashlib.sha256()
+    for f in KP_FIELDS + MATCH_FIELDS:
+        h.update(p1[f].tobytes())
+    for f in KP_FIELDS:
+        h.update(p2[f].tobytes())
+    return int.from_bytes(h.digest()[:8], "little", signed=True)
+
+
+def summarize_pairs(counts, pts, gids):
+    """one 32-byte summary {pair_id, n1 << 32 | n2, n_matches, checksum} per pair of a downloaded batch"""
+    out = np.zeros((len(gids), 4), np.int64)
+    for k, g in enumerate(gids):
+        n1, n2 = int(counts[2 * k]), int(counts[2 * k + 1])
+        p1, p2 = pts[2 * k, :n1], pts[2 * k + 1, :n2]
+        out[k] = (g, (n1 << 32) | n2, int((p1["match"] >= 0).sum()), pair_digest(p1, p2))
+    return out
+
+
+def gather_pair_summaries(local, device, use_dist):
+    """all-gather of the per-pair summaries (the one collective of the path: ceil(P / G) x 32 B per rank); ranks with fewer pairs
+    pad with pair_id -1.  Returns the [P, 4] table of all ranks, sorted by pair_id."""
+    local = np.asarray(local, np.int64).reshape(-1, 4)
+    if not use_dist:
+        return local[np.argsort(local[:, 0], kind="stable")]
+    n = torch.tensor([len(local)], dtype=torch.int64, device=device)
+    dist.all_reduce(n, op=dist.ReduceOp.MAX)
+    buf = torch.full((int(n.item()), 4), -1, dtype=torch.int64, device=device)
+    if len(local):
+        buf[:len(local)] = torch.from_numpy(local).to(device)
+    parts = [torch.empty_like(buf) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, buf)
+    tab = torch.cat(parts).cpu().numpy()
+    tab = tab[tab[:, 0] >= 0]
+    return tab[np.argsort(tab[:, 0], kind="stable")]
+
+
+def check_pair_table(tab, expected_pairs, golden=None):
+    """rank 0's checks on the gathered table: every pair exactly once; equal seeds => equal summaries on every rank; and, when a
+    G = 1 table is committed for this configuration, equal to it (so an N-device run equals the 1-device run pair for pair)"""
+    ids = tab[:, 0]
+    complete = len(tab) == expected_pairs and np.array_equal(ids, np.arange(expected_pairs))
+    by_seed = {}
+    for row in tab:
+        by_seed.setdefault(int(row[0]) % NDIST, set()).add((int(row[1]), int(row[2]), int(row[3])))
+    consistent = all(len(v) == 1 for v in by_seed.values())
+    res = {"pairs": int(len(tab)), "complete": bool(complete), "bytes_per_pair": 32, "distinct_seeds": len(by_seed),
+           "equal_seed_equal_checksum": bool(consistent), "keypoints": int(((tab[:, 1] >> 32) + (tab[:, 1] & 0xFFFFFFFF)).sum()),
+           "matches": int(tab[:, 2].sum()), "equals_g1_table": None}
+    if golden is not None and consistent:
+        res["equals_g1_table"] = all(list(next(iter(v))) == [int(x) for x in golden[str(sd)]] for sd, v in by_seed.items())
+    return res
 
 
 def pin_to_gpu_numa_node(local_rank, world):
@@ -199,9 +284,7 @@ def oracle_pairs(okz, synth, u8_pairs, w, p, max_pts, npairs):
 
 
 def verify_batch(want, pts, counts):
-    """byte-for-byte comparison of the timed batch's first images with the oracle"""
-    fields_kp = ("x", "y", "octave", "response", "size", "angle", "features")
-    fields_m = ("match", "distance", "match_x", "match_y")
+    """field-by-field comparison of a downloaded batch's first len(want) pairs with the oracle (says WHICH bar broke)"""
     pts_ok, m_ok = True, True
     for k, (o1, o2) in enumerate(want):
         for j, o in enumerate((o1, o2)):
@@ -210,13 +293,33 @@ def verify_batch(want, pts, counts):
             if counts[i] != len(o):
                 pts_ok = False
                 continue
-            for f in fields_kp:
+            for f in KP_FIELDS:
                 pts_ok &= g[f].tobytes() == o[f].tobytes()
             if j == 0:
-                for f in fields_m:
+                for f in MATCH_FIELDS:
                     m_ok &= g[f].tobytes() == o[f].tobytes()
-    return {"images": 2 * len(want), "points_equal": bool(pts_ok), "matches_equal": bool(m_ok),
-            "checker": "CPU oracle (oracle/akaze_oracle.c) on the same seeded pairs, all 104-byte fields"}
+    return bool(pts_ok), bool(m_ok)
+
+
+def oracle_fast_pairs(okz, u8_pairs, max_pts):
+    out = []
+    for a, b in u8_pairs:
+        r1 = okz.fast_detect_and_compute(a, max_pts=max_pts).points
+        r2 = okz.fast_detect_and_compute(b, max_pts=max_pts).points
+        okz.match(r1, r2)
+        out.append((r1, r2))
+    return out
+
+
+def slot_digests(counts, pts, npairs):
+    """one 64-bit digest per pair slot of a downloaded batch (read in place from the pinned host buffer)"""
+    return np.array([pair_digest(pts[2 * k, :int(counts[2 * k])], pts[2 * k + 1, :int(counts[2 * k + 1])]) for k in range(npairs)], np.int64)
+
+
+def count_slot_mismatches(digests, want_digests, lo):
+    """slot k of a launch sequence holds the pair with global id lo + k (+ a multiple of NDIST), i.e. seed index (lo + k) % NDIST"""
+    exp = np.array([want_digests[(lo + k) % NDIST] for k in range(len(digests))], np.int64)
+    return int((digests != exp).sum())
 
 
 def opencv_baseline(u8_pairs, cores):
@@ -241,12 +344,12 @@ def opencv_baseline(u8_pairs, cores):
             "what": "cv2.AKAZE_create() defaults + BFMatcher(NORM_HAMMING), median of 10 pairs"}
 
 
-def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times, budget_s=25.0):
-    """median pairs/s of the oracle over >= 10 pairs (after the warm-up pairs already run for the verification)"""
+def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times, budget_s=12.0):
+    """median pairs/s of the oracle over >= 10 pairs (the NDIST pairs already run for the verification count, minus the first)"""
     times = list(first_times[1:])                 # the very first pair paid page-in and the OpenMP pool start-up
     t_start = time.perf_counter()
     k = 0
-    while len(times) < 10 or (time.perf_counter() - t_start < budget_s and len(times) < 30):
+    while len(times) < 10 or (time.perf_counter() - t_start < budget_s and len(times) < 24):
         _, t = oracle_pairs(okz, synth, [u8_pairs[k % len(u8_pairs)]], w, p, max_pts, 1)
         times += t
         k += 1
@@ -287,6 +390,7 @@ class Pipeline:
             self.h_pts.append(hp)
             self.h_num.append(hn)
         self.nctx = nctx
+        self.last_pairs = [0] * nctx            # pairs of the last job each context ran (whose download its host buffers hold)
         # off by default: +1.4 % at 1080p in one A/B, nothing in the next, -3 % at 720p
         self.phase_lock = os.environ.get("HAK_BENCH_PHASE_LOCK", "0") != "0"
         self.phase_ev = []
@@ -318,6 +422,7 @@ class Pipeline:
                 # start this context's scale space when the other context's reaches its keypoint stages (hak_phase_event)
                 self.ah.check(self.ah.lib.hak_wait_event(self.dets[i % N].ctx, self.phase_ev[(i + 1) % N]))
             self.enqueue(i % N, imgs, npairs)
+            self.last_pairs[i % N] = self.nimg // 2 if npairs is None else npairs
             if i >= N - 1:
                 j = i - (N - 1)
                 self.download(j % N, jobs[j][1])
@@ -358,11 +463,64 @@ def timed_throughput(pipe, d_imgs, B, steps, warmup):
     return B * steps / (time.perf_counter() - t0)
 
 
-def other_configs(ah, synth, args, rank):
-    """BASELINE.json configs[1] as a single pair, configs[2], configs[3]'s shape on one GPU, configs[4]; never `value`"""
+def batch_curve(ah, synth, u8_pairs, w, h, p, max_pts):
+    """pairs/s against the pairs in flight (contexts x pairs per launch sequence), the small-batch end of the headline: where a
+    caller that cannot collect 256 pairs stands.  One context with 1 pair per sequence is the pair-level call (both images of a
+    pair in ONE launch sequence + the match, then one synchronisation)."""
+    rows = []
+    for nctx, ppseq in ((1, 1), (1, 2), (2, 2), (1, 4), (2, 4), (1, 8), (2, 8), (2, 16)):
+        nimg = 2 * ppseq
+        d = torch.from_numpy(np.stack([synth.to_float(u8_pairs[(i // 2) % NDIST][i % 2], p) for i in range(nimg)])).cuda()
+        pipe = Pipeline(ah, w, h, p, nimg, max_pts, nctx, serial=False, torch_stream=False)
+        rate = timed_throughput(pipe, d, ppseq, max(20, 320 // (nctx * ppseq)), 5)
+        rows.append({"pairs_in_flight": nctx * ppseq, "contexts": nctx, "pairs_per_sequence": ppseq, "pairs_per_s": round(rate, 1),
+                     "ms_per_sequence": round(1e3 * nctx * ppseq / rate, 3),
+                     "arena_MB": round(nctx * nimg * (w * h * 100 + 2 * max_pts * 104) / 1e6)})
+        pipe.close()
+        del d, pipe
+    return rows
+
+
+def natural_leg(ah, synth, okz, max_pts):
+    """the natural-image 1080p pair (img1 / img2 of BASELINE configs[0], reconstructed from the reference's own result pictures:
+    tools/ref_render_check.py) through the same batched path, verified against the oracle"""
+    f = os.path.join(ROOT, "tests", "golden", "ref_recon_1080p_u8.npz")
+    if not os.path.exists(f):
+        return None
+    rec = np.load(f)
+    a, b = rec["img1"], rec["img2"]
+    h, w = a.shape
+    p = ah.iAlignUp(w, 128)
+    B = 64
+    d = torch.from_numpy(np.stack([synth.to_float((a, b)[i % 2], p) for i in range(2 * B)])).cuda()
+    pipe = Pipeline(ah, w, h, p, 2 * B, max_pts, 2, serial=True, torch_stream=False)
+    rate = timed_throughput(pipe, d, B, 6, 2)
+    counts, pts = pipe.results(1)
+    out = {"pairs_per_s": round(rate, 1), "pairs_per_sequence": B, "keypoints": [int(counts[0]), int(counts[1])],
+           "matches": int((pts[0, :counts[0]]["match"] >= 0).sum()),
+           "reference_printed_keypoints": [2205, 2382], "verified": None}
+    if okz is not None:
+        r1 = okz.detect_and_compute(synth.to_float(a, p), w, max_pts=max_pts).points
+        r2 = okz.detect_and_compute(synth.to_float(b, p), w, max_pts=max_pts).points
+        okz.match(r1, r2)
+        dg = pair_digest(r1, r2)
+        bad = sum(pair_digest(pts[2 * k, :counts[2 * k]], pts[2 * k + 1, :counts[2 * k + 1]]) != dg for k in range(B))
+        out["verified"] = {"images": 2, "slots": B, "slots_equal": bad == 0}
+    pipe.close()
+    return out
+
+
+def other_configs(ah, synth, args, rank, okz=None, u8_pairs=None):
+    """BASELINE.json configs[1] as a single pair and as a batch-size curve, configs[0]'s images, configs[2], configs[3]'s shape on
+    one GPU, configs[4]; never `value`"""
     out = {}
     max_pts = 10000
     out.update(args.single_pair_result or {})               # configs[1] literally: measured first, in a child process (run_single_pair_leg)
+    if u8_pairs is not None:
+        out["batch_curve_1080p"] = batch_curve(ah, synth, u8_pairs, 1920, 1080, ah.iAlignUp(1920, 128), max_pts)
+        torch.cuda.empty_cache()
+    out["natural_1080p"] = natural_leg(ah, synth, okz, max_pts)
+    torch.cuda.empty_cache()
     # ---- configs[2]: 3840x2160, 5 octaves, MLDB-upright
     w, h = 3840, 2160
     p = ah.iAlignUp(w, 128)
@@ -478,7 +636,10 @@ def single_pair_leg():
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks = GPUs (default: WORLD_SIZE when a launcher set it, else 1)")
+    ap.add_argument("--config", type=int, default=1, choices=(1, 2, 3),
+                    help="BASELINE.json configs[]: 1 = 1080p pairs (default); 2 = 3840x2160, 5 octaves, MLDB-upright; "
+                         "3 = the same 512 1280x720 pairs sharded over all ranks (--total-pairs 512 --width 1280 --height 720)")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--pairs", type=int, default=256, help="pairs per GPU per launch sequence (batch); halved until the arenas fit the free HBM")
@@ -493,10 +654,12 @@ def main():
     ap.add_argument("--no-configs", action="store_true", help="skip the other BASELINE configs measured after the timed region")
     ap.add_argument("--no-pipeline", action="store_true", help="one context: no overlap between consecutive steps")
     ap.add_argument("--pipeline", type=int, default=2, help="contexts used round-robin (batches in flight)")
-    ap.add_argument("--upload", action="store_true",
-                    help="also measure the upload-inclusive rate: uint8 host images -> H2D -> on-device ingest -> path (default on for N > 1)")
-    ap.add_argument("--fast", action="store_true",
-                    help="also time the integer FAST path (fastDetectAndCompute, uint8 inputs) on the same pairs")
+    ap.add_argument("--upload", action="store_true", help="(default now; kept for old command lines)")
+    ap.add_argument("--no-upload", action="store_true",
+                    help="skip the upload-inclusive leg: uint8 host images -> H2D -> on-device ingest -> path")
+    ap.add_argument("--fast", action="store_true", help="time the integer FAST path also with N > 1 (default on for N = 1)")
+    ap.add_argument("--no-fast", action="store_true",
+                    help="skip the integer FAST path leg (fastDetectAndCompute, uint8 inputs, same pairs, verified against its oracle)")
     ap.add_argument("--upright", action="store_true", help="MLDB-upright (skip the orientation stage; configs[2] of BASELINE.json)")
     ap.add_argument("--serial", action="store_true",
                     help="one stream per context in the timed region (the default when two contexts are in flight)")
@@ -508,13 +671,22 @@ def main():
     args = ap.parse_args()
     if args.single_pair_leg:
         return single_pair_leg()
+    if args.config == 2:
+        args.width, args.height, args.octaves, args.upright = 3840, 2160, 5, True
+        args.pairs = min(args.pairs, 32)
+    elif args.config == 3:
+        args.width, args.height = 1280, 720
+        args.total_pairs = args.total_pairs or 512
 
+    gpus_given = args.gpus is not None
+    if not gpus_given:
+        args.gpus = int(os.environ.get("WORLD_SIZE", "1"))  # started by a launcher without --gpus: its world size
     if (args.gpus > 1 or args.launch) and "WORLD_SIZE" not in os.environ:
         self_launch(args, sys.argv[1:])                     # never returns
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
+    if gpus_given and world != args.gpus:                   # an explicit --gpus that contradicts the launcher is an error
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
@@ -547,15 +719,20 @@ def main():
         lo, hi = shard_pairs(args.total_pairs, world, rank)
         my_pairs = hi - lo
         B = max(1, min(B, my_pairs)) if my_pairs else 1
+        if my_pairs > B and B > NDIST:
+            B -= B % NDIST              # every launch sequence of a step starts at a multiple of NDIST: one resident batch serves all
         chunks = [min(B, my_pairs - c) for c in range(0, my_pairs, B)]          # pairs per launch sequence of one step
     else:
         lo, my_pairs, chunks = rank * B, B, [B]
     nimg = 2 * B
 
-    # ---- synthetic inputs, resident in HBM: 8 distinct seeded pairs per rank, cycled over the batch
-    NDIST = 8
-    u8_pairs = [synth.pair(w, h, 1 + NDIST * rank + i) for i in range(NDIST)]
-    host = np.stack([synth.to_float(u8_pairs[(i // 2) % NDIST][i % 2], p) for i in range(nimg)])
+    # ---- synthetic inputs, resident in HBM: NDIST distinct seeded pairs, the pair with GLOBAL id g drawn from seed 1 + g % NDIST on
+    # whichever rank it lands -- so `--total-pairs T` is the same set of pairs at every G, and equal seeds must give equal results
+    # on every rank (the gather below checks exactly that).  Slot k of a launch sequence holds global pair lo + (chunk start) + k.
+    u8_pairs = [synth.pair(w, h, 1 + i) for i in range(NDIST)]
+    seed_of = lambda k: (lo + k) % NDIST                     # noqa: E731
+    assert len(chunks) <= 1 or B % NDIST == 0 or B >= my_pairs
+    host = np.stack([synth.to_float(u8_pairs[seed_of(i // 2)][i % 2], p) for i in range(nimg)])
     d_imgs = torch.from_numpy(host).cuda()
     del host
 
@@ -573,15 +750,20 @@ def main():
     pipe.run(step_jobs * args.steps)
     fence(use_dist)
     elapsed = max_over_ranks(time.perf_counter() - t0, "cuda", use_dist)
-    last_ctx = (len(step_jobs) * args.steps - 1) % NCTX if step_jobs else 0
-    counts, pts = pipe.results(last_ctx)
-    counts, pts = counts.copy(), pts.copy()
-    last_pairs = chunks[-1] if chunks else 0
+    # the last download of EVERY context of the timed region (checked slot by slot against the oracle below)
+    timed_digests, first_slots = [], None
+    for k in range(NCTX):
+        if pipe.last_pairs[k]:
+            ck, pk = pipe.results(k)
+            timed_digests.append(slot_digests(ck, pk, pipe.last_pairs[k]))
+            if first_slots is None:                         # kept for the field-by-field diagnosis of a mismatch
+                nf = min(pipe.last_pairs[k], NDIST)
+                first_slots = (ck[:2 * nf].copy(), pk[:2 * nf].copy(), nf)
 
     # ---- PCIe-inclusive rate (never `value`): pinned uint8 batch -> H2D -> hak_ingest_u8 -> same steps
     upload_rate = None
-    if (args.upload or world > 1) and my_pairs:
-        h_u8 = torch.from_numpy(np.stack([u8_pairs[(i // 2) % NDIST][i % 2] for i in range(nimg)])).pin_memory()
+    if not args.no_upload and my_pairs:
+        h_u8 = torch.from_numpy(np.stack([u8_pairs[seed_of(i // 2)][i % 2] for i in range(nimg)])).pin_memory()
         # every pipeline context ingests into its OWN image batch: with two batches in flight the other context may still be
         # reading its images while this one's are rewritten (real frames change from step to step)
         d_u8s = [torch.empty_like(h_u8, device="cuda") for _ in range(NCTX)]
@@ -615,15 +797,16 @@ def main():
             ah.check(ah.lib.hak_set_stream(pipe.dets[k].ctx, None))
         del h_u8, d_u8s, d_imgs_k, up_streams
 
-    # ---- optional: the integer FAST path on the same pairs (secondary figure, never `value`)
-    fast_rate = None
-    if args.fast and my_pairs:
-        d_fu8 = torch.from_numpy(np.stack([np.pad(u8_pairs[(i // 2) % NDIST][i % 2], ((0, 0), (0, p - w))) for i in range(nimg)])).cuda()
+    # ---- the integer FAST path on the same pairs (secondary figure, never `value`; default at N = 1)
+    fast_rate, fast_results = None, []          # fast_results: per-context slot digests of the FAST leg's last downloads
+    if (args.fast or world == 1) and not args.no_fast and my_pairs:
+        d_fu8 = torch.from_numpy(np.stack([np.pad(u8_pairs[seed_of(i // 2)][i % 2], ((0, 0), (0, p - w))) for i in range(nimg)])).cuda()
 
         def fast_run(n):
             jobs = step_jobs * n
             for i, (_, c) in enumerate(jobs):
                 pipe.enqueue(i % NCTX, d_fu8, c, fast=True)
+                pipe.last_pairs[i % NCTX] = c
                 if i >= NCTX - 1:
                     j = i - (NCTX - 1)
                     pipe.download(j % NCTX, jobs[j][1])
@@ -635,11 +818,27 @@ def main():
         fast_run(args.steps)
         fence(use_dist)
         fast_rate = (args.total_pairs if strong else world * B) * args.steps / max_over_ranks(time.perf_counter() - tf, "cuda", use_dist)
+        for k in range(NCTX):
+            if pipe.last_pairs[k]:
+                ck, pk = pipe.results(k)
+                fast_results.append(slot_digests(ck, pk, pipe.last_pairs[k]))
         del d_fu8
 
-    nmatch = int(sum((pts[2 * k, :counts[2 * k]]["match"] >= 0).sum() for k in range(last_pairs)))
-    nkp = int(counts[:2 * last_pairs].sum())
-    summary = gather_summary(last_pairs, nkp, nmatch, "cuda", use_dist)
+    # ---- SURVEY 8e's verification gather: an untimed pass over this rank's pairs of one step, one 32-byte summary per pair,
+    # all-gathered (the path's only collective); rank 0 checks the table
+    local_rows = []
+    c0 = 0
+    for c in chunks if my_pairs else []:
+        pipe.enqueue(0, d_imgs, c)
+        pipe.download(0, c)
+        ck, pk = pipe.results(0)
+        local_rows.append(summarize_pairs(ck, pk, [lo + c0 + k for k in range(c)]))
+        c0 += c
+    table = gather_pair_summaries(np.concatenate(local_rows) if local_rows else np.zeros((0, 4), np.int64), "cuda", use_dist)
+    golden_tab = None
+    if os.path.exists(CHECKSUM_FILE) and args.octaves == 4 and not args.upright:
+        golden_tab = json.load(open(CHECKSUM_FILE)).get(f"{w}x{h}")
+    gather = check_pair_table(table, args.total_pairs if strong else world * B, golden_tab) if rank == 0 else None
 
     # ---- roofline leg: the same launch sequence strictly serially on one stream with per-launch HIP events
     # (per-kernel durations are only meaningful without overlap; the timed region overlaps the octaves on separate streams)
@@ -661,7 +860,7 @@ def main():
             cls_ms[name], cls_n[name] = m2.value / nprof, n2.value // nprof
         ah.check(ah.lib.hak_prof_enable(det.ctx, 0))
         ah.check(ah.lib.hak_set_concurrency(det.ctx, 0 if pipe.serial else 1))
-        tr = det.traffic(int(round(nkp / max(1, 2 * last_pairs))))
+        tr = det.traffic(int(round(gather["keypoints"] / max(1, 2 * gather["pairs"]))))
         nim = 2 * rl_pairs
         gb = C.c_double()
         ah.check(ah.lib.hak_op_copy_probe(2 << 30, 10, C.byref(gb)))           # 2 GiB source + 2 GiB destination, far beyond the caches
@@ -725,18 +924,36 @@ def main():
                                    "pmc_frac_peak": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
                                    "pmc_frac_copy": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (copy_gbs * world), 4)})(
                                        sum(pmc.values()) / nim))},
-                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r03_*_serial_kernel_stats.csv"}
+                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r04_*_serial_kernel_stats.csv"}
 
-    # ---- the oracle legs: verification of the timed batch, then the CPU baseline (rank 0)
-    verified, cpu = None, None
+    # ---- the oracle legs (rank 0): the oracle on ALL distinct pairs, every slot of every context's last download of the timed
+    # region and every pair of the gathered table against it, the FAST leg the same way; then the CPU baseline from the same runs
+    verified, cpu, okz = None, None, None
     if rank == 0 and my_pairs and not args.no_verify:
         okz, cores, flags = oracle_setup()
-        nver = min(2, last_pairs)
         if args.octaves != 4 or args.upright:
             verified = {"images": 0, "note": "verification covers the default configuration only"}
         else:
-            want, first_times = oracle_pairs(okz, synth, u8_pairs, w, p, max_pts, nver)
-            verified = verify_batch(want, pts, counts)
+            want, first_times = oracle_pairs(okz, synth, u8_pairs, w, p, max_pts, NDIST)
+            want_dig = [pair_digest(a, b) for a, b in want]
+            nf = first_slots[2]
+            pts_ok, m_ok = verify_batch([want[seed_of(k)] for k in range(nf)], first_slots[1], first_slots[0])
+            bad = sum(count_slot_mismatches(d, want_dig, lo) for d in timed_digests)
+            nslots = sum(len(d) for d in timed_digests)
+            tab_bad = int(sum(int(r[3]) != want_dig[int(r[0]) % NDIST] for r in table))
+            verified = {"images": 2 * NDIST, "distinct_pairs": NDIST, "points_equal": pts_ok, "matches_equal": m_ok,
+                        "slots": nslots, "contexts": len(timed_digests), "slots_equal": bad == 0 and pts_ok and m_ok,
+                        "gathered_pairs": int(len(table)), "gathered_pairs_equal": tab_bad == 0,
+                        "checker": "CPU oracle (oracle/akaze_oracle.c) on all distinct seeded pairs; every pair slot of each pipeline "
+                                   "context's last timed download and every gathered pair summary digested (sha256 of all record fields) "
+                                   "against the oracle's records of its seed",
+                        "fast": None}
+            if fast_results:
+                fwant = oracle_fast_pairs(okz, u8_pairs, max_pts)
+                fdig = [pair_digest(a, b) for a, b in fwant]
+                fbad = sum(count_slot_mismatches(d, fdig, lo) for d in fast_results)
+                verified["fast"] = {"images": 2 * NDIST, "slots": sum(len(d) for d in fast_results), "slots_equal": fbad == 0,
+                                    "checker": "oracle/akaze_oracle_fast.c"}
             if world == 1 and not args.no_cpu_baseline and (w, h) == (1920, 1080):
                 cpu = cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times)
 
@@ -745,7 +962,7 @@ def main():
     extra = None
     if rank == 0 and world == 1 and not args.no_configs and not strong and (w, h, args.octaves) == (1920, 1080, 4):
         torch.cuda.empty_cache()
-        extra = other_configs(ah, synth, args, rank)
+        extra = other_configs(ah, synth, args, rank, okz, u8_pairs)
 
     if rank == 0:
         total_pairs = (args.total_pairs if strong else world * B) * args.steps
@@ -754,7 +971,8 @@ def main():
             "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 0,
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" + (" (+ configs.natural_1080p: img1 / img2 reconstructed from the reference's result pictures)" if extra and extra.get("natural_1080p") else ""),
             "config": {"workload": ("configs[1]: " if (w, h, args.octaves) == (1920, 1080, 4) else "configs[3] shape: " if (w, h) == (1280, 720) else
                                     "configs[2]: " if (w, h, args.octaves) == (3840, 2160, 5) else "") +
                                    f"{w}x{h} grayscale pairs, {args.octaves} octaves x 4 sublevels, PM_G2, "
@@ -763,18 +981,24 @@ def main():
                        "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
                        "octave_streams": "one stream per context" if pipe.serial else "concurrent", "step_pipeline": NCTX,
                        "sharding": "independent pairs per rank, no data-path collective", "rank0_gpu_numa_node": numa_node,
-                       "keypoints_per_image": round(summary[1] / max(1.0, 2.0 * summary[0]), 1),
-                       "matches_per_pair": round(summary[2] / max(1.0, float(summary[0])), 1)},
-            "verified": verified, "roofline": roof, "cpu_baseline": cpu, "configs": extra,
+                       "keypoints_per_image": round(gather["keypoints"] / max(1.0, 2.0 * gather["pairs"]), 1),
+                       "matches_per_pair": round(gather["matches"] / max(1.0, float(gather["pairs"])), 1)},
+            "verified": verified, "gather": gather, "roofline": roof, "cpu_baseline": cpu, "configs": extra,
             "upload_inclusive_pairs_per_s": None if upload_rate is None else round(upload_rate, 1),
             "fast_path_pairs_per_s": None if fast_rate is None else round(fast_rate, 1),
         }
         print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
-    if rank == 0 and verified and verified.get("images") and not (verified["points_equal"] and verified["matches_equal"]):
-        print("bench.py: the timed batch differs from the oracle", file=sys.stderr)
-        sys.exit(3)
+    if rank == 0:
+        ok = True
+        if verified and verified.get("images"):
+            ok = verified["slots_equal"] and verified["gathered_pairs_equal"] and (verified["fast"] is None or verified["fast"]["slots_equal"])
+        if gather and not (gather["complete"] and gather["equal_seed_equal_checksum"] and gather["equals_g1_table"] is not False):
+            ok = False
+        if not ok:
+            print("bench.py: results differ from the oracle / between ranks / from the committed G = 1 table", file=sys.stderr)
+            sys.exit(3)
 
 
 if __name__ == "__main__":

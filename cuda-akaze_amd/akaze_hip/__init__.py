@@ -105,12 +105,15 @@ SYMBOLS = {
     "hak_describe_plan_query": (C.c_int, [C.c_int, C.POINTER(C.c_uint), C.POINTER(C.c_uint)]),
     "hak_query_schedule": (C.c_int, [_vp, _ip, _ip, _fp, _fp]),
     "hak_query_geometry": (C.c_int, [_vp, _ip]),
-    "hak_debug_plane": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
-    "hak_debug_kcontrast": (C.c_int, [_vp, C.c_int, _fp]),
     "hak_query_traffic": (C.c_int, [_vp, C.c_int, C.POINTER(hak_traffic)]),
     "hak_prof_enable": (C.c_int, [_vp, C.c_int]),
     "hak_prof_read": (C.c_int, [_vp, C.c_int, C.POINTER(C.c_double), _ip]),
     "hak_prof_reset": (C.c_int, [_vp]),
+}
+# the TEST ABI (include/hipakaze_test.h -> libhipakaze_test.so): stage operators, plane introspection, probes
+TEST_SYMBOLS = {
+    "hak_debug_plane": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, _vp]),
+    "hak_debug_kcontrast": (C.c_int, [_vp, C.c_int, _fp]),
     "hak_op_lowpass": (C.c_int, [_vp, _vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int]),
     "hak_op_down_smooth": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "hak_op_kcontrast": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_float, _fp, _fp, _ip]),
@@ -136,11 +139,40 @@ if not os.path.exists(LIB_PATH):
     raise ImportError(
         f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
         "(there is no CPU fallback for the HIP path)")
-lib = C.CDLL(LIB_PATH)
-for _name, (_res, _args) in SYMBOLS.items():
-    _f = getattr(lib, _name)          # AttributeError here = ABI drift between header and library
-    _f.restype = _res
-    _f.argtypes = _args
+TEST_LIB_PATH = os.path.join(os.path.dirname(LIB_PATH), "libhipakaze_test.so")
+
+
+class _Libs:
+    """`lib.<symbol>`: the product ABI from libhipakaze.so; hak_op_* / hak_debug_* from libhipakaze_test.so, which is loaded on
+    first use (tests and bench only) and links against the product library next to it"""
+
+    def __init__(self):
+        self.product = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        self.test = None
+        for name, (res, args) in SYMBOLS.items():
+            f = getattr(self.product, name)          # AttributeError here = ABI drift between header and library
+            f.restype, f.argtypes = res, args
+            setattr(self, name, f)
+
+    def load_test(self):
+        if self.test is None:
+            if not os.path.exists(TEST_LIB_PATH):
+                raise ImportError(f"{TEST_LIB_PATH} is missing: build it with `make -C cuda-akaze_amd/csrc`")
+            self.test = C.CDLL(TEST_LIB_PATH)
+            for name, (res, args) in TEST_SYMBOLS.items():
+                f = getattr(self.test, name)
+                f.restype, f.argtypes = res, args
+                setattr(self, name, f)
+        return self.test
+
+    def __getattr__(self, name):                     # only reached for names not bound yet
+        if name in TEST_SYMBOLS:
+            self.load_test()
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+
+lib = _Libs()
 
 
 def check(status):

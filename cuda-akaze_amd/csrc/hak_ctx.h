@@ -1,0 +1,110 @@
+// hak_ctx.h -- the context behind the C ABI (struct hak_ctx) and its host-side helpers, shared by hak_api.hip (the product entry
+// points, libhipakaze.so) and hak_test_api.hip (stage operators / probes of the test ABI, libhipakaze_test.so).  Internal.
+#pragma once
+#include "hak_internal.h"
+#include <string>
+#include <vector>
+
+// ------------------------------------------------------------------ errors
+int hak_fail(const std::string& m);          // hak_api.hip: sets the calling thread's hak_last_error() text, returns 1
+static inline int fail(const std::string& m) { return hak_fail(m); }
+#define HIP_TRY(call)                                                                           \
+    do {                                                                                        \
+        hipError_t e__ = (call);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return fail(std::string(#call) + ": " + hipGetErrorString(e__));                    \
+    } while (0)
+
+// ----------------------------------------------------------------- context
+struct LevelPlan {
+    int nsteps = 0;
+    std::vector<float> tau;
+    int sigma_size = 0;
+    float size = 0, border = 0;
+};
+
+struct ProfClass {
+    std::vector<hipEvent_t> ev;     // pairs
+    size_t used = 0;
+    double acc_ms = 0;
+    int launches = 0;
+};
+
+struct hak_ctx {
+    hak_config cfg;
+    HakLayout L;
+    HakTables htab;
+    HakTables* dtab = nullptr;
+    std::vector<LevelPlan> plan;    // [noct*ms]
+    float taps1[8], taps_base[8];
+    int itaps1[8], itaps_base[8];       // FAST path: (int)(tap * 65536 + 0.5f)   akazed.cu:3896
+    int base_R = 4;
+    int psz = 28;
+    float* arena = nullptr;
+    unsigned long long* maps = nullptr;
+    unsigned long long* bitmap = nullptr;
+    int* rowcount = nullptr;
+    unsigned long long* cand = nullptr;
+    int* perm = nullptr;            // [batch][cfg.max_pts] visiting order of the keypoint kernels (HakBatch::perm)
+    long cand_cap = 0;
+    HakImgState* state = nullptr;
+    int* d_num = nullptr;           // [batch] counts for the synchronous entry points
+    int* h_num = nullptr;           // pinned
+    hipStream_t own_stream = nullptr, stream = nullptr;
+    // octave o+1 depends only on Lt(o,0) (akaze.cpp:371-375), so each octave runs on its own stream and the
+    // latency-bound small-octave launches overlap octave 0's heavy kernels
+    hipStream_t oct_stream[HAK_MAX_OCTAVES] = {};      // [0] unused (= stream)
+    hipEvent_t ev_ready[HAK_MAX_OCTAVES] = {}, ev_done[HAK_MAX_OCTAVES] = {};
+    bool concurrent = true;
+    // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
+    bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
+    int graph_mode = 1;             // HAK_GRAPH: 0 never, 1 replay except for launch-bound single-image sequences, 2 always
+    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; hak_point* hpts; };
+    static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
+    hipGraphExec_t graph_exec[NGRAPH] = {};
+    GraphKey gkey[NGRAPH] = {};
+    unsigned long graph_age[NGRAPH] = {}, graph_clock = 0;
+    bool prof_on = false;
+    ProfClass prof[HAK_PROF_COUNT];
+    int fed_launches = 0;
+    double fed_fused_bytes = 0;     // compulsory HBM bytes per image of the FED launches as enqueued (read L [+ g], write L' [+ smooth, g])
+    int max_fuse = 4;               // FED steps fused per launch (env HAK_FED_MAX_FUSE, 1..6)
+    int fuse_head = 1;              // octave heads through the decimating k_fed_sf variant (env HAK_FUSE_HEAD=0 disables)
+    int level_min_steps = 8;        // shortest FED cycle that goes through k_level_tile under the size rule (env HAK_LEVEL_MIN_STEPS)
+    int fuse_sf = 1;                // low-pass + conductivity fused into the first FED launch of a sublevel: 0 never, 1 by size
+                                    // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
+    int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
+    int* d_cnt = nullptr;
+    unsigned* match_keys = nullptr; // sliced 1-NN search of one big pair (hak_launch_match): grows on demand, on this context's device
+    long match_keys_cap = 0;
+    HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
+    hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
+    hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
+    hipEvent_t ev_phase = nullptr;  // recorded in every detect sequence between the scale space and the keypoint stages (hak_phase_event)
+    hipStream_t sync_stream = nullptr;                            // where the last detect sequence ends (c->stream unless it was left on the chain)
+    bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)
+    bool maps_dirty = false;        // a call failed between writing the key map and cleaning it up: clear it in full next time
+};
+
+struct ProfScope {
+    hak_ctx* c; int k; hipEvent_t stop = nullptr; hipStream_t s;
+    ProfScope(hak_ctx* ctx, int klass, hipStream_t st = nullptr) : c(ctx), k(klass), s(st ? st : ctx->stream)
+    {
+        if (!c->prof_on) return;
+        ProfClass& p = c->prof[k];
+        if (p.used + 2 > p.ev.size()) {
+            hipEvent_t a, b;
+            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            p.ev.push_back(a); p.ev.push_back(b);
+        }
+        (void)hipEventRecord(p.ev[p.used], s);
+        stop = p.ev[p.used + 1];
+        p.used += 2;
+        p.launches++;
+    }
+    ~ProfScope() { if (stop) (void)hipEventRecord(stop, s); }
+};
+
+// hak_api.hip: the key map must be all zero when a launch sequence starts; a failed call leaves the flag set (see there)
+void maps_guard_begin(hak_ctx* c);
+int maps_guard_end(hak_ctx* c, int rc);

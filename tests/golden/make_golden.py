@@ -7,6 +7,10 @@
   left_right_oracle.npz   oracle result on them (demo parameters main.cpp:156-166): points + match fields
   synth_oracle.npz        oracle results on small seeded synthetic scenes (several sizes / parameter sets)
   fast_oracle.npz         integer FAST-path oracle (akaze_oracle_fast.c) results on left/right and two synthetic scenes
+  bench_pair_checksums.json  the G = 1 table of bench.py's verification gather: per seed index of the bench's NDIST
+                          synthetic pairs {n1 << 32 | n2, n_matches, 64-bit checksum of the records}, from the ORACLE, for the
+                          1080p (configs[1]) and 720p (configs[3]) workloads
+  ref_recon_1080p_u8.npz, ref_render_report.json   written by tools/ref_render_check.py (not by this script)
 """
 import json
 import os
@@ -103,7 +107,29 @@ def fast_golden():
     np.savez_compressed(os.path.join(OUT, "fast_oracle.npz"), **out)
 
 
+def bench_checksums():
+    sys.path.insert(0, ROOT)
+    import bench
+    out = {}
+    for w, h in ((1920, 1080), (1280, 720)):
+        p = (w + 127) // 128 * 128
+        rows = {}
+        for i in range(bench.NDIST):
+            a, b = synth.pair(w, h, 1 + i)
+            r1 = okz.detect_and_compute(synth.to_float(a, p), w).points
+            r2 = okz.detect_and_compute(synth.to_float(b, p), w).points
+            okz.match(r1, r2)
+            rows[str(i)] = [(len(r1) << 32) | len(r2), int((r1["match"] >= 0).sum()), bench.pair_digest(r1, r2)]
+            print(f"{w}x{h} seed {1 + i}: {len(r1)} / {len(r2)} keypoints, {rows[str(i)][1]} matches")
+        out[f"{w}x{h}"] = rows
+    json.dump(out, open(os.path.join(OUT, "bench_pair_checksums.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                       # e.g. `make_golden.py bench_checksums`
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     fed_golden()
     pgm_golden()
     synth_golden()

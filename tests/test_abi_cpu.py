@@ -21,6 +21,25 @@ def test_header_symbols_are_exported(ah):
     out = subprocess.check_output(["nm", "-D", "--defined-only", ah.LIB_PATH], text=True)
     exported = set(re.findall(r" T (hak_[a-z0-9_]+)", out))
     assert declared <= exported, declared - exported
+    # the product ABI carries no test scaffolding: stage operators, plane introspection and probes are a library of their own
+    assert not [n for n in declared if n.startswith(("hak_op_", "hak_debug_"))]
+    assert not [n for n in exported if n.startswith(("hak_op_", "hak_debug_"))], "test entry points linked into libhipakaze.so"
+
+
+def test_test_abi_is_a_separate_library(ah):
+    """include/hipakaze_test.h -> libhipakaze_test.so: every declared symbol exported there, the library links against the product
+    library (it drives the product's launchers, it does not carry kernels of the launch sequence) and loads without a GPU"""
+    hdr = open(os.path.join(ROOT, "include", "hipakaze_test.h")).read()
+    declared = set(re.findall(r"\b(hak_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(ah.TEST_SYMBOLS), declared ^ set(ah.TEST_SYMBOLS)
+    assert all(n.startswith(("hak_op_", "hak_debug_")) for n in declared) and len(declared) >= 20
+    out = subprocess.check_output(["nm", "-D", "--defined-only", ah.TEST_LIB_PATH], text=True)
+    exported = set(re.findall(r" T (hak_[a-z0-9_]+)", out))
+    assert declared <= exported, declared - exported
+    assert "libhipakaze.so" in subprocess.check_output(["ldd", ah.TEST_LIB_PATH], text=True)
+    assert "okz_" not in subprocess.check_output(["nm", "-D", ah.TEST_LIB_PATH], text=True)
+    ah.lib.load_test()
+    assert callable(ah.lib.hak_op_lowpass) and callable(ah.lib.hak_debug_plane)
 
 
 def test_product_never_links_the_oracle(ah):
@@ -33,7 +52,7 @@ def test_product_never_links_the_oracle(ah):
             if f.endswith((".hip", ".h", ".cpp", ".py")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "import okz" not in txt and "oracle/" not in txt.replace("oracle/okz_math.h", ""), f
-    for f in ("akaze.h", "akaze_structures.h", "hip_utils.h", "hipakaze.h"):
+    for f in ("akaze.h", "akaze_structures.h", "hip_utils.h", "hipakaze.h", "hipakaze_test.h"):
         path = os.path.join(ROOT, "include", f)
         if os.path.exists(path):
             assert "liboracle" not in open(path).read()

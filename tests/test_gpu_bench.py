@@ -29,12 +29,19 @@ def run_bench(extra, env_extra=None, timeout=900):
 def test_bench_contract_verified_and_roofline():
     out = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs"])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-              "dtype", "data", "config", "roofline", "cpu_baseline", "verified"):
+              "dtype", "data", "config", "roofline", "cpu_baseline", "verified", "gather"):
         assert k in out, k
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f32"
     assert out["value"] > 100 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 0.01
     v = out["verified"]
-    assert v["images"] == 4 and v["points_equal"] and v["matches_equal"]
+    # the oracle on all 8 distinct pairs; every slot of both contexts' last timed downloads; the FAST leg the same way
+    assert v["images"] == 16 and v["points_equal"] and v["matches_equal"]
+    assert v["slots"] == 32 and v["contexts"] == 2 and v["slots_equal"] and v["gathered_pairs"] == 16 and v["gathered_pairs_equal"]
+    assert v["fast"]["slots"] == 32 and v["fast"]["slots_equal"]
+    g = out["gather"]
+    assert g["pairs"] == 16 and g["complete"] and g["equal_seed_equal_checksum"] and g["equals_g1_table"] is True
+    # the default N = 1 run measures the upload-inclusive and the FAST rates too
+    assert out["upload_inclusive_pairs_per_s"] > 100 and out["fast_path_pairs_per_s"] > 100
     r = out["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -51,15 +58,20 @@ def test_bench_contract_verified_and_roofline():
 def test_bench_rccl_path_with_one_rank_weak_and_strong():
     """barrier / all_reduce(MAX) / all_gather over RCCL on the MI355X (world size 1), in both scaling modes"""
     env = {"HAK_BENCH_FORCE_DIST": "1", "MASTER_PORT": "29611"}
-    weak = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs", "--no-roofline"], env)
-    assert weak["scaling"] == "weak" and weak["config"]["total_pairs_per_step"] == 16 and weak["verified"]["points_equal"]
+    weak = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs", "--no-roofline", "--no-fast",
+                      "--no-upload"], env)
+    assert weak["scaling"] == "weak" and weak["config"]["total_pairs_per_step"] == 16 and weak["verified"]["slots_equal"]
+    assert weak["upload_inclusive_pairs_per_s"] is None and weak["fast_path_pairs_per_s"] is None
     env["MASTER_PORT"] = "29612"
-    strong = run_bench(["--steps", "2", "--warmup", "1", "--pairs", "16", "--total-pairs", "40", "--width", "1280", "--height", "720",
-                        "--no-cpu-baseline", "--no-configs", "--no-roofline", "--upload"], env)
+    # configs[3]'s shape through its shorthand, with fewer pairs: 40 pairs of 1280x720 = launch sequences of 16 + 16 + 8
+    strong = run_bench(["--config", "3", "--steps", "2", "--warmup", "1", "--pairs", "16", "--total-pairs", "40",
+                        "--no-cpu-baseline", "--no-configs", "--no-roofline"], env)
     assert strong["scaling"] == "strong" and strong["config"]["total_pairs_per_step"] == 40
-    assert strong["config"]["pairs_per_launch_sequence"] == 16            # 40 pairs = launch sequences of 16 + 16 + 8
+    assert strong["metric"].endswith("720p") and strong["config"]["pairs_per_launch_sequence"] == 16
     assert abs(strong["value"] - 40 * 2 / (strong["ms_per_step"] * 2e-3)) / strong["value"] < 0.01
-    assert strong["verified"]["points_equal"] and strong["verified"]["matches_equal"]
+    assert strong["verified"]["slots_equal"] and strong["verified"]["gathered_pairs"] == 40 and strong["verified"]["gathered_pairs_equal"]
+    g = strong["gather"]               # all 40 pairs of the step, each once, equal to the committed 720p table of one GPU
+    assert g["pairs"] == 40 and g["complete"] and g["equal_seed_equal_checksum"] and g["equals_g1_table"] is True
     assert strong["upload_inclusive_pairs_per_s"] > 0
 
 
@@ -67,8 +79,8 @@ def test_bench_through_its_own_rank_launcher():
     """`--launch`: bench.py starts torch.distributed.run itself (the N > 1 path of a plain `python bench.py --gpus N`) with one
     rank; the child runs over RCCL and the parent relays its line"""
     out = run_bench(["--gpus", "1", "--launch", "--steps", "2", "--warmup", "1", "--pairs", "16", "--no-cpu-baseline", "--no-configs",
-                     "--no-roofline"], {"MASTER_PORT": "29613", "HAK_BENCH_FORCE_DIST": "1"})
-    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["verified"]["points_equal"]
+                     "--no-roofline", "--no-fast", "--no-upload"], {"MASTER_PORT": "29613", "HAK_BENCH_FORCE_DIST": "1"})
+    assert out["n_gpus"] == 1 and out["rccl_ranks"] == 1 and out["verified"]["slots_equal"]
 
 
 def test_bench_refuses_more_ranks_than_devices():
