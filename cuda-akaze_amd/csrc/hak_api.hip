@@ -18,6 +18,8 @@
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 int hak_fail(const std::string& m) { g_err = m; return 1; }
+static thread_local const char* g_launch_err = nullptr;
+void hak_note_launch_error(const char* msg) { if (!g_launch_err) g_launch_err = msg; }
 
 extern "C" const char* hak_last_error(void) { return g_err.c_str(); }
 
@@ -642,6 +644,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         hak_launch_download(main_st, d_points, d_num_pts, max_pts, nimg, h_points, c->h_num);
     if (tail_fork && hipStreamWaitEvent(main_st, c->ev_tail_join, 0) != hipSuccess) return fail("stream join");
     if (hipGetLastError() != hipSuccess) return fail("kernel launch failed");
+    if (g_launch_err) { const char* m = g_launch_err; g_launch_err = nullptr; return fail(m); }
     return 0;
 }
 
@@ -837,10 +840,17 @@ extern "C" int hak_detect_and_compute_batch(hak_ctx* c, const float* d_images, l
 }
 
 // is p device-visible (pinned) host memory?  A pageable pointer makes the query fail: not an error here.
+// ... and may the download kernel write it directly?  k_download stores 8-byte words through the pointer itself, so it must be
+// 8-byte aligned and mapped into this device at the same address (hipHostMalloc memory is; an offset into a pinned buffer or
+// hipHostRegister'd memory need not be) -- anything else takes the count + hipMemcpy route.
 static bool host_pinned(const void* p)
 {
     hipPointerAttribute_t a{};
-    const bool pinned = p && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    bool pinned = p && ((uintptr_t)p & 7) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+    if (pinned) {
+        void* dp = nullptr;
+        pinned = hipHostGetDevicePointer(&dp, const_cast<void*>(p), 0) == hipSuccess && dp == p;
+    }
     (void)hipGetLastError();
     return pinned;
 }

@@ -439,3 +439,7 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
 void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,
                             long stride2, int npairs, const int4* fwd, const int4* rev, long knn_stride, int ratio_num,
                             int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count);
+
+// A launcher that cannot do what it was asked (a precondition its caller should have checked) records the reason here instead
+// of aborting; enqueue_detect turns it into the call's error (hak_api.hip).  Thread-local, like hak_last_error().
+void hak_note_launch_error(const char* msg);

@@ -382,9 +382,11 @@ bool hak_launch_hessian_level(hipStream_t st, const float* src, float* dxy, floa
                                       lp_taps))
             return true;
     }
-    if (lp_taps) {                                          // (the caller asked hak_hessian_stream_covers first: not reached)
-        fprintf(stderr, "hipakaze: LP Hessian not covered for %d x %d step %d\n", w, h, step);
-        abort();
+    if (lp_taps) {
+        // the caller asked hak_hessian_stream_covers first, so this is not reached; should the two predicates ever drift apart the
+        // CALL fails (enqueue_detect returns the error) -- a drop-in library does not end its host process
+        hak_note_launch_error("LP Hessian requested for a level the streaming kernel does not cover");
+        return true;
     }
     const HakExtremaArgs<float> ex = extrema_args<float>(b, L, htab, octave, sub, dthreshold);
     float* od = store_det ? det : nullptr;

@@ -18,6 +18,7 @@
 // neighbours taken at reflect-101 INDICES (abs / borderAdd, akazed.cu:1251-1254), never from mirrored halo cells: a mirrored
 // cell would add its N and S terms in the other order.  The raw tile alone is loaded through mirrored indices (on the
 // source extents for an octave head, akazed.cu:466-494), which is what the Gaussian's taps read.
+#include <atomic>
 #include "fed_common.h"
 
 #define LV_MAX_STEPS 36
@@ -360,11 +361,16 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
     // (T + 2 ns + 6)^2): ~100 blocks keep a block short without multiplying the work of the octaves that run beside the critical chain
     while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 96) T -= 8;
     const size_t lds = sizeof(V) * (size_t)total(T);
-    static bool attr_done = false;                           // (per instantiation: each has its own static)
-    if (!attr_done) {
+    // the 150 KB dynamic-LDS opt-in is a per-DEVICE attribute of the function: once per device and instantiation (contexts on
+    // several devices may live in one process, and two threads may create contexts at once)
+    static std::atomic<unsigned long long> attr_done{0};     // bit d: done on device d (per instantiation: each has its own static)
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_level_tile<V, HEAD, FIRST>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   LV_LDS_FLOATS * 4);
-        attr_done = true;
+        attr_done.fetch_or(bit, std::memory_order_release);
     }
     const int nbx = (w + T - 1) / T, nby = (h + T - 1) / T;
     k_level_tile<V, HEAD, FIRST><<<hak_xcd_grid(nbx, nby, nimg), LV_NT, lds, st>>>(src, smooth, dst, stride, so.w, so.h, so.p, w, h, p, t, diffusivity,
