@@ -81,6 +81,7 @@ SYMBOLS = {
     "hak_phase_event": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "hak_set_concurrency": (C.c_int, [_vp, C.c_int]),
     "hak_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
+    "hak_detect_and_compute_pair": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _ip, _ip, _vp, _vp, C.c_int, C.c_int]),
     "hak_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
     "hak_fast_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
     "hak_fast_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),
@@ -150,7 +151,12 @@ class _Libs:
         self.product = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
         self.test = None
         for name, (res, args) in SYMBOLS.items():
-            f = getattr(self.product, name)          # AttributeError here = ABI drift between header and library
+            try:
+                f = getattr(self.product, name)      # AttributeError here = ABI drift between header and library
+            except AttributeError:
+                if os.environ.get("HAK_LIB"):        # an older build loaded for an A/B run may lack the newest entry points
+                    continue
+                raise
             f.restype, f.argtypes = res, args
             setattr(self, name, f)
 
@@ -315,6 +321,19 @@ class Akazer:
         hptr = result.h_data.ctypes.data if result.h_data is not None else None
         check(lib.hak_detect_and_compute(self.ctx, image, p, result.d_data, result.max_pts, C.byref(n), hptr, int(desc)))
         result.num_pts = n.value
+
+    def detectAndComputePair(self, image1, image2, result1, result2, whp0, desc=True, match=True):
+        """build-side addition (akaze.h): both images + cuMatch(result1, result2) as one launch sequence and one synchronisation.
+        The context must have been init()-ed with batch >= 2."""
+        w, h, p = whp0
+        if self._ctx is None or self._ctx_wh != (w, h):
+            self._make_ctx(w, h)
+        n1, n2 = C.c_int(0), C.c_int(0)
+        h1 = result1.h_data.ctypes.data if result1.h_data is not None else None
+        h2 = result2.h_data.ctypes.data if result2.h_data is not None else None
+        check(lib.hak_detect_and_compute_pair(self.ctx, image1, image2, p, result1.d_data, result2.d_data, result1.max_pts, result2.max_pts,
+                                              C.byref(n1), C.byref(n2), h1, h2, int(desc), int(match)))
+        result1.num_pts, result2.num_pts = n1.value, n2.value
 
     def fastDetectAndCompute(self, image, result, whp0, desc=True):
         """akaze.h:30, akaze.cpp:153-201 -- integer FAST path.  ``image`` = device pointer to uint8, pitch whp0[2] bytes."""

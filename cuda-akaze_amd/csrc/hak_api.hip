@@ -323,7 +323,8 @@ extern "C" void hak_destroy(hak_ctx* c)
     }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
-    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt, c->match_keys, c->perm};
+    hak_match_scratch_free(&c->msc);
+    void* bufs[] = {c->arena, c->maps, c->bitmap, c->rowcount, c->cand, c->state, c->d_num, c->dtab, c->knn, c->d_cnt, c->perm, c->pair_pts};
     for (void* b : bufs) (void)hipFree(b);
     if (c->h_num) (void)hipHostFree(c->h_num);
     if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
@@ -885,6 +886,69 @@ extern "C" int hak_detect_and_compute(hak_ctx* c, const float* d_image, int pitc
     return 0;
 }
 
+// Scratch for callers without a context (cuMatch is a free function in the reference, so hak_match / hak_match_knn2 accept
+// ctx == NULL): a pool per device, guarded by a mutex.  A call takes a scratch of the CURRENT device for its duration -- both
+// entry points synchronise before they return -- and puts it back; concurrent callers get different ones.
+namespace {
+std::mutex g_pool_mu;
+std::vector<HakMatchScratch*> g_pool;
+HakMatchScratch* pool_acquire()
+{
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (size_t i = 0; i < g_pool.size(); i++)
+        if (g_pool[i]->device == dev) { HakMatchScratch* sc = g_pool[i]; g_pool.erase(g_pool.begin() + (long)i); return sc; }
+    HakMatchScratch* sc = new HakMatchScratch();
+    sc->device = dev;
+    return sc;
+}
+void pool_release(HakMatchScratch* sc, bool ok)
+{
+    // a call that failed may have left keys / tickets behind: such a scratch is not handed out again
+    if (!ok) { hak_match_scratch_free(sc); delete sc; return; }
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool.push_back(sc);
+}
+}
+
+// One PAIR per call (include/hipakaze.h): both images through ONE launch sequence (the batch path with two images: every launch
+// covers both), the match appended, the records scattered to the caller's arrays by one more kernel, ONE synchronisation --
+// instead of the three synchronous calls of main.cpp:201-209 (43 + 43 + 1 launches, three waits).
+extern "C" int hak_detect_and_compute_pair(hak_ctx* c, const float* d_image1, const float* d_image2, int pitch,
+                                           hak_point* d_points1, hak_point* d_points2, int max_pts1, int max_pts2,
+                                           int* num_pts1, int* num_pts2, hak_point* h_points1, hak_point* h_points2, int desc, int match)
+{
+    if (!c || !d_image1 || !d_image2 || !d_points1 || !d_points2 || !num_pts1 || !num_pts2) return fail("null argument");
+    if (c->cfg.batch < 2) return fail("hak_detect_and_compute_pair needs a context created with batch >= 2");
+    if (max_pts1 < 1 || max_pts2 < 1) return fail("max_pts < 1");
+    if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    const long mp = c->cfg.max_pts;
+    if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");
+    if (!c->pair_pts) HIP_TRY(hipMalloc((void**)&c->pair_pts, sizeof(hak_point) * 2 * (size_t)mp));
+    // the clamp of the call: the smaller of the two AkazeData capacities and the context's (akaze.cpp:246, 451)
+    int clamp = max_pts1 < max_pts2 ? max_pts1 : max_pts2;
+    if (clamp > mp) clamp = (int)mp;
+    if (run_detect(c, d_image1, (long)(d_image2 - d_image1), pitch, 2, c->pair_pts, c->d_num, desc, clamp)) return 1;
+    if (match) {
+        ProfScope ps(c, HAK_PROF_MATCH);
+        hak_launch_match(c->sync_stream, c->pair_pts, c->pair_pts + mp, c->d_num, c->d_num + 1, 0, 0, 2 * mp, 2 * mp, 1);
+    }
+    HakPairDst dst{{d_points1, d_points2}, {host_pinned(h_points1) ? h_points1 : nullptr, host_pinned(h_points2) ? h_points2 : nullptr},
+                   {max_pts1, max_pts2}};
+    hak_launch_download_pair(c->sync_stream, c->pair_pts, c->d_num, mp, dst, c->h_num);
+    if (hipGetLastError() != hipSuccess) return fail("pair launch failed");
+    HIP_TRY(hipStreamSynchronize(c->sync_stream));
+    *num_pts1 = c->h_num[0];
+    *num_pts2 = c->h_num[1];
+    // pageable host arrays take the reference's route (akaze.cpp:134-139): a copy of the valid records
+    if (h_points1 && !dst.h[0] && *num_pts1 > 0)
+        HIP_TRY(hipMemcpy(h_points1, d_points1, sizeof(hak_point) * (size_t)*num_pts1, hipMemcpyDeviceToHost));
+    if (h_points2 && !dst.h[1] && *num_pts2 > 0)
+        HIP_TRY(hipMemcpy(h_points2, d_points2, sizeof(hak_point) * (size_t)*num_pts2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point* d_pts2, int n2, hak_point* h_pts1)
 {
     // ctx may be NULL (cuMatch is a free function in the reference): default stream, no profiling
@@ -892,16 +956,19 @@ extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point*
     if (n1 <= 0) return 0;
     if (n2 >= (1 << 20)) return fail("more than 2^20 - 1 train points");         // k_match packs distance << 20 | index
     // one big pair takes the sliced search (kernels_match.hip), whose scratch belongs to the context (its device) or, without
-    // one, is a stream-ordered allocation on the current device -- no process-wide buffer, no lock
+    // one, comes from the per-device pool above for the duration of the call -- no process-wide buffer
     hipStream_t st = c ? c->stream : nullptr;
-    if (c) {
+    HakMatchScratch* sc = c ? &c->msc : pool_acquire();
+    {
         ProfScope ps(c, HAK_PROF_MATCH);
-        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, &c->match_keys, &c->match_keys_cap);
-    } else {
-        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1);
+        hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, sc);
     }
-    if (hipGetLastError() != hipSuccess) return fail("match launch failed");
-    HIP_TRY(hipStreamSynchronize(st));
+    int rc = 0;
+    if (hipGetLastError() != hipSuccess) rc = fail("match launch failed");
+    if (hipStreamSynchronize(st) != hipSuccess) rc = fail("hipStreamSynchronize(match)");
+    if (!c) pool_release(sc, rc == 0);
+    else if (rc) hak_match_scratch_free(sc);
+    if (rc) return rc;
     if (h_pts1)                                                                   // akaze.cpp:58-63
         HIP_TRY(hipMemcpy2D(&h_pts1[0].match, sizeof(hak_point), &d_pts1[0].match, sizeof(hak_point), 16, n1,
                             hipMemcpyDeviceToHost));
@@ -940,36 +1007,35 @@ extern "C" int hak_match_knn2(hak_ctx* c, hak_point* d_pts1, int n1, const hak_p
     if (n1 <= 0) return 0;
     if (max_dist <= 0) max_dist = HAK_MAX_DIST;
     hipStream_t st = c ? c->stream : nullptr;
-    int4* scratch = nullptr;
-    int* d_cnt = nullptr;
-    const bool own = !c || n1 > c->cfg.max_pts || n2 > c->cfg.max_pts;
-    if (own) {
-        HIP_TRY(hipMalloc((void**)&scratch, sizeof(int4) * ((size_t)n1 + (size_t)(n2 > 0 ? n2 : 1))));
-        HIP_TRY(hipMalloc((void**)&d_cnt, sizeof(int)));
-    } else {
-        if (knn_scratch(c)) return 1;
-        scratch = c->knn;
-        d_cnt = c->d_cnt;
+    HakMatchScratch* sc = c ? &c->msc : pool_acquire();
+    const int nb = (n1 + 1023) / 1024;
+    if (!hak_match_scratch_reserve(sc, st, 0, 0, 0, (long)n1 + (long)(n2 > 0 ? n2 : 1), nb)) {
+        if (!c) pool_release(sc, false);
+        return fail("hak_match_knn2: out of device memory for the 2-NN scratch");
     }
-    int4* fwd = scratch;
-    int4* rev = scratch + n1;
+    int4* fwd = sc->knn;
+    int4* rev = sc->knn + n1;
+    *sc->h_cnt = -1;
     {
-        hak_launch_knn2(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, fwd, 0);
-        if (cross_check && n2 > 0) hak_launch_knn2(st, d_pts2, d_pts1, nullptr, nullptr, n2, n1, 0, 0, 1, rev, 0);
+        hak_launch_knn2(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, fwd, 0, sc);
+        if (cross_check && n2 > 0) hak_launch_knn2(st, d_pts2, d_pts1, nullptr, nullptr, n2, n1, 0, 0, 1, rev, 0, sc);
         hak_launch_knn2_finish(st, d_pts1, d_pts2, nullptr, n1, 0, 0, 1, fwd, cross_check ? rev : nullptr, 0, ratio_num, ratio_den,
-                               cross_check ? 1 : 0, max_dist, d_out, 0, d_cnt);
+                               cross_check ? 1 : 0, max_dist, d_out, 0, sc->d_cnt, sc);
     }
     int rc = 0;
     if (hipGetLastError() != hipSuccess) rc = fail("knn2 launch failed");
-    if (!rc && hipMemcpyAsync(count, d_cnt, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) rc = fail("count download");
     if (!rc && hipStreamSynchronize(st) != hipSuccess) rc = fail("sync");
+    // the multi-block finish leaves the count in the scratch's pinned word; the one-block finish only in device memory
+    if (!rc && *sc->h_cnt < 0 && hipMemcpy(sc->h_cnt, sc->d_cnt, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess) rc = fail("count download");
+    if (!rc) *count = *sc->h_cnt;
+    if (!c) pool_release(sc, rc == 0);
+    else if (rc) hak_match_scratch_free(sc);
     if (!rc && h_out && *count > 0 &&
         hipMemcpy(h_out, d_out, sizeof(hak_match_pair) * (size_t)*count, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail("match list download");
     if (!rc && h_pts1 &&                                                          // akaze.cpp:58-63
         hipMemcpy2D(&h_pts1[0].match, sizeof(hak_point), &d_pts1[0].match, sizeof(hak_point), 16, n1, hipMemcpyDeviceToHost) != hipSuccess)
         rc = fail("match field download");
-    if (own) { (void)hipFree(scratch); (void)hipFree(d_cnt); }
     return rc;
 }
 

@@ -75,8 +75,8 @@ struct hak_ctx {
                                     // (hak_stream_pays), 2 always where covered (env HAK_FUSE_SF)
     int4* knn = nullptr;            // 2-NN scratch: fwd[batch/2][max_pts] | rev[batch/2][max_pts], allocated on first use
     int* d_cnt = nullptr;
-    unsigned* match_keys = nullptr; // sliced 1-NN search of one big pair (hak_launch_match): grows on demand, on this context's device
-    long match_keys_cap = 0;
+    hak_point* pair_pts = nullptr;  // [2][cfg.max_pts]: the contiguous pair layout hak_detect_and_compute_pair detects into and matches on
+    HakMatchScratch msc;            // sliced searches of one big pair (hak_match / hak_match_knn2): grows on demand, on this context's device
     HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
     hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
     hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
@@ -88,9 +88,9 @@ struct hak_ctx {
 
 struct ProfScope {
     hak_ctx* c; int k; hipEvent_t stop = nullptr; hipStream_t s;
-    ProfScope(hak_ctx* ctx, int klass, hipStream_t st = nullptr) : c(ctx), k(klass), s(st ? st : ctx->stream)
+    ProfScope(hak_ctx* ctx, int klass, hipStream_t st = nullptr) : c(ctx), k(klass), s(st ? st : (ctx ? ctx->stream : nullptr))
     {
-        if (!c->prof_on) return;
+        if (!c || !c->prof_on) return;      // (no context: hak_match(NULL, ...))
         ProfClass& p = c->prof[k];
         if (p.used + 2 > p.ev.size()) {
             hipEvent_t a, b;

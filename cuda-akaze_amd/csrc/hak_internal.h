@@ -395,6 +395,9 @@ void hak_launch_extrema_level(hipStream_t st, const HakBatch& b, const HakLayout
                               int s, float dthreshold, long det_off);
 void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d_num, long max_pts, int nimg, hak_point* h_points,
                          int* h_num);
+// destinations of a pair call's records: device arrays, pinned host arrays (or NULL), capacity of each in records
+struct HakPairDst { hak_point* d[2]; hak_point* h[2]; int cap[2]; };
+void hak_launch_download_pair(hipStream_t st, const hak_point* src, const int* d_num, long max_pts, const HakPairDst& dst, int* h_num);
 void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, const HakTables* tab, int psz,
                          hak_point* points, int max_pts, int* num_out, int fast = 0, int refine = 1);
 void hak_launch_clear_maps(hipStream_t st, const HakBatch& b, const HakLayout& L);
@@ -431,14 +434,34 @@ int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, dou
 int hak_launch_stream_probe(int w, int h, int nimg, int nwrite, int warm, int iters, double* ms, double* bytes);
 
 // matcher (kernels_match.hip)
+// Scratch of the SLICED searches (one big pair through hak_match / hak_match_knn2, e.g. 10k x 10k: the train set is cut into
+// slices so that the query blocks x slices fill the chip).  Owned by a context or handed out by the per-device pool of
+// hak_api.hip (ctx == NULL: cuMatch is a free function in the reference); lives on one device, used by one call at a time.
+// Invariant between calls: every key is 0xFFFFFFFF and every ticket 0 -- the kernels restore that themselves (the block that
+// draws a query block's last ticket reads the merged keys with exchanges and resets the ticket), so no call starts with a memset.
+struct HakMatchScratch {
+    unsigned* keys = nullptr; long keys_cap = 0;        // [queries][16] class minima, merged with atomicMin          (1-NN)
+    int* ticket = nullptr; long ticket_cap = 0;         // [query blocks of 128]
+    uint2* part = nullptr; long part_cap = 0;           // [slices][queries padded to 128] two smallest keys per slice (2-NN)
+    int4* knn = nullptr; long knn_cap = 0;              // forward | reverse 2-NN results of hak_match_knn2
+    int* blk = nullptr; long blk_cap = 0;               // accepted matches per 1024-query block (compaction of hak_match_knn2)
+    int* d_cnt = nullptr; int* h_cnt = nullptr;         // accepted-match count: device word and its pinned host mirror
+    int device = -1;
+};
+// grow-only; returns false (and leaves a usable smaller state) when the device is out of memory.  `st`: the stream earlier
+// users of the buffers ran on (synchronised before a buffer is replaced).
+bool hak_match_scratch_reserve(HakMatchScratch* sc, hipStream_t st, long keys, long tickets, long parts, long knn, long blks);
+void hak_match_scratch_free(HakMatchScratch* sc);
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs,
-                      unsigned** scratch = nullptr, long* cap = nullptr);
+                      HakMatchScratch* scratch = nullptr);
 void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
-                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride);
+                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride,
+                     HakMatchScratch* scratch = nullptr);
 void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,
                             long stride2, int npairs, const int4* fwd, const int4* rev, long knn_stride, int ratio_num,
-                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count);
+                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count,
+                            HakMatchScratch* scratch = nullptr);
 
 // A launcher that cannot do what it was asked (a precondition its caller should have checked) records the reason here instead
 // of aborting; enqueue_detect turns it into the call's error (hak_api.hip).  Thread-local, like hak_last_error().

@@ -364,3 +364,28 @@ void hak_launch_download(hipStream_t st, const hak_point* d_points, const int* d
 {
     k_download<<<dim3(8, nimg), 256, 0, st>>>(d_points, d_num, max_pts, h_points, h_num);
 }
+
+// ---- the results of a PAIR call (hak_detect_and_compute_pair): the two images' records go from the context's contiguous pair
+// buffer to the caller's two device arrays (AkazeData::d_data) and, when those are pinned, straight to the two host arrays
+// (AkazeData::h_data) -- one launch behind the match, counts included
+__global__ __launch_bounds__(256) void k_download_pair(const hak_point* __restrict__ src_base, const int* __restrict__ d_num, long max_pts,
+                                                       HakPairDst dst, int* h_num)
+{
+    const int img = blockIdx.y;
+    const int n = min(d_num[img], dst.cap[img]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) h_num[img] = n;
+    const uint2* src = reinterpret_cast<const uint2*>(src_base + (long)img * max_pts);
+    uint2* dd = reinterpret_cast<uint2*>(dst.d[img]);
+    uint2* dh = reinterpret_cast<uint2*>(dst.h[img]);
+    const long total = (long)n * (long)(sizeof(hak_point) / sizeof(uint2));
+    for (long i = blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const uint2 v = src[i];
+        if (dd) dd[i] = v;
+        if (dh) dh[i] = v;
+    }
+}
+
+void hak_launch_download_pair(hipStream_t st, const hak_point* src, const int* d_num, long max_pts, const HakPairDst& dst, int* h_num)
+{
+    k_download_pair<<<dim3(8, 2), 256, 0, st>>>(src, d_num, max_pts, dst, h_num);
+}

@@ -196,23 +196,34 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 // the vector pipe can do with it).  To make the train side's bit -> int8 expansion ONE v_and_b32 per four k, bit t of a nibble
 // stays where it is: x_k = a_k 2^t (mask 0x01010101 << t), y_k = (1 - 2 b_k) 2^(3-t), every product is +-8 a_k and the
 // accumulator holds 8 x the distance (the |b| chunks meet the constant 8).
-//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h (by the thread
-//                      that stages the tile), AND-ed with 0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
+//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h,
+//                      AND-ed with 0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
 //   B (query, cols n): the same bits of query q0 + r as +-2^(3-t); expanded ONCE per wave into 64 VGPRs
 //   C/D: lane (n = l & 31, h) holds train rows (i & 3) + 8 (i >> 2) + 4 h, i < 16, of query n (cdna_hip_programming.md 158)
 // Any assignment of descriptor bits to k positions is fine as long as A and B agree: both come from mm_* below.  Per accumulator
 // element the epilogue is one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32 into the running minimum of
 // ITS register slot -- all rows a slot ever sees are congruent mod 16, i.e. one residue class -- so the reference's "first strict
-// minimum per class" survives as the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set;
-// the four waves of a block share every train tile through LDS: one coalesced 8-byte load and one ds_write_b64 per thread and
-// tile (a lane fetching ITS descriptor row straight from the 104-byte records touches 32 different lines per load instruction:
-// that version ran at a third of the matrix pipe's rate, bound by the texture addresser), rows padded to 80 bytes so that the
-// four ds_read_b128 per lane and tile are conflict-free, double-buffered with one barrier per tile.
+// minimum per class" survives as the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set
+// (or its slice); the four waves of a block share the train descriptors through LDS.
+//
+// Round 4: the train set travels in CHUNKS of MM_CH descriptors (rows of 144 bytes: the 16 dwords, the same shifted right by 4 for lane
+// half 1, padding -- conflict-free ds_read_b128), double-buffered: the 8-byte loads of chunk c+1 (MM_CH / 32 per thread, all in
+// flight at once; a lane fetching ITS descriptor row straight from the 104-byte records touches 32 lines per load instruction and ran
+// at a third of the matrix pipe's rate) are issued before the tiles of chunk c are multiplied and written to the other buffer after
+// them: ONE barrier and ONE exposed memory round trip per chunk.  Round 3 staged tile by tile (a barrier and a dependent load per 32
+// rows, two tiles ahead); for one big pair that loop was latency-bound -- 10k x 10k: 80 us against the 24 us of its MFMAs.
+// What the SQ counters say about the loop now (profiles/r04_match10k_sq.txt): a SIMD's vector and matrix instructions do not overlap
+// here -- SQ_VALU_MFMA_BUSY_CYCLES is exactly 32 cycles per MFMA, SQ_ACTIVE_INST_VALU 4 per vector instruction, and the two add up to
+// the kernel's duration -- so a tile costs 16 x 32 cycles of MFMA + ~100 x 4 cycles of bit expansion and epilogue.  Tried against
+// that and measured equal or worse: two independent accumulation chains per step (same time: the chain is not the limit), no
+// pre-shifted copy (one more v_lshrrev per fragment, same time), other chunk sizes and occupancies (the values below are the best).
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v16i __attribute__((ext_vector_type(16)));
 #define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
+#define MM_BCH 128      // train descriptors per LDS chunk of the batched (unsliced) launches; the sliced search of one big pair uses 256
 #define MM_ROW 36       // dwords per staged train row: the 16 descriptor dwords, the same 16 shifted right by 4 (lane half 1 reads
-                        // those: no shift in the tile loop), 4 of padding (144-byte rows make the ds_read_b128 conflict-free)
+                        // those: no shift in the tile loop, where every VALU instruction counts -- matrix and vector work of a SIMD do
+                        // not overlap here), 4 of padding (144-byte rows make the ds_read_b128 conflict-free)
 __device__ __forceinline__ unsigned mm_chunks3(unsigned p, unsigned& c3)     // p <= 488 as four int8 <= 127: three in bytes 1..3, the fourth in c3
 {
     const unsigned c0 = min(p, 127u), c1 = min(p - c0, 127u), c2 = min(p - c0 - c1, 127u);
@@ -251,31 +262,83 @@ __device__ __forceinline__ void mm_load(const hak_point* __restrict__ pts, int j
     }
 }
 
+// accept rule of gHammingMatch on a query's 16 class minima (akazed.cu:2190-2223): distances only decide (key >> 20) -- the rule
+// compares class minima, not indices; ties between classes never matter for the result (nflag rejects them)
+__device__ __forceinline__ void mm_accept(hak_point* p1, const hak_point* __restrict__ pts2, const unsigned (&all)[16], const int n2)
+{
+    unsigned kmin = all[0];
+#pragma unroll
+    for (int t = 1; t < 16; t++)
+        if ((all[t] >> 20) < (kmin >> 20)) kmin = all[t];
+    const int dmin = (int)(kmin >> 20);
+    int nflag = 0;
+#pragma unroll
+    for (int t = 0; t < 16; t++) nflag += (unsigned)dmin < (all[t] >> 20) ? 1 : 0;                        // akazed.cu:2206
+    const int bi = min((int)(kmin & 0xFFFFFu), max(n2 - 1, 0));           // (always the index itself: belt and braces for the gather below)
+    if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {                             // akazed.cu:2223
+        p1->match = bi;
+        p1->distance = dmin;
+        p1->match_x = pts2[bi].x;
+        p1->match_y = pts2[bi].y;
+    } else {
+        p1->match = -1;
+        p1->distance = -1;
+        p1->match_x = -1.f;
+        p1->match_y = -1.f;
+    }
+}
+
+// Sliced search of one big pair (blockIdx.y = train slice, `ticket` != nullptr): a block merges what it found into scratch and
+// takes a ticket for its query block; the block that draws the LAST ticket finishes the 128 queries -- no memset in front, no
+// finish kernel behind.  The finishing block resets the ticket, so the scratch is in its initial state when the kernel ends.
+//   1-NN: part[slice][query] = {this slice's smallest key, mask of the residue classes that attain its distance}
+//   2-NN: part[slice][query] = this slice's two smallest keys
+// (plain 8-byte stores: no initial state to restore)
 // KNN = true: the 2-NN search of hak_match_knn2 on the same tiles -- per register slot the two smallest keys (min / max / min per
 // element), nearest neighbour = the smallest key of all slots (smallest index among equal distances), d2 = the smallest
 // distance of every OTHER train point; results go to knn_out[query] = {index, d1, d2, 0} instead of the point records.
-template <bool KNN>
-__global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
+template <bool KNN, int MM_CH>
+__global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
-                                                       unsigned* __restrict__ gkey, int tiles_per_slice,
-                                                       int4* __restrict__ knn_out_base, long knn_stride)
+                                                       int rows_per_slice,
+                                                       int4* __restrict__ knn_out_base, long knn_stride,
+                                                       int* __restrict__ ticket, uint2* __restrict__ part, int n1_pad)
 {
-    const int pair = gkey ? 0 : blockIdx.y;
+    const bool sliced = ticket != nullptr;
+    const int pair = sliced ? 0 : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
     hak_point* pts1 = pts1_base + (long)pair * stride1;
     const hak_point* __restrict__ pts2 = pts2_base + (long)pair * stride2;
-    const int jbeg = gkey ? (int)blockIdx.y * tiles_per_slice * MT : 0;      // (multiples of 32: rows keep their residue class)
-    const int jend = gkey ? min(n2, jbeg + tiles_per_slice * MT) : n2;
+    const int jbeg = sliced ? (int)blockIdx.y * rows_per_slice : 0;          // (multiples of 32: rows keep their residue class)
+    const int jend = sliced ? min(n2, jbeg + rows_per_slice) : n2;
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // dword 15 holds byte 60 only, so bytes 1..3 of its fragments are spare k positions: the first four of lane half 0 carry |b|
     // (train side: the constant 8 = the scale of every other product; query side: four chunks of |b|)
     const unsigned a15x = h ? 0u : 0x08080800u, a15y = h ? 0u : 0x00000800u;
-    __shared__ __attribute__((aligned(16))) unsigned int tile[2][32 * MM_ROW];
+    __shared__ __attribute__((aligned(16))) unsigned int tile[2][MM_CH * MM_ROW];
+    __shared__ int s_last;
+    // thread t fetches dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptors j0 + (t >> 3) + 32 i, i < 8: one chunk, all eight
+    // loads in flight together; byte offsets in 32 bits from the (uniform) set base (n2 < 2^20 records, checked by the launcher)
+    const unsigned toff = (unsigned)(threadIdx.x >> 3) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) +
+                          8u * (threadIdx.x & 7);
+    const unsigned tmask = (threadIdx.x & 7) == 7 ? 0xFFu : 0xFFFFFFFFu;                // byte 60 only; bytes 61..63 are struct padding
     for (int qb = blockIdx.x * 128; qb < n1; qb += gridDim.x * 128) {                   // block-uniform: every wave takes part in the staging
         const int q0 = qb + 32 * wv;                                                    // (a wave past n1 computes on zeros and stores nothing)
+        uint2 pre[MM_CH / 32];
+        auto fetch = [&](int j0) {
+#pragma unroll
+            for (int i = 0; i < MM_CH / 32; i++) {
+                uint2 v = make_uint2(0u, 0u);
+                if (j0 + (int)(threadIdx.x >> 3) + 32 * i < jend)
+                    v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2) +
+                                                        ((unsigned)(j0 + 32 * i) * (unsigned)sizeof(hak_point) + toff));
+                pre[i] = v;                                         // (raw: masking here would make the wave wait for the load at once)
+            }
+        };
+        if (jbeg < jend) fetch(jbeg);                               // the first chunk travels while the query is loaded and expanded
         mm_v4i B[16];
         {
             unsigned int qd[16];
@@ -295,13 +358,32 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         for (int i = 0; i < 16; i++) best[i] = 0xFFFFFFFFu;
 #pragma unroll
         for (int i = 0; i < (KNN ? 16 : 1); i++) sec[i] = 0xFFFFFFFFu;
-        // the lane's 16 dwords of tile BUF (row r, half h) -> TD
-#define MM_READ(BUF, TD)                                                                                    \
+        // the lane's 16 dwords of row r of tile K of chunk buffer BUF -> TD
+#define MM_READ(BUF, K, TD)                                                                                 \
         {                                                                                                   \
-            const uint4* row = reinterpret_cast<const uint4*>(tile[BUF] + r * MM_ROW + 16 * h);             \
+            const uint4* row = reinterpret_cast<const uint4*>(tile[BUF] + (32 * (K) + r) * MM_ROW + 16 * h); \
             _Pragma("unroll") for (int c = 0; c < 4; c++) {                                                 \
                 const uint4 v = row[c];                                                                     \
                 TD[4 * c] = v.x; TD[4 * c + 1] = v.y; TD[4 * c + 2] = v.z; TD[4 * c + 3] = v.w;             \
+            }                                                                                               \
+        }
+        // the epilogue of one tile's accumulator: per element one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32
+#define MM_EPI(ACC, J0)                                                                                     \
+        {                                                                                                   \
+            const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
+            if ((J0) + 32 <= jend) {                                                                        \
+                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
+                    const unsigned key = ((unsigned)ACC[i] << 17) + jb;                                     \
+                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
+                    best[i] = min(best[i], key);                                                            \
+                }                                                                                           \
+            } else {                        /* last, partial tile: rows past jend do not exist */            \
+                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
+                    const int row = (i & 3) + 8 * (i >> 2);                                                 \
+                    const unsigned key = (int)jb + row < jend ? ((unsigned)ACC[i] << 17) + jb : 0xFFFFFFFFu; \
+                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
+                    best[i] = min(best[i], key);                                                            \
+                }                                                                                           \
             }                                                                                               \
         }
         // one tile: 32 train descriptors j0 .. j0 + 31 from registers TD
@@ -315,65 +397,35 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                 last.x |= (int)a15x; last.y |= (int)a15y;                                                   \
                 acc = MM_MFMA(last, B[15], acc);                                                            \
             }                                                                                               \
-            const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
-            if ((J0) + 32 <= jend) {                                                                        \
-                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
-                    const unsigned key = ((unsigned)acc[i] << 17) + jb;                                     \
-                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
-                    best[i] = min(best[i], key);                                                            \
-                }                                                                                           \
-            } else {                        /* last, partial tile: rows past jend do not exist */            \
-                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
-                    const int row = (i & 3) + 8 * (i >> 2);                                                 \
-                    const unsigned key = (int)jb + row < jend ? ((unsigned)acc[i] << 17) + jb : 0xFFFFFFFFu; \
-                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
-                    best[i] = min(best[i], key);                                                            \
-                }                                                                                           \
-            }                                                                                               \
+            MM_EPI(acc, J0)                                                                                 \
         }
-        // thread t stages dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptor j0 + (t >> 3)
-        auto fetch = [&](int j0) -> uint2 {
-            const int j = j0 + (int)(threadIdx.x >> 3);
-            uint2 v = make_uint2(0u, 0u);
-            if (j < jend) {
-                v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2 + j) + offsetof(hak_point, features) + 8 * (threadIdx.x & 7));
-                if ((threadIdx.x & 7) == 7) v.y &= 0xFFu;           // byte 60 only; bytes 61..63 are struct padding
+        auto stage = [&](int buf) {
+#pragma unroll
+            for (int i = 0; i < MM_CH / 32; i++) {
+                unsigned int* row = tile[buf] + ((threadIdx.x >> 3) + 32 * i) * MM_ROW + 2 * (threadIdx.x & 7);
+                const uint2 v = make_uint2(pre[i].x, pre[i].y & tmask);
+                *reinterpret_cast<uint2*>(row) = v;
+                *reinterpret_cast<uint2*>(row + 16) = make_uint2(v.x >> 4, v.y >> 4);
             }
-            return v;
         };
-        auto stage = [&](int buf, const uint2 v) {
-            unsigned int* row = tile[buf] + (threadIdx.x >> 3) * MM_ROW + 2 * (threadIdx.x & 7);
-            *reinterpret_cast<uint2*>(row) = v;
-            *reinterpret_cast<uint2*>(row + 16) = make_uint2(v.x >> 4, v.y >> 4);
-        };
-        // Pipeline, one barrier per tile: while tile t is multiplied out of registers, tile t+1 travels LDS -> registers and
-        // tile t+2 global -> registers -> LDS (into the buffer tile t was read from an iteration ago).
-        __syncthreads();                                            // (the previous query group's tiles have been read)
-        stage(0, fetch(jbeg));
-        stage(1, fetch(jbeg + 32));
+        __syncthreads();                                            // (the previous query group's chunks have been read)
+        if (jbeg < jend) stage(0);
         __syncthreads();
-        unsigned int ta[16], tb[16];
-        MM_READ(0, ta)
-        __syncthreads();                                            // (buffer 0 is free again)
-        for (int j0 = jbeg; j0 < jend; j0 += 64) {
-            {
-                const uint2 nx = fetch(j0 + 64);
-                MM_READ(1, tb)
-                __builtin_amdgcn_sched_barrier(0);                  // (the LDS reads are issued here, not sunk to their uses)
-                MM_TILE(ta, j0)
-                stage(0, nx);
-                __syncthreads();
+        int buf = 0;
+        for (int j0 = jbeg; j0 < jend; j0 += MM_CH, buf ^= 1) {
+            const bool more = j0 + MM_CH < jend;                    // (uniform)
+            if (more) fetch(j0 + MM_CH);                            // lands while this chunk is multiplied
+            const int nt = min(MM_CH / 32, (jend - j0 + 31) >> 5);  // tiles of this chunk (uniform)
+            unsigned int ta[16];
+            for (int k = 0; k < nt; k++) {
+                MM_READ(buf, k, ta)
+                MM_TILE(ta, j0 + 32 * k)
             }
-            if (j0 + 32 < jend) {                                   // (uniform)
-                const uint2 nx = fetch(j0 + 96);
-                MM_READ(0, ta)
-                __builtin_amdgcn_sched_barrier(0);
-                MM_TILE(tb, j0 + 32)
-                stage(1, nx);
-                __syncthreads();
-            }
+            if (more) stage(buf ^ 1);                               // (that buffer was last read a chunk ago, before the barrier below)
+            __syncthreads();
         }
 #undef MM_TILE
+#undef MM_EPI
 #undef MM_READ
         const int qi = q0 + r;
         if constexpr (KNN) {
@@ -394,10 +446,46 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             unsigned m2 = 0xFFFFFFFFu;                              // the keys are distinct (they carry the index): one slot holds m1
 #pragma unroll
             for (int i = 0; i < 32; i++) m2 = min(m2, b1[i] == m1 ? b2[i] : b1[i]);
-            if (h == 0 && qi < n1) {
-                int4* out = knn_out_base + (long)pair * knn_stride;
-                out[qi] = m1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
-                                            : make_int4((int)(m1 & 0xFFFFFu), (int)(m1 >> 20), m2 == 0xFFFFFFFFu ? 512 : (int)(m2 >> 20), 0);
+            int4* out = knn_out_base + (long)pair * knn_stride;
+            if (!sliced) {
+                if (h == 0 && qi < n1)
+                    out[qi] = m1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
+                                                : make_int4((int)(m1 & 0xFFFFFu), (int)(m1 >> 20), m2 == 0xFFFFFFFFu ? 512 : (int)(m2 >> 20), 0);
+                continue;
+            }
+            // sliced: this slice's two smallest keys of the query, then the ticket; the last block of the query block merges the slices:
+            // nearest = the smallest m1, second = the smallest of the other slices' m1 and the winning slice's m2
+            if (h == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi), ((unsigned long long)m2 << 32) | m1,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
+            // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
+            // s_waitcnt orders them in front of the ticket)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tk = __hip_atomic_fetch_add(&ticket[qb >> 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = tk == (int)gridDim.y - 1;
+                if (s_last) __hip_atomic_store(&ticket[qb >> 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_last) {                                           // (block-uniform)
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int q = qb + (int)threadIdx.x;
+                if (threadIdx.x < 128 && q < n1) {
+                    unsigned M1 = 0xFFFFFFFFu, M2 = 0xFFFFFFFFu;
+                    for (int s = 0; s < (int)gridDim.y; s++) {
+                        const unsigned long long pv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)s * n1_pad + q),
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned a1 = (unsigned)pv, a2 = (unsigned)(pv >> 32);
+                        // union of {M1, M2} and {a1, a2}, each ascending: its two smallest
+                        const unsigned lo = min(M1, a1), hi = max(M1, a1);
+                        M2 = min(hi, lo == M1 ? M2 : a2);
+                        M1 = lo;
+                    }
+                    out[q] = M1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
+                                               : make_int4((int)(M1 & 0xFFFFFu), (int)(M1 >> 20), M2 == 0xFFFFFFFFu ? 512 : (int)(M2 >> 20), 0);
+                }
             }
             continue;
         }
@@ -410,54 +498,79 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             const unsigned hi = best[k + 8] == 0xFFFFFFFFu ? best[k + 8] : best[k + 8] + (unsigned)((k & 3) + 8 * (k >> 2) + 16);
             cls[k] = min(lo, hi);
         }
-        if (gkey) {                                                 // (uniform) sliced search: merge, k_match_finish decides
+        if (sliced) {                                               // (uniform)
+            // What the accept rule needs of a slice is little: the smallest key (distance << 20 | index) and WHICH classes attain
+            // its distance -- the rule asks whether exactly one class attains the global minimum distance (akazed.cu:2206, 2223).
+            // Plain 8-byte stores; atomicMin on 16 class keys per query ran into the atomic units' throughput (2 M lane-atomics:
+            // 35-85 us for 10k x 10k).
+            unsigned kloc = cls[0];
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (qi < n1 && cls[k] != 0xFFFFFFFFu) atomicMin(&gkey[(long)qi * MC + (k & 3) + 8 * (k >> 2) + 4 * h], cls[k]);
+            for (int k = 1; k < 8; k++) kloc = min(kloc, cls[k]);
+            const unsigned kmin = min(kloc, (unsigned)__shfl_xor((int)kloc, 32));
+            unsigned mloc = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) mloc |= (cls[k] >> 20) == (kmin >> 20) ? 1u << ((k & 3) + 8 * (k >> 2) + 4 * h) : 0u;
+            const unsigned mask = mloc | (unsigned)__shfl_xor((int)mloc, 32);
+            if (h == 0)
+                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi),
+                                   ((unsigned long long)(kmin == 0xFFFFFFFFu ? 0u : mask) << 32) | kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
+            // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
+            // s_waitcnt orders them in front of the ticket)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const int tk = __hip_atomic_fetch_add(&ticket[qb >> 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                s_last = tk == (int)gridDim.y - 1;
+                if (s_last) __hip_atomic_store(&ticket[qb >> 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            __syncthreads();
+            if (s_last) {                                           // (block-uniform) the last block of the query block decides
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                const int q = qb + (int)threadIdx.x;
+                if (threadIdx.x < 128 && q < n1) {
+                    unsigned K = 0xFFFFFFFFu, M = 0u;
+                    for (int s = 0; s < (int)gridDim.y; s++) {
+                        const unsigned long long pv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)s * n1_pad + q),
+                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const unsigned k2 = (unsigned)pv, m2 = (unsigned)(pv >> 32);
+                        if ((k2 >> 20) < (K >> 20)) M = m2;          // a smaller distance: its classes alone attain it
+                        else if ((k2 >> 20) == (K >> 20)) M |= m2;
+                        K = min(K, k2);
+                    }
+                    hak_point* p1 = pts1 + q;
+                    const int dmin = (int)(K >> 20);
+                    const int bi = min((int)(K & 0xFFFFFu), max(n2 - 1, 0));
+                    if (K != 0xFFFFFFFFu && __popc(M) == 1 && dmin < HAK_MAX_DIST) {                   // akazed.cu:2206, 2223
+                        p1->match = bi; p1->distance = dmin; p1->match_x = pts2[bi].x; p1->match_y = pts2[bi].y;
+                    } else {
+                        p1->match = -1; p1->distance = -1; p1->match_x = -1.f; p1->match_y = -1.f;
+                    }
+                }
+            }
             continue;
         }
-        // the other half of the query's classes sits in lane ^ 32; distances only decide (key >> 20): the accept rule compares
-        // class minima, not indices (akazed.cu:2190-2223)
+        // the other half of the query's classes sits in lane ^ 32
         unsigned all[16];
 #pragma unroll
         for (int k = 0; k < 8; k++) { all[k] = cls[k]; all[8 + k] = (unsigned)__shfl_xor((int)cls[k], 32); }
-        unsigned kmin = all[0];
-#pragma unroll
-        for (int t = 1; t < 16; t++) {
-            // ties between classes never matter for the result (nflag below rejects them), any deterministic pick will do
-            if ((all[t] >> 20) < (kmin >> 20)) kmin = all[t];
-        }
-        const int dmin = (int)(kmin >> 20);
-        int nflag = 0;
-#pragma unroll
-        for (int t = 0; t < 16; t++) nflag += (unsigned)dmin < (all[t] >> 20) ? 1 : 0;                    // akazed.cu:2206
-        if (h == 0 && qi < n1) {
-            hak_point* p1 = pts1 + qi;
-            const int bi = min((int)(kmin & 0xFFFFFu), max(n2 - 1, 0));       // (always the index itself: belt and braces for the gather below)
-            if (kmin != 0xFFFFFFFFu && nflag == MC - 1 && dmin < HAK_MAX_DIST) {                         // akazed.cu:2223
-                p1->match = bi;
-                p1->distance = dmin;
-                p1->match_x = pts2[bi].x;
-                p1->match_y = pts2[bi].y;
-            } else {
-                p1->match = -1;
-                p1->distance = -1;
-                p1->match_x = -1.f;
-                p1->match_y = -1.f;
-            }
-        }
+        if (h == 0 && qi < n1) mm_accept(pts1 + qi, pts2, all, n2);
     }
 }
 
-// accept rule of gHammingMatch (akazed.cu:2190-2223) on the merged class minima of the sliced search; one thread per query
-__global__ __launch_bounds__(256) void k_match_finish(hak_point* pts1, const hak_point* pts2, int n1, const unsigned* __restrict__ gkey)
+// accept rule of gHammingMatch (akazed.cu:2190-2223) on the merged class minima of the sliced search of the VALU kernel
+// (HAK_MATCH_VALU=1; k_match_mfma finishes inside its last block); one thread per query
+__global__ __launch_bounds__(256) void k_match_finish(hak_point* pts1, const hak_point* pts2, int n1, unsigned* __restrict__ gkey)
 {
     const int qi = blockIdx.x * 256 + threadIdx.x;
     if (qi >= n1) return;
-    const uint4* k4 = reinterpret_cast<const uint4*>(gkey + (long)qi * MC);
+    uint4* k4 = reinterpret_cast<uint4*>(gkey + (long)qi * MC);
     unsigned k[MC];
 #pragma unroll
-    for (int t = 0; t < MC / 4; t++) { const uint4 v = k4[t]; k[4 * t] = v.x; k[4 * t + 1] = v.y; k[4 * t + 2] = v.z; k[4 * t + 3] = v.w; }
+    for (int t = 0; t < MC / 4; t++) {
+        const uint4 v = k4[t]; k[4 * t] = v.x; k[4 * t + 1] = v.y; k[4 * t + 2] = v.z; k[4 * t + 3] = v.w;
+        k4[t] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);     // the scratch goes back to its empty state (HakMatchScratch)
+    }
     int bc = 0;
 #pragma unroll
     for (int t = 1; t < MC; t++)
@@ -592,8 +705,125 @@ __global__ __launch_bounds__(1024) void k_knn2_finish(hak_point* pts1_base, cons
     if (threadIdx.x == 0 && out_count) out_count[pair * count_out_stride] = sbase;
 }
 
+// ---- big single pairs: accept rule + compaction in two multi-block passes (k_knn2_finish above walks a pair with ONE block:
+// right for a batch of pairs, 35 us for 10k queries).  Pass A applies the rule, writes the match fields and counts the accepted
+// matches of its 1024 queries; pass B re-derives the rule's outcome, adds the counts of the blocks in front of it and writes the
+// match list in ascending query order.
+__device__ __forceinline__ bool knn2_rule(const int i, const int n1, const int4* __restrict__ fwd, const int4* __restrict__ rev,
+                                          const int ratio_num, const int ratio_den, const int cross, const int max_dist, int4& f)
+{
+    f = make_int4(-1, 512, 512, 0);
+    if (i >= n1) return false;
+    f = fwd[i];
+    bool ok = f.x >= 0 && f.y < max_dist && (long)f.y * ratio_den < (long)f.z * ratio_num;
+    if (ok && cross) ok = rev[f.x].x == i;
+    return ok;
+}
+__global__ __launch_bounds__(1024) void k_knn2_finish_a(hak_point* pts1, const hak_point* __restrict__ pts2, int n1,
+                                                        const int4* __restrict__ fwd, const int4* __restrict__ rev, int ratio_num,
+                                                        int ratio_den, int cross, int max_dist, int* __restrict__ blk)
+{
+    __shared__ int wsum[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    int4 f;
+    const bool ok = knn2_rule(i, n1, fwd, rev, ratio_num, ratio_den, cross, max_dist, f);
+    if (i < n1) {
+        hak_point* p1 = pts1 + i;
+        if (ok) { p1->match = f.x; p1->distance = f.y; p1->match_x = pts2[f.x].x; p1->match_y = pts2[f.x].y; }
+        else { p1->match = -1; p1->distance = -1; p1->match_x = -1.f; p1->match_y = -1.f; }
+    }
+    const unsigned long long m = __ballot(ok);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) { int tot = 0; for (int t = 0; t < 16; t++) tot += wsum[t]; blk[blockIdx.x] = tot; }
+}
+__global__ __launch_bounds__(1024) void k_knn2_finish_b(const hak_point* __restrict__ pts1, const hak_point* __restrict__ pts2, int n1,
+                                                        const int4* __restrict__ fwd, const int4* __restrict__ rev, int ratio_num,
+                                                        int ratio_den, int cross, int max_dist, const int* __restrict__ blk,
+                                                        hak_match_pair* __restrict__ out, int* __restrict__ out_count, int* __restrict__ h_count)
+{
+    __shared__ int wsum[16];
+    __shared__ int sbase;
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int4 f;
+    const bool ok = knn2_rule(i, n1, fwd, rev, ratio_num, ratio_den, cross, max_dist, f);
+    const unsigned long long m = __ballot(ok);
+    if (lane == 0) wsum[wv] = __popcll(m);
+    if (wv == 0) {                                                  // accepted matches of all blocks in front of this one
+        int part = 0;
+        for (int b = lane; b < (int)blockIdx.x; b += 64) part += blk[b];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) sbase = part;
+    }
+    __syncthreads();
+    int before = sbase;
+    for (int t = 0; t < wv; t++) before += wsum[t];
+    if (ok && out) {
+        hak_match_pair r;
+        r.query = i; r.train = f.x; r.distance = f.y; r.second = f.z;
+        r.x1 = pts1[i].x; r.y1 = pts1[i].y; r.x2 = pts2[f.x].x; r.y2 = pts2[f.x].y;
+        out[before + __popcll(m & ((1ull << lane) - 1ull))] = r;
+    }
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+        int tot = sbase;
+        for (int t = 0; t < 16; t++) tot += wsum[t];
+        if (out_count) *out_count = tot;
+        if (h_count) *h_count = tot;                                // pinned host word: the count is there when the stream is idle
+    }
+}
+
+// ---- scratch of the sliced searches (hak_internal.h)
+static bool grow(void** p, long* cap, long want, size_t elem, int fill, hipStream_t st)
+{
+    if (want <= *cap) return true;
+    if (*p) { (void)hipStreamSynchronize(st); (void)hipFree(*p); }
+    *p = nullptr; *cap = 0;
+    if (hipMalloc(p, elem * (size_t)want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
+    if (fill >= 0 && hipMemset(*p, fill, elem * (size_t)want) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*p); *p = nullptr; return false; }
+    *cap = want;
+    return true;
+}
+bool hak_match_scratch_reserve(HakMatchScratch* sc, hipStream_t st, long keys, long tickets, long parts, long knn, long blks)
+{
+    if (sc->device < 0) (void)hipGetDevice(&sc->device);
+    bool ok = grow((void**)&sc->keys, &sc->keys_cap, keys, sizeof(unsigned), 0xFF, st);
+    ok = grow((void**)&sc->ticket, &sc->ticket_cap, tickets, sizeof(int), 0, st) && ok;
+    ok = grow((void**)&sc->part, &sc->part_cap, parts, sizeof(uint2), -1, st) && ok;
+    ok = grow((void**)&sc->knn, &sc->knn_cap, knn, sizeof(int4), -1, st) && ok;
+    ok = grow((void**)&sc->blk, &sc->blk_cap, blks, sizeof(int), -1, st) && ok;
+    if (ok && (knn > 0 || blks > 0) && !sc->d_cnt) {
+        ok = hipMalloc((void**)&sc->d_cnt, sizeof(int)) == hipSuccess && hipHostMalloc((void**)&sc->h_cnt, sizeof(int)) == hipSuccess;
+        if (!ok) (void)hipGetLastError();
+    }
+    return ok;
+}
+void hak_match_scratch_free(HakMatchScratch* sc)
+{
+    void* bufs[] = {sc->keys, sc->ticket, sc->part, sc->knn, sc->blk, sc->d_cnt};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (sc->h_cnt) (void)hipHostFree(sc->h_cnt);
+    *sc = HakMatchScratch();
+}
+
+// slices of a big pair's train set for the matrix-core kernel: query blocks x slices ~ `want` blocks (two per CU: the kernel's
+// occupancy), every slice a whole number of 32-row tiles, none empty.  HAK_MATCH_SLICES overrides the count (tuning).
+static int mfma_slices(int gx, int n2, int* rows_per_slice)
+{
+    static const int env = [] { const char* e = getenv("HAK_MATCH_SLICES"); return e ? atoi(e) : 0; }();
+    const int tiles = (n2 + 31) / 32;
+    if (tiles < 16) { *rows_per_slice = tiles * 32; return 1; }
+    int slices = env > 0 ? env : (512 + gx / 2) / gx;
+    if (slices > tiles / 8) slices = tiles / 8;                     // at least 8 tiles (one LDS chunk) per slice
+    if (slices < 1) slices = 1;
+    const int tps = (tiles + slices - 1) / slices;
+    *rows_per_slice = tps * 32;
+    return (tiles + tps - 1) / tps;
+}
+
 void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
-                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride)
+                     int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride, HakMatchScratch* sc)
 {
     const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call, as in hak_launch_match)
     if (!(env_valu && atoi(env_valu) != 0) && nB_host < (1 << 20)) {
@@ -601,8 +831,18 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
         int gx = nA_dev ? 83 : (nA_host + 127) / 128;
         if (gx < 1) gx = 1;
         if (gx > 4096) gx = 4096;
-        k_match_mfma<true><<<dim3(gx, npairs), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB,
-                                                            2, nullptr, 0, out, out_stride);
+        // one big pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set
+        if (sc && !nA_dev && npairs == 1 && gx < 384 && (long)gx * 128 >= nA_host) {
+            int rps = 0;
+            const int slices = mfma_slices(gx, nB_host, &rps);
+            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
+                k_match_mfma<true, 256><<<dim3(gx, slices), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nullptr, nullptr, nA_host, nB_host, 0, 0,
+                                                                    2, rps, out, 0, sc->ticket, sc->part, gx * 128);
+                return;
+            }
+        }
+        k_match_mfma<true, MM_BCH><<<dim3(gx, npairs), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB,
+                                                            2, 0, out, out_stride, nullptr, nullptr, 0);
         return;
     }
     int gx = nA_dev ? 640 : (nA_host + MQ - 1) / MQ;
@@ -613,18 +853,25 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
 
 void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, int n1_host, long stride1,
                             long stride2, int npairs, const int4* fwd, const int4* rev, long knn_stride, int ratio_num,
-                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count)
+                            int ratio_den, int cross, int max_dist, hak_match_pair* out, long out_stride, int* out_count,
+                            HakMatchScratch* sc)
 {
+    const int nb = (n1_host + 1023) / 1024;
+    if (sc && !n1_dev && npairs == 1 && nb > 1 && hak_match_scratch_reserve(sc, st, 0, 0, 0, 0, nb)) {
+        k_knn2_finish_a<<<nb, 1024, 0, st>>>(pts1, pts2, n1_host, fwd, rev, ratio_num, ratio_den, cross, max_dist, sc->blk);
+        k_knn2_finish_b<<<nb, 1024, 0, st>>>(pts1, pts2, n1_host, fwd, rev, ratio_num, ratio_den, cross, max_dist, sc->blk, out, out_count,
+                                             sc->h_cnt);
+        return;
+    }
     k_knn2_finish<<<npairs, 1024, 0, st>>>(pts1, pts2, n1_dev, n1_host, stride1, stride2, 2, fwd, rev, knn_stride, ratio_num,
                                            ratio_den, cross, max_dist, out, out_stride, out_count, 1);
 }
 
-// Scratch of the sliced search (one big pair through hak_match): owned by the calling context (`scratch` / `cap` point at its
-// members; the buffer lives on the context's device and only ever grows).  Without a context (cuMatch is a free function in
-// the reference, so hak_match accepts ctx == NULL) the buffer is a stream-ordered allocation on the device that is current
-// for this call, released after the finish kernel -- never a process-wide pointer that could belong to another device.
+// Big single pairs (hak_match with host-side counts, e.g. 10k x 10k) are SLICED: the train set is cut so that query blocks x
+// slices fill the chip; the slices merge through `scratch` (HakMatchScratch: owned by the calling context or handed out by
+// hak_api.hip's per-device pool -- never a process-wide pointer that could belong to another device).
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
-                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, unsigned** scratch, long* cap)
+                      int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, HakMatchScratch* sc)
 {
     // k_match_mfma: a wave = 32 queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
     const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call: the tests run both kernels in one process)
@@ -639,41 +886,32 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
     // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well
-    const int tiles = (n2_host + MT - 1) / MT;
-    const int want = valu ? 2048 : 1536;                            // blocks
-    if (!n1_dev && npairs == 1 && !(valu && two) && gx < want && tiles >= 4) {
-        int slices = (want + gx - 1) / gx;
-        if (slices > tiles / 2) slices = tiles / 2;
-        const int tps = (tiles + slices - 1) / slices;
-        slices = (tiles + tps - 1) / tps;
-        const long need = (long)n1_host * MC;
-        if (slices > 1) {
-            unsigned* keys = nullptr;
-            bool transient = false;
-            if (scratch && cap) {
-                if (need > *cap) {                                  // (earlier launches that used the old buffer are ahead of us on `st`)
-                    if (*scratch) { (void)hipStreamSynchronize(st); (void)hipFree(*scratch); }
-                    *scratch = nullptr; *cap = 0;
-                    if (hipMalloc((void**)scratch, sizeof(unsigned) * (size_t)need) == hipSuccess) *cap = need;
-                    else (void)hipGetLastError();
-                }
-                keys = *scratch;
-            } else {
-                transient = hipMallocAsync((void**)&keys, sizeof(unsigned) * (size_t)need, st) == hipSuccess;
-                if (!transient) { keys = nullptr; (void)hipGetLastError(); }
+    if (sc && !n1_dev && npairs == 1 && (long)gx * qb >= nq) {
+        if (!valu && gx < 384) {
+            int rps = 0;
+            const int slices = mfma_slices(gx, n2_host, &rps);
+            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
+                k_match_mfma<false, 256><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, rps,
+                                                                     nullptr, 0, sc->ticket, sc->part, gx * 128);
+                return;
             }
-            if (keys) {
-                (void)hipMemsetAsync(keys, 0xFF, sizeof(unsigned) * (size_t)need, st);
-                if (valu) k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps);
-                else k_match_mfma<false><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, keys, tps, nullptr, 0);
-                k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, keys);
-                if (transient) (void)hipFreeAsync(keys, st);
+        }
+        const int tiles = (n2_host + MT - 1) / MT;
+        if (valu && !two && gx < 2048 && tiles >= 4) {
+            int slices = (2048 + gx - 1) / gx;
+            if (slices > tiles / 2) slices = tiles / 2;
+            const int tps = (tiles + slices - 1) / slices;
+            slices = (tiles + tps - 1) / tps;
+            if (slices > 1 && hak_match_scratch_reserve(sc, st, (long)n1_host * MC, 0, 0, 0, 0)) {
+                k_match<1><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, sc->keys, tps);
+                k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, sc->keys);
                 return;
             }
         }
     }
     dim3 grid(gx, npairs);
-    if (!valu) k_match_mfma<false><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0, nullptr, 0);
+    if (!valu) k_match_mfma<false, MM_BCH><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, 0,
+                                                        nullptr, 0, nullptr, nullptr, 0);
     else if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
     else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
 }

@@ -55,6 +55,18 @@ int hak_detect_and_compute(hak_ctx* c, const float* img, int pitch, hak_point* d
 { return img ? fake_detect(c, pitch, d, max_pts, n, h) : (g_err = "null image", 1); }
 int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* img, int pitch, hak_point* d, int max_pts, int* n, hak_point* h, int)
 { return img ? fake_detect(c, pitch, d, max_pts, n, h) : (g_err = "null image", 1); }
+int hak_match(hak_ctx*, hak_point* p1, int n1, const hak_point* p2, int n2, hak_point* h1);
+int hak_detect_and_compute_pair(hak_ctx* c, const float* i1, const float* i2, int pitch, hak_point* d1, hak_point* d2, int m1, int m2,
+                                int* n1, int* n2, hak_point* h1, hak_point* h2, int, int match)
+{
+    if (!c || c->cfg.batch < 2) { g_err = "pair call needs batch >= 2"; return 1; }
+    const int clamp = m1 < m2 ? m1 : m2;
+    if (!i1 || !i2 || fake_detect(c, pitch, d1, clamp, n1, nullptr) || fake_detect(c, pitch, d2, clamp, n2, nullptr)) return 1;
+    if (match) hak_match(nullptr, d1, *n1, d2, *n2, nullptr);
+    if (h1 && *n1) memcpy(h1, d1, sizeof(hak_point) * (size_t)*n1);
+    if (h2 && *n2) memcpy(h2, d2, sizeof(hak_point) * (size_t)*n2);
+    return 0;
+}
 int hak_match(hak_ctx*, hak_point* p1, int n1, const hak_point* p2, int n2, hak_point* h1)
 {
     for (int i = 0; i < n1; i++) {

@@ -35,6 +35,10 @@ namespace akaze
         void fastDetectAndCompute(unsigned char* image, AkazeData& result, int3 whp0, const bool desc = true);
 
         // build-side additions (no reference counterpart)
+        // both images of a pair + cuMatch(result1, result2) as ONE launch sequence and one synchronisation (hak_detect_and_compute_pair):
+        // same results in result1 / result2 as the two detectAndCompute calls followed by cuMatch of main.cpp:201-209
+        void detectAndComputePair(float* image1, float* image2, AkazeData& result1, AkazeData& result2, int3 whp0,
+                                  const bool desc = true, const bool match = true);
         void setMaxPoints(int max_pts);      // capacity the context is built for (default 10000, main.cpp:155)
         void setUpright(bool upright);       // MLDB-upright extension
         hak_ctx* context() { return ctx; }
@@ -44,6 +48,8 @@ namespace akaze
         int3 whp{0, 0, 0};
         hak_ctx* ctx = nullptr;      // owns the arena (the reference's omem), freed in the destructor
         int ctx_w = 0, ctx_h = 0;
+        hak_ctx* pair_ctx = nullptr; // two-image context of detectAndComputePair, created on first use
+        int pair_w = 0, pair_h = 0;
         void ensureContext(int w, int h);
     };
 }

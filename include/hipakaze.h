@@ -127,6 +127,16 @@ int hak_fast_detect_and_compute(hak_ctx* ctx, const unsigned char* d_image, int 
 int hak_fast_detect_and_compute_batch(hak_ctx* ctx, const unsigned char* d_images, long image_stride, int pitch,
                                       int nimg, hak_point* d_points, int* d_num_pts, int desc);
 
+/* ---- one PAIR per call: detectAndCompute on both images + cuMatch of the pair (main.cpp:201-209's three synchronous calls) as ONE
+ * launch sequence and ONE synchronisation.  Build-side addition for callers that are bound by launches, not by bytes (a single
+ * 1080p pair: 0.94 ms through the three calls).  The context must have been created with batch >= 2.  d_points1 / d_points2
+ * (device, max_pts1 / max_pts2 records), h_points1 / h_points2 (host or NULL; pinned host arrays are written by the launch
+ * sequence itself) and the counts are filled exactly as two hak_detect_and_compute calls followed by hak_match(ctx, 1, 2) would;
+ * the clamp of the call is min(max_pts1, max_pts2, the context's max_pts).  match = 0 skips the matcher. */
+int hak_detect_and_compute_pair(hak_ctx* ctx, const float* d_image1, const float* d_image2, int pitch,
+                                hak_point* d_points1, hak_point* d_points2, int max_pts1, int max_pts2,
+                                int* num_pts1, int* num_pts2, hak_point* h_points1, hak_point* h_points2, int desc, int match);
+
 /* ---- cuMatch (akaze.h:14; ctx may be NULL = default stream, akaze.cpp:55-64, akazed.cu:2144-2241): 1-NN
  * Hamming, accepted iff dist < 96 and the minimum is attained in exactly one
  * of the 16 residue classes j mod 16.  Fills match/distance/match_x/match_y

@@ -156,6 +156,49 @@ def test_natural_1080p_pair_vs_oracle(ah, okz, torch, synth, golden):
         assert_points_equal(gpu_fast_detect(ah, torch, rec[name]), r.points)
 
 
+@pytest.mark.parametrize("pinned", [True, False], ids=["pinned h_data", "pageable h_data"])
+def test_pair_call_equals_the_three_calls(ah, torch, synth, golden, pinned):
+    """hak_detect_and_compute_pair / Akazer.detectAndComputePair: both images + cuMatch as ONE launch sequence -- byte for byte what
+    detectAndCompute x 2 + cuMatch leave in the two AkazeData (device and host arrays), on the reference's bundled pair; also with
+    unequal capacities (the smaller one clamps both) and without the match"""
+    a, b = golden.lr_u8["left"], golden.lr_u8["right"]
+    h, w = a.shape
+    p = ah.iAlignUp(w, 128)
+    imgs = [torch.from_numpy(synth.to_float(u, p)).cuda() for u in (a, b)]
+    det = ah.Akazer()
+    det.init((w, h, p), batch=2)
+    d = [ah.AkazeData() for _ in range(4)]
+    for k, cap in enumerate((10000, 10000, 10000, 2500)):
+        ah.initAkazeData(d[k], cap, True, True, pinned=pinned)
+    det.detectAndComputePair(imgs[0].data_ptr(), imgs[1].data_ptr(), d[0], d[1], (w, h, p), True, True)
+    g1, g2 = golden.lr["pts1"], golden.lr["pts2"]
+    assert d[0].num_pts == len(g1) and d[1].num_pts == len(g2)
+    assert_points_equal(d[0].h_data[:d[0].num_pts], g1, fields=("x", "y", "octave", "response", "size", "angle", "features", "match", "distance",
+                                                                 "match_x", "match_y"))
+    assert_points_equal(d[1].h_data[:d[1].num_pts], g2)
+    # the device arrays hold the same records (what a later cuMatch / cuMatchKnn of the caller reads)
+    dev = np.zeros(d[0].num_pts, ah.POINT_DTYPE)
+    ah.check(ah.lib.hak_memcpy_d2h(dev.ctypes.data, d[0].d_data, dev.nbytes))
+    assert dev.tobytes() == d[0].h_data[:d[0].num_pts].tobytes()
+    # unequal capacities: min(cap1, cap2) is the clamp of the call; no match: the fields stay at -1
+    det.detectAndComputePair(imgs[0].data_ptr(), imgs[1].data_ptr(), d[2], d[3], (w, h, p), True, False)
+    assert d[2].num_pts == 2500 and d[3].num_pts == 2500
+    assert_points_equal(d[2].h_data[:2500], g1[:2500])
+    assert_points_equal(d[3].h_data[:2500], g2[:2500])
+    assert (d[2].h_data[:2500]["match"] == -1).all()
+    # the call repeats (graph replay of the captured sequence) and a one-image context refuses it
+    det.detectAndComputePair(imgs[0].data_ptr(), imgs[1].data_ptr(), d[0], d[1], (w, h, p), True, True)
+    assert dev.tobytes() == d[0].h_data[:d[0].num_pts].tobytes()
+    one = ah.Akazer()
+    one.init((w, h, p))
+    with pytest.raises(ah.HakError, match="batch >= 2"):
+        one.detectAndComputePair(imgs[0].data_ptr(), imgs[1].data_ptr(), d[0], d[1], (w, h, p))
+    one.close()
+    for x in d:
+        ah.freeAkazeData(x)
+    det.close()
+
+
 def test_max_pts_clamp_is_raster_prefix(ah, okz, torch, synth):
     u8 = _mg().case_scene(640, 480, 21)
     full = okz.detect_and_compute(synth.to_float(u8, 640), 640).points
