@@ -390,6 +390,7 @@ class Pipeline:
             self.h_pts.append(hp)
             self.h_num.append(hn)
         self.nctx = nctx
+        self.nseq = 0                           # float-path launch sequences enqueued so far (the PMC tools divide by it)
         self.last_pairs = [0] * nctx            # pairs of the last job each context ran (whose download its host buffers hold)
         # off by default: +1.4 % at 1080p in one A/B, nothing in the next, -3 % at 720p
         self.phase_lock = os.environ.get("HAK_BENCH_PHASE_LOCK", "0") != "0"
@@ -404,6 +405,7 @@ class Pipeline:
         ah = self.ah
         n = self.nimg if npairs is None else 2 * npairs
         fn = ah.lib.hak_fast_detect_and_compute_batch if fast else ah.lib.hak_detect_and_compute_batch
+        self.nseq += 0 if fast else 1
         ah.check(fn(self.dets[k].ctx, d_imgs.data_ptr(), self.h * self.p, self.p, n, self.d_pts[k].data_ptr(), self.d_num[k].data_ptr(), 1))
         ah.check(ah.lib.hak_match_batch(self.dets[k].ctx, self.d_pts[k].data_ptr(), self.d_num[k].data_ptr(), n // 2))
 
@@ -968,6 +970,7 @@ def main():
             if world == 1 and not args.no_cpu_baseline and (w, h) == (1920, 1080):
                 cpu = cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times)
 
+    nseq_total = pipe.nseq
     pipe.close()
     del d_imgs
     extra = None
@@ -990,6 +993,7 @@ def main():
                                    "MLDB-486, max_pts 10000, float path; detect+describe both images + match, D2H included",
                        "pairs_per_step_per_gpu": my_pairs if strong else B, "pairs_per_launch_sequence": B,
                        "total_pairs_per_step": args.total_pairs if strong else world * B, "distinct_pairs_per_gpu": NDIST,
+                       "float_sequences_enqueued": nseq_total,
                        "octave_streams": "one stream per context" if pipe.serial else "concurrent", "step_pipeline": NCTX,
                        "sharding": "independent pairs per rank, no data-path collective", "rank0_gpu_numa_node": numa_node,
                        "keypoints_per_image": round(gather["keypoints"] / max(1.0, 2.0 * gather["pairs"]), 1),

@@ -75,45 +75,44 @@ template <int I, typename V4> __device__ __forceinline__ auto hs_c(const V4& r)
     else if constexpr (I == 2) return r.z;
     else return r.w;
 }
-// value at column x0 + K - S of the row held as r (columns x0 .. x0+3): the own component, or the left lane's through one
-// DPP shift; `le` (the lane holding image column 0) reads the reflected column S - K instead.  One scalar at a time so
-// that only the values of the component being evaluated are live.
-template <int S, int K, bool XEDGE, typename V4>
-__device__ __forceinline__ auto hs_l(const V4& r, const bool le)
+// value at column x0 + K - S of the row held as r (columns x0 .. x0+3): the own component, or the left lane's through one DPP
+// shift.  One scalar at a time so that only the values of the component being evaluated are live.  No reflect logic here: in
+// the strips that contain image column 0 / w-1 the lane just OUTSIDE the image holds the reflected columns (hs_patch).
+template <int S, int K, typename V4>
+__device__ __forceinline__ auto hs_l(const V4& r)
 {
-    decltype(r.x) v;
-    if constexpr (K - S >= 0) v = hs_c<K - S>(r);
-    else {
-        v = wave_shr1(hs_c<4 + K - S>(r));
-        if (XEDGE) {
-            if constexpr (S - K <= 3) v = le ? hs_c<S - K>(r) : v;
-            else {
-                // column 4 = the right lane's first component.  The shift must execute with every lane active: inside the
-                // conditional operator it would run under the `le` lane's EXEC mask only and read its neighbour as 0.
-                const auto c4 = wave_shl1(r.x);
-                v = le ? c4 : v;
-            }
-        }
-    }
-    return v;
+    if constexpr (K - S >= 0) return hs_c<K - S>(r);
+    else return wave_shr1(hs_c<4 + K - S>(r));
 }
-// value at column x0 + K + S; `re` (the lane holding image column w-1) reads the reflected column 6 - K - S (relative)
-template <int S, int K, bool XEDGE, typename V4>
-__device__ __forceinline__ auto hs_r(const V4& r, const bool re)
+// value at column x0 + K + S
+template <int S, int K, typename V4>
+__device__ __forceinline__ auto hs_r(const V4& r)
 {
-    decltype(r.x) v;
-    if constexpr (K + S <= 3) v = hs_c<K + S>(r);
-    else {
-        v = wave_shl1(hs_c<K + S - 4>(r));
-        if (XEDGE) {
-            if constexpr (6 - K - S >= 0) v = re ? hs_c<6 - K - S>(r) : v;
-            else {
-                const auto cm1 = wave_shr1(r.w);                   // column -1 = the left lane's last component (all lanes active)
-                v = re ? cm1 : v;
-            }
-        }
+    if constexpr (K + S <= 3) return hs_c<K + S>(r);
+    else return wave_shl1(hs_c<K + S - 4>(r));
+}
+// Reflect-101 in x, once per ring row instead of once per tap (round 4).  The reference reflects the INDEX it reads a plane at
+// (akazed.cu:1284-1291, 1318-1325): column -k reads column k, column w-1+k reads column w-1-k -- in EVERY plane (smooth, Lx, Ly)
+// separately.  So when a row enters a ring, the lane that holds columns -4 .. -1 (lm1) takes columns 4, 3, 2, 1 from its two right
+// neighbours and the lane that holds w .. w+3 (rp1) takes w-2 .. w-5 from its two left neighbours; every dilated tap (|offset| <= 4)
+// of an image column then finds the reflected value through the ordinary wave shift.  XE: bit 0 = the strip contains column 0,
+// bit 1 = it contains column w-1.  10 vector instructions per side and ring row against a select on every shifted tap before
+// (S = 3: 307 -> ~250 instructions per row in the edge strips, a third of the class's pixels).
+template <int XE, typename V4>
+__device__ __forceinline__ V4 hs_patch(const V4 r, const bool lm1, const bool rp1)
+{
+    V4 o = r;
+    if constexpr ((XE & 1) != 0) {
+        const auto c1 = wave_shl1(r.y), c2 = wave_shl1(r.z), c3 = wave_shl1(r.w);      // the right neighbour's columns 1, 2, 3
+        const auto c4 = wave_shl1(wave_shl1(r.x));                                     // column 4: two lanes to the right
+        o.x = lm1 ? c4 : o.x; o.y = lm1 ? c3 : o.y; o.z = lm1 ? c2 : o.z; o.w = lm1 ? c1 : o.w;
     }
-    return v;
+    if constexpr ((XE & 2) != 0) {
+        const auto m2 = wave_shr1(r.z), m3 = wave_shr1(r.y), m4 = wave_shr1(r.x);      // the left neighbour's columns w-2, w-3, w-4
+        const auto m5 = wave_shr1(wave_shr1(r.w));                                     // column w-5: two lanes to the left
+        o.x = rp1 ? m2 : o.x; o.y = rp1 ? m3 : o.y; o.z = rp1 ? m4 : o.z; o.w = rp1 ? m5 : o.w;
+    }
+    return o;
 }
 
 __device__ __forceinline__ float hs_max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
@@ -185,7 +184,7 @@ __device__ __forceinline__ void hs_emit(const bool hit, const V v, const int x, 
     }
 }
 
-template <typename V, int S, int U, bool XEDGE, bool YEDGE, bool LP>
+template <typename V, int S, int U, int XE, bool YEDGE, bool LP>
 __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const HsArgs<V>& a, const int xl, const int x0,
                                         const int ybeg, const int yend, const bool owns, const unsigned xok, const int lane,
                                         const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3], const int er0, const int er1,
@@ -196,7 +195,8 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
     constexpr int PD = HsGeo<S, LP>::PD;
     const V fac1 = a.fac1, fac2 = a.fac2;
     const int w = a.w, h = a.h, p = a.p;
-    const bool le = x0 == 0, re = x0 + 3 == w - 1;
+    [[maybe_unused]] const bool le = x0 == 0, re = x0 + 3 == w - 1;      // (LP row pass only)
+    const bool lm1 = x0 == -4, rp1 = x0 == w;                            // the lanes just outside the image: hs_patch
     // ---- input row t arrived in its ring slot (requested PD iterations ago); request row t + PD straight into the slot it
     // will occupy (the row that slot held, t - 2S - 1, is dead).  No register is ever copied while its load is in flight:
     // rotating a prefetch queue by moves made the compiler wait for vmcnt(0) every iteration.
@@ -212,7 +212,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
             const V sl1 = wave_shr1(c.w), sl2 = wave_shr1(c.z), sr1 = wave_shl1(c.x), sr2 = wave_shl1(c.y);
             V4 l1 = mk4(sl1, c.x, c.y, c.z), l2 = mk4(sl2, sl1, c.x, c.y);
             V4 r1 = mk4(c.y, c.z, c.w, sr1), r2 = mk4(c.z, c.w, sr1, sr2);
-            if (XEDGE) {
+            if (XE) {
                 l1.x = le ? c.y : l1.x;                         // column -1 -> 1
                 l2.x = le ? c.z : l2.x;                         // column -2 -> 2
                 l2.y = le ? c.y : l2.y;                         // column -1 -> 1
@@ -244,6 +244,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
             T.A[pmod(U, R)] = sm;
         }
     }
+    if constexpr (XE != 0) T.A[pmod(U, R)] = hs_patch<XE>(T.A[pmod(U, R)], lm1, rp1);
     if (YEDGE) {
 #pragma unroll
         for (int j = 1; j <= S; j++) {
@@ -259,9 +260,9 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
         V4 vx, vy;
 #define HS_S1(k, K)                                                                                         \
         {                                                                                                   \
-            const V ul = hs_l<S, K, XEDGE>(ru, le), ur = hs_r<S, K, XEDGE>(ru, re);                     \
-            const V cl = hs_l<S, K, XEDGE>(rc, le), cr = hs_r<S, K, XEDGE>(rc, re);                     \
-            const V ll = hs_l<S, K, XEDGE>(rl, le), lr = hs_r<S, K, XEDGE>(rl, re);                     \
+            const V ul = hs_l<S, K>(ru), ur = hs_r<S, K>(ru);                                               \
+            const V cl = hs_l<S, K>(rc), cr = hs_r<S, K>(rc);                                               \
+            const V ll = hs_l<S, K>(rl), lr = hs_r<S, K>(rl);                                               \
             vx.k = HS_DX(ul, ur, cl, cr, ll, lr);                                                           \
             vy.k = HS_DY(ul, ru.k, ur, ll, rl.k, lr);                                                       \
         }
@@ -270,6 +271,7 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
         HS_S1(x, 0) __builtin_amdgcn_sched_barrier(0); HS_S1(y, 1) __builtin_amdgcn_sched_barrier(0);
         HS_S1(z, 2) __builtin_amdgcn_sched_barrier(0); HS_S1(w, 3) __builtin_amdgcn_sched_barrier(0);
 #undef HS_S1
+        if constexpr (XE != 0) { vx = hs_patch<XE>(vx, lm1, rp1); vy = hs_patch<XE>(vy, lm1, rp1); }
         T.X[pmod(U, R)] = vx;
         T.Y[pmod(U, R) * 64 + lane] = vy;
         {
@@ -316,11 +318,11 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
         V4 d;
 #define HS_DET(k, K)                                                                                        \
         {                                                                                                   \
-            const V xul = hs_l<S, K, XEDGE>(xu, le), xur = hs_r<S, K, XEDGE>(xu, re);                   \
-            const V xcl = hs_l<S, K, XEDGE>(xc, le), xcr = hs_r<S, K, XEDGE>(xc, re);                   \
-            const V xll = hs_l<S, K, XEDGE>(xd, le), xlr = hs_r<S, K, XEDGE>(xd, re);                   \
-            const V yul = hs_l<S, K, XEDGE>(yu, le), yur = hs_r<S, K, XEDGE>(yu, re);                   \
-            const V yll = hs_l<S, K, XEDGE>(yd, le), ylr = hs_r<S, K, XEDGE>(yd, re);                   \
+            const V xul = hs_l<S, K>(xu), xur = hs_r<S, K>(xu);                                             \
+            const V xcl = hs_l<S, K>(xc), xcr = hs_r<S, K>(xc);                                             \
+            const V xll = hs_l<S, K>(xd), xlr = hs_r<S, K>(xd);                                             \
+            const V yul = hs_l<S, K>(yu), yur = hs_r<S, K>(yu);                                             \
+            const V yll = hs_l<S, K>(yd), ylr = hs_r<S, K>(yd);                                             \
             const V dxx = HS_DX(xul, xur, xcl, xcr, xll, xlr);                                          \
             const V dxy = HS_DY(xul, xu.k, xur, xll, xd.k, xlr);                                        \
             const V dyy = HS_DY(yul, yu.k, yur, yll, yd.k, ylr);                                        \
@@ -369,16 +371,16 @@ __device__ __forceinline__ void hs_iter(HsState<V, S, LP>& T, const int t, const
     }
 }
 
-template <typename V, int S, bool XEDGE, bool YEDGE, bool LP, int... U>
+template <typename V, int S, int XE, bool YEDGE, bool LP, int... U>
 __device__ __forceinline__ void hs_group(std::integer_sequence<int, U...>, HsState<V, S, LP>& T, const int tb, const HsArgs<V>& a,
                                          const int xl, const int x0, const int ybeg, const int yend, const bool owns,
                                          const unsigned xok, const int lane, const __amdgpu_buffer_rsrc_t orsrc, const unsigned (&ovoff)[3],
                                          const int er0, const int er1, const HsCold* cold)
 {
-    (hs_iter<V, S, U, XEDGE, YEDGE, LP>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold), ...);
+    (hs_iter<V, S, U, XE, YEDGE, LP>(T, tb + U, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold), ...);
 }
 
-template <typename V, int S, bool XEDGE, bool LP>
+template <typename V, int S, int XE, bool LP>
 __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const int ybeg, const int yend, const bool owns,
                                          const int lane, typename FedV<V>::V4* yring, typename FedV<V>::V4* xstage, unsigned long long* cbuf,
                                          const HsCold* cold)
@@ -441,9 +443,9 @@ __device__ __forceinline__ void hs_strip(const HsArgs<V>& a, const int x0, const
         // reflect injections fire while a ring is at rows 1..S (t <= 2S) or at the virtual rows past h-1 (LP: the raw row of
         // iteration t is t+2)
         if (tb <= 2 * S || tb + G::R - 1 >= h - (LP ? 2 : 0))
-            hs_group<V, S, XEDGE, true, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
+            hs_group<V, S, XE, true, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
         else
-            hs_group<V, S, XEDGE, false, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
+            hs_group<V, S, XE, false, LP>(std::make_integer_sequence<int, G::R>{}, T, tb, a, xl, x0, ybeg, yend, owns, xok, lane, orsrc, ovoff, er0, er1, cold);
     }
     if (a.maps != nullptr) hs_flush(T.cb, cold, lane);
 }
@@ -472,9 +474,14 @@ __global__ __launch_bounds__(256, (HsGeo<S, LP>::MINW)) void k_hessian_stream(Hs
     const int yend = min(ybeg + ry, a.h);
     const int x0 = bx * G::XV - G::M + 4 * lane;                // first pixel of this lane (may lie outside the image)
     const bool owns = 4 * lane >= G::M && 4 * lane < G::M + G::XV && x0 >= 0 && x0 < a.w;
-    // only the strips that contain image column 0 or w-1 pay for the reflect selects
-    if (bx == 0 || (bx + 1) * G::XV + G::M >= a.w) hs_strip<V, S, true, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
-    else hs_strip<V, S, false, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold);
+    // only the strips that contain image column 0 or w-1 pay for the reflect patch, and only for their own side (block-uniform)
+    const bool sl = bx == 0, sr = (bx + 1) * G::XV + G::M >= a.w;
+#define HS_GO(XE) hs_strip<V, S, XE, LP>(a, x0, ybeg, yend, owns, lane, yring + wv * G::R * 64, xstage + wv * 64, cbuf + wv * HS_CBUF, &cold)
+    if (sl && sr) HS_GO(3);
+    else if (sl) HS_GO(1);
+    else if (sr) HS_GO(2);
+    else HS_GO(0);
+#undef HS_GO
 }
 
 template <typename V, int S, bool LP>

@@ -5,7 +5,7 @@ R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-verify --serial --no-pipeline "$@" > $OUT/log.txt 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o s -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-verify --no-upload --no-fast --serial --no-pipeline "$@" > $OUT/log.txt 2>&1
 [ -n "$KEEP_TRACE" ] || find $OUT -name "*kernel_trace.csv" -delete
 python3 - $OUT <<'P'
 import csv,glob,sys

@@ -39,7 +39,8 @@ def run_shape(log_path):
         for ln in open(log_path):
             if ln.startswith("{") and '"metric"' in ln:
                 d = json.loads(ln)
-                return int(d["config"]["pairs_per_launch_sequence"]), int(d["steps"]) + int(d["warmup"])
+                # every float-path launch sequence the run enqueued (warm-up, timed steps, the untimed gather pass, ...)
+                return int(d["config"]["pairs_per_launch_sequence"]), int(d["config"].get("float_sequences_enqueued", int(d["steps"]) + int(d["warmup"])))
     except (OSError, ValueError, KeyError):
         pass
     return None

@@ -1,18 +1,18 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on the GPU box (run via gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r03_a
+#   bash tools/refresh_profiles.sh r04_a
 # Every profiler run is wrapped in `timeout`; PMC passes are separate runs without any trace option.
 set -u
-TAG=${1:-r03_x}
+TAG=${1:-r04_x}
 R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --upload --fast > $OUT/bench.json 2> $OUT/bench.err
-B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-verify"
+python3 $R/bench.py > $OUT/bench.json 2> $OUT/bench.err
+B="python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-configs --no-verify --no-upload --no-fast"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/default -o d -- $B > $OUT/default.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/serial -o s -- $B --serial --no-pipeline > $OUT/serial.log 2>&1
-P="python3 $R/bench.py --steps 1 --warmup 1 --serial --no-pipeline --no-cpu-baseline --no-roofline --no-configs --no-verify"
+P="python3 $R/bench.py --steps 1 --warmup 1 --serial --no-pipeline --no-cpu-baseline --no-roofline --no-configs --no-verify --no-upload --no-fast"
 # (the PMC passes need the roofline leg off -- its copy probe would be counted -- so the bench line of these runs carries no roofline)
 timeout 300 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcF -- $P > $OUT/pmcF.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcW -- $P > $OUT/pmcW.log 2>&1
