@@ -580,29 +580,37 @@ def other_configs(ah, synth, args, rank, okz=None, u8_pairs=None):
     return out
 
 
-def run_single_pair_leg():
-    """configs[1] literally -- ONE 1080p pair at a time, synchronous calls like the reference demo (main.cpp:199-209) -- in a child
-    process started with GPU_MAX_HW_QUEUES=8: a single-image call keeps four launch chains in flight and wants them on queues of
-    their own, while the batched legs of the bench process are 2-13 % slower with eight queues, and the variable is read once, when
-    the HIP runtime initialises (INTEGRATION.md "Hardware queues").  Called BEFORE this process touches the GPU: two
-    processes with live queues on one device slow each other's short synchronous calls (match 0.06 -> 0.16 ms)."""
+def _run_leg(flag, env_extra):
     import subprocess
-    env = dict(os.environ, GPU_MAX_HW_QUEUES=os.environ.get("HAK_SINGLE_HW_QUEUES", "8"))
+    env = dict(os.environ, **env_extra)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--single-pair-leg"], capture_output=True, text=True, env=env, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), flag], capture_output=True, text=True, env=env, timeout=600)
     leg = None
     for ln in r.stdout.splitlines():
         if ln.startswith("{"):
             leg = json.loads(ln)
     if r.returncode != 0 or leg is None:
-        raise RuntimeError("single-pair leg failed: " + r.stdout[-500:] + r.stderr[-2000:])
+        raise RuntimeError(flag + " failed: " + r.stdout[-500:] + r.stderr[-2000:])
     return leg
 
 
-def single_pair_leg():
-    """one 1080p pair at a time through the drop-in class: two synchronous detectAndCompute calls + cuMatch per iteration, h_data pinned as
-    the C++ layer's initAkazeData hands it out (host/akaze.cpp); prints one JSON object"""
+def run_single_pair_leg():
+    """configs[1] literally -- ONE 1080p pair at a time, synchronous calls like the reference demo (main.cpp:199-209) -- in child
+    processes, BEFORE this process touches the GPU (two processes with live queues on one device slow each other's short synchronous
+    calls: match 0.06 -> 0.16 ms).  Two children, because the two call styles want different numbers of hardware queues and the variable
+    is read once, when the HIP runtime initialises (INTEGRATION.md "Hardware queues"): the three-call pattern keeps four
+    eagerly launched chains in flight and wants GPU_MAX_HW_QUEUES=8; the pair call replays a captured graph, whose queue placement is
+    best with the runtime's default of four (0.57-0.60 ms; 0.83 with eight) -- like the batched legs of the bench process itself."""
+    leg = _run_leg("--single-pair-leg", {"GPU_MAX_HW_QUEUES": os.environ.get("HAK_SINGLE_HW_QUEUES", "8")})
+    env2 = {}
+    if "HAK_PAIR_HW_QUEUES" in os.environ:
+        env2["GPU_MAX_HW_QUEUES"] = os.environ["HAK_PAIR_HW_QUEUES"]
+    leg.update(_run_leg("--pair-call-leg", env2))
+    return leg
+
+
+def _pair_setup():
     import akaze_hip as ah
     from akaze_hip import synth
     assert torch.cuda.is_available(), "needs a HIP device"
@@ -613,36 +621,49 @@ def single_pair_leg():
     d1 = torch.from_numpy(synth.to_float(a, p)).cuda()
     d2 = torch.from_numpy(synth.to_float(b, p)).cuda()
     det = ah.Akazer()
-    det.init((w, h, p), max_pts=max_pts)
+    det.init((w, h, p), max_pts=max_pts, batch=2)           # as the C++ Akazer: one context for single-image and pair calls
     r1, r2 = ah.AkazeData(), ah.AkazeData()
     ah.initAkazeData(r1, max_pts, True, True, pinned=True)
     ah.initAkazeData(r2, max_pts, True, True, pinned=True)
+    return ah, det, d1, d2, r1, r2, (w, h, p)
+
+
+def single_pair_leg():
+    """one 1080p pair at a time through the drop-in class: two synchronous detectAndCompute calls + cuMatch per iteration, h_data pinned as
+    the C++ layer's initAkazeData hands it out (host/akaze.cpp); prints one JSON object"""
+    ah, det, d1, d2, r1, r2, whp = _pair_setup()
     lat, det_ms, match_ms = [], [], []
     for i in range(45):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        det.detectAndCompute(d1.data_ptr(), r1, (w, h, p), True)
-        det.detectAndCompute(d2.data_ptr(), r2, (w, h, p), True)
+        det.detectAndCompute(d1.data_ptr(), r1, whp, True)
+        det.detectAndCompute(d2.data_ptr(), r2, whp, True)
         t1 = time.perf_counter()
         ah.cuMatch(r1, r2, det)
         t2 = time.perf_counter()
         if i >= 5:
             lat.append((t2 - t0) * 1e3); det_ms.append((t1 - t0) * 1e3); match_ms.append((t2 - t1) * 1e3)
-    # the same pair through ONE call (hak_detect_and_compute_pair: one launch sequence for both images + the match, one wait)
-    det2 = ah.Akazer()
-    det2.init((w, h, p), max_pts=max_pts, batch=2)
-    plat = []
-    for i in range(45):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        det2.detectAndComputePair(d1.data_ptr(), d2.data_ptr(), r1, r2, (w, h, p), True, True)
-        if i >= 5:
-            plat.append((time.perf_counter() - t0) * 1e3)
-    det2.close()
-    print(json.dumps({"single_pair_latency_ms": round(statistics.median(lat), 3), "pair_call_latency_ms": round(statistics.median(plat), 3),
+    print(json.dumps({"single_pair_latency_ms": round(statistics.median(lat), 3),
                       "single_pair_detect_ms": round(statistics.median(det_ms), 3), "single_pair_match_ms": round(statistics.median(match_ms), 3),
                       "single_pair_keypoints": [r1.num_pts, r2.num_pts],
                       "single_pair_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}))
+    ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
+
+
+def pair_call_leg():
+    """the same pair through ONE call (hak_detect_and_compute_pair / Akazer::detectAndComputePair: one launch sequence for both images
+    + the match, one wait); prints one JSON object"""
+    ah, det, d1, d2, r1, r2, whp = _pair_setup()
+    plat = []
+    for i in range(65):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        det.detectAndComputePair(d1.data_ptr(), d2.data_ptr(), r1, r2, whp, True, True)
+        if i >= 5:
+            plat.append((time.perf_counter() - t0) * 1e3)
+    print(json.dumps({"pair_call_latency_ms": round(statistics.median(plat), 3), "pair_call_keypoints": [r1.num_pts, r2.num_pts],
+                      "pair_call_matches": int((r1.h_data[:r1.num_pts]["match"] >= 0).sum()),
+                      "pair_call_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)")}))
     ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
 
 
@@ -679,11 +700,14 @@ def main():
     ap.add_argument("--concurrent", action="store_true",
                     help="the octaves of a context on concurrent streams in the timed region (the default for --no-pipeline)")
     ap.add_argument("--single-pair-leg", action="store_true", help="internal: run only the one-pair-at-a-time leg of `configs` and print it")
+    ap.add_argument("--pair-call-leg", action="store_true", help="internal: run only the one-pair-per-call leg of `configs` and print it")
     ap.add_argument("--launch", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 without a launcher always does)")
     args = ap.parse_args()
     if args.single_pair_leg:
         return single_pair_leg()
+    if args.pair_call_leg:
+        return pair_call_leg()
     if args.config == 2:
         args.width, args.height, args.octaves, args.upright = 3840, 2160, 5, True
         args.pairs = min(args.pairs, 32)

@@ -397,13 +397,25 @@ static bool level_tile_pays(const hak_ctx* c, const HakOct& oc, int nimg)
     return c->fuse_sf != 2 && (long)oc.w * oc.h * nimg <= HAK_LEVEL_TILE_MAX_PX;
 }
 
+// Launch-bound sequences -- a single image: octave 0 small enough for k_level_tile -- are issued in SPINE order (enqueue_detect) and
+// eagerly instead of as a replayed graph: their time is the longest dependency chain, not bytes.  Round 4 tried the same for a PAIR
+// (two to four images; HAK_SPINE_MAX_PX widens the rule): with four chains of two-image kernels in flight the kernels slow each other
+// down and the call got slower, 0.60 -> 0.635 ms (8 hardware queues) / 0.675 (4) -- a pair is bound by the GPU time of its small
+// kernels, the replayed per-octave order is the better one for it (profiles/r04_pair_timeline.txt).
+static bool spine_pays(const hak_ctx* c, int nimg)
+{
+    static const long max_px = [] { const char* e = getenv("HAK_SPINE_MAX_PX"); return e ? atol(e) : 0L; }();
+    if (max_px > 0 && c->knobs.level_tile == 1) return c->fuse_sf != 2 && (long)c->L.oct[0].w * c->L.oct[0].h * nimg <= max_px;
+    return level_tile_pays(c, c->L.oct[0], nimg);
+}
+
 static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
                           hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_points = nullptr)
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
     // Octave o+1 depends only on Lt(o, 0) (the reference decimates from sublevel 0, akaze.cpp:371-375).
-    const bool spine = c->concurrent && L.noct > 1 && level_tile_pays(c, L.oct[0], nimg);
+    const bool spine = c->concurrent && L.noct > 1 && spine_pays(c, nimg);
     const hipStream_t main_st = c->stream;
     c->sync_stream = c->stream;
     float* A = c->arena;
@@ -793,7 +805,7 @@ static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride
     // A launch-bound sequence (single images: the spine order of enqueue_detect) is issued eagerly: with ~50 launches on four
     // streams the host keeps ahead of the GPU, and the graph replay of ROCm 7.2 submits queue by queue in an order of its own
     // (measured on the C++ demo, ms per 1080p pair: eager 1.18, replay 1.31; HAK_GRAPH=2 forces the replay).
-    const bool launch_bound = c->concurrent && c->L.noct > 1 && level_tile_pays(c, c->L.oct[0], nimg);
+    const bool launch_bound = c->concurrent && c->L.noct > 1 && spine_pays(c, nimg);
     if (!c->use_graph || c->prof_on || (launch_bound && c->graph_mode != 2))
         return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
     hak_ctx::GraphKey key;
@@ -932,7 +944,7 @@ extern "C" int hak_detect_and_compute_pair(hak_ctx* c, const float* d_image1, co
     if (run_detect(c, d_image1, (long)(d_image2 - d_image1), pitch, 2, c->pair_pts, c->d_num, desc, clamp)) return 1;
     if (match) {
         ProfScope ps(c, HAK_PROF_MATCH);
-        hak_launch_match(c->sync_stream, c->pair_pts, c->pair_pts + mp, c->d_num, c->d_num + 1, 0, 0, 2 * mp, 2 * mp, 1);
+        hak_launch_match(c->sync_stream, c->pair_pts, c->pair_pts + mp, c->d_num, c->d_num + 1, 0, 0, 2 * mp, 2 * mp, 1, &c->msc);
     }
     HakPairDst dst{{d_points1, d_points2}, {host_pinned(h_points1) ? h_points1 : nullptr, host_pinned(h_points2) ? h_points2 : nullptr},
                    {max_pts1, max_pts2}};
@@ -981,7 +993,7 @@ extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num
     const long mp = c->cfg.max_pts;
     if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");   // k_match packs distance << 20 | index
     { ProfScope ps(c, HAK_PROF_MATCH);
-      hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs); }
+      hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs, &c->msc); }
     if (hipGetLastError() != hipSuccess) return fail("match launch failed");
     return 0;
 }

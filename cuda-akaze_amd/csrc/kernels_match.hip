@@ -303,16 +303,23 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
                                                        int rows_per_slice,
                                                        int4* __restrict__ knn_out_base, long knn_stride,
-                                                       int* __restrict__ ticket, uint2* __restrict__ part, int n1_pad)
+                                                       int* ticket, uint2* part, int n1_pad)
 {
+    // unsliced: grid (query blocks, pairs); sliced: grid (query blocks, slices, pairs)
     const bool sliced = ticket != nullptr;
-    const int pair = sliced ? 0 : blockIdx.y;
+    const int pair = sliced ? blockIdx.z : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
     hak_point* pts1 = pts1_base + (long)pair * stride1;
     const hak_point* __restrict__ pts2 = pts2_base + (long)pair * stride2;
-    const int jbeg = sliced ? (int)blockIdx.y * rows_per_slice : 0;          // (multiples of 32: rows keep their residue class)
-    const int jend = sliced ? min(n2, jbeg + rows_per_slice) : n2;
+    // rows_per_slice <= 0: the train count lives on the device (batched pairs): equal slices of whole 32-row tiles, cut here
+    const int rps = rows_per_slice > 0 ? rows_per_slice : (((n2 + 31) >> 5) + (int)gridDim.y - 1) / (int)gridDim.y * 32;
+    const int jbeg = sliced ? (int)blockIdx.y * rps : 0;                     // (multiples of 32: rows keep their residue class)
+    const int jend = sliced ? min(n2, jbeg + rps) : n2;
+    if (sliced) {                                                            // this pair's part of the scratch
+        ticket += (long)pair * gridDim.x;
+        part += (long)pair * gridDim.y * n1_pad;
+    }
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // dword 15 holds byte 60 only, so bytes 1..3 of its fragments are spare k positions: the first four of lane half 0 carry |b|
@@ -907,6 +914,16 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
                 k_match_finish<<<(n1_host + 255) / 256, 256, 0, st>>>(pts1, pts2, n1_host, sc->keys);
                 return;
             }
+        }
+    }
+    // few pairs with device-side counts (the pair call, batches of a handful of images): 18 of a pair's 83 blocks find queries,
+    // each walks the whole train set (71 tiles, ~40 us) while most of the chip idles -- slice the train sets as for one big pair
+    if (!valu && sc && n1_dev && npairs <= 12) {
+        const int slices = npairs <= 2 ? 8 : npairs <= 4 ? 4 : npairs <= 8 ? 3 : 2;
+        if (hak_match_scratch_reserve(sc, st, 0, (long)npairs * gx, (long)npairs * slices * gx * 128, 0, 0)) {
+            k_match_mfma<false, MM_BCH><<<dim3(gx, slices, npairs), 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2,
+                                                                                 2, 0, nullptr, 0, sc->ticket, sc->part, gx * 128);
+            return;
         }
     }
     dim3 grid(gx, npairs);

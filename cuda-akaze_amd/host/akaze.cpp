@@ -77,10 +77,10 @@ namespace akaze
 
     Akazer::Akazer() { hak_default_config(&cfg); }
 
-    Akazer::~Akazer() { hak_destroy(ctx); hak_destroy(pair_ctx); }                              // akaze.cpp:74-77
+    Akazer::~Akazer() { hak_destroy(ctx); }                              // akaze.cpp:74-77
 
-    void Akazer::setMaxPoints(int max_pts) { cfg.max_pts = max_pts; hak_destroy(ctx); ctx = nullptr; hak_destroy(pair_ctx); pair_ctx = nullptr; }
-    void Akazer::setUpright(bool upright) { cfg.upright = upright ? 1 : 0; hak_destroy(ctx); ctx = nullptr; hak_destroy(pair_ctx); pair_ctx = nullptr; }
+    void Akazer::setMaxPoints(int max_pts) { cfg.max_pts = max_pts; hak_destroy(ctx); ctx = nullptr; }
+    void Akazer::setUpright(bool upright) { cfg.upright = upright ? 1 : 0; hak_destroy(ctx); ctx = nullptr; }
 
     void Akazer::ensureContext(int w, int h)
     {
@@ -106,11 +106,11 @@ namespace akaze
         cfg.dthreshold = _dthreshold;
         cfg.diffusivity = _diffusivity;
         cfg.descriptor_pattern_size = _descriptor_pattern_size;
-        cfg.batch = 1;
+        // ONE context serves detectAndCompute (one image of it) and detectAndComputePair (both): a second context would double the
+        // streams of the process, and launch chains that share a hardware queue run one after the other
+        cfg.batch = 2;
         hak_destroy(ctx);
         ctx = nullptr;
-        hak_destroy(pair_ctx);
-        pair_ctx = nullptr;
         ensureContext(whp.x, whp.y);                  // arena allocated once for the init size ("reused", akaze.cpp:109-113)
     }
 
@@ -126,16 +126,8 @@ namespace akaze
     void Akazer::detectAndComputePair(float* image1, float* image2, AkazeData& result1, AkazeData& result2, int3 whp0, const bool desc,
                                       const bool match)
     {
-        if (!pair_ctx || pair_w != whp0.x || pair_h != whp0.y) {
-            hak_destroy(pair_ctx);
-            pair_ctx = nullptr;
-            hak_config c2 = cfg;
-            c2.batch = 2;
-            if (hak_create(&c2, whp0.x, whp0.y, &pair_ctx)) die("Akazer: hak_create (pair)");
-            pair_w = whp0.x;
-            pair_h = whp0.y;
-        }
-        if (hak_detect_and_compute_pair(pair_ctx, image1, image2, whp0.z, result1.d_data, result2.d_data, result1.max_pts, result2.max_pts,
+        ensureContext(whp0.x, whp0.y);
+        if (hak_detect_and_compute_pair(ctx, image1, image2, whp0.z, result1.d_data, result2.d_data, result1.max_pts, result2.max_pts,
                                         &result1.num_pts, &result2.num_pts, result1.h_data, result2.h_data, desc ? 1 : 0, match ? 1 : 0))
             die("detectAndComputePair");
     }

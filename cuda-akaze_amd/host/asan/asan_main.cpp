@@ -49,13 +49,13 @@ int main()
         d2.num_pts = 0;
         cuMatch(d1, d2);                                            // empty train set (D10)
         REQUIRE(d1.h_data[0].match == -1);
-        // the pair call: a second, two-image context; results as the three calls give them; the smaller capacity is the clamp
+        // the pair call on the same (two-image) context; results as the three calls give them; the smaller capacity is the clamp
         det->detectAndComputePair(img.data(), img.data(), d1, d2, whp, true, true);
-        REQUIRE(d1.num_pts == 1920 * 1080 / 4096 && d2.num_pts == d1.num_pts && d1.h_data[7].match == 7 && g_live_ctx == 2);
+        REQUIRE(d1.num_pts == 1920 * 1080 / 4096 && d2.num_pts == d1.num_pts && d1.h_data[7].match == 7 && g_live_ctx == 1);
         det->detectAndComputePair(img.data(), img.data(), d1, small, whp, true, false);
         REQUIRE(d1.num_pts == 7 && small.num_pts == 7);
-        det->detectAndComputePair(img.data(), img.data(), d1, d2, whp2, false, true);   // another size: the pair context is rebuilt
-        REQUIRE(d1.num_pts == 1280 * 720 / 4096 && g_live_ctx == 2);
+        det->detectAndComputePair(img.data(), img.data(), d1, d2, whp2, false, true);   // another size: the context is rebuilt
+        REQUIRE(d1.num_pts == 1280 * 720 / 4096 && g_live_ctx == 1);
         det->setMaxPoints(500);                                     // drops the context; the next call rebuilds it
         det->setUpright(true);
         REQUIRE(g_live_ctx == 0);

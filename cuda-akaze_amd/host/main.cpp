@@ -2,11 +2,13 @@
 // reads two binary PGMs (or synthesises a pair), uploads them, runs detectAndCompute on both images
 // `nrepeats` times and cuMatch once, and prints the same five result lines.
 //
-//   hipakaze_demo [device] [left.pgm right.pgm] [nrepeats] [--dump file] [--api-checks]
+//   hipakaze_demo [device] [left.pgm right.pgm] [nrepeats] [--dump file] [--api-checks] [--pair]
 //
 // --dump file   writes the host-side results as raw 104-byte AkazePoint records:
 //               int32 n1, n2, then n1 + n2 records of the float path (image 1 after cuMatch),
 //               then int32 f1, f2 and f1 + f2 records of the FAST path (image 1 after cuMatch).
+// --pair        the loop calls Akazer::detectAndComputePair (both images + cuMatch in ONE launch sequence, akaze.h) instead of
+//               detectAndCompute x 2 (+ cuMatch after the loop); the printed counts and the dumped records are the same
 // --api-checks  additionally drives Akazer through the call patterns of akaze.cpp:101-150 that the demo loop does not:
 //               an AkazeData smaller and larger than the default capacity, and an image size other than init()'s.
 #include "akaze.h"
@@ -73,15 +75,21 @@ int main(int argc, char** argv)
 {
     // One image per call keeps four launch chains in flight: ask the HIP runtime for more than its default of four
     // hardware queues -- before its first call, and only if the user has not chosen a value ("Hardware queues")
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    // (--pair: one launch sequence per call, replayed as a graph -- the runtime's default of four queues is the better one there)
+    {
+        bool pair = false;
+        for (int i = 1; i < argc; i++) pair |= !strcmp(argv[i], "--pair");
+        if (!pair) setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    }
     std::cout << "===== Registration by HIP-AKAZE (MI355X) =====" << std::endl;
     std::string dumpPath;
-    bool apiChecks = false;
+    bool apiChecks = false, pairCalls = false;
     {   // strip the options; what is left are the reference demo's positional arguments (main.cpp:131-135)
         int n = 1;
         for (int i = 1; i < argc; i++) {
             if (!strcmp(argv[i], "--dump") && i + 1 < argc) dumpPath = argv[++i];
             else if (!strcmp(argv[i], "--api-checks")) apiChecks = true;
+            else if (!strcmp(argv[i], "--pair")) pairCalls = true;
             else argv[n++] = argv[i];
         }
         argc = n;
@@ -133,11 +141,14 @@ int main(int argc, char** argv)
 
     float t1 = timer.read();
     for (int i = 0; i < nrepeats; i++) {
-        detector->detectAndCompute(img1, akaze_data1, whp1, true);
-        detector->detectAndCompute(img2, akaze_data2, whp2, true);
+        if (pairCalls) detector->detectAndComputePair(img1, img2, akaze_data1, akaze_data2, whp1, true, true);
+        else {
+            detector->detectAndCompute(img1, akaze_data1, whp1, true);
+            detector->detectAndCompute(img2, akaze_data2, whp2, true);
+        }
     }
     float t2 = timer.read();
-    akaze::cuMatch(akaze_data1, akaze_data2);
+    if (!pairCalls) akaze::cuMatch(akaze_data1, akaze_data2);
     float t3 = timer.read();
 
     int nmatch = 0;

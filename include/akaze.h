@@ -46,10 +46,8 @@ namespace akaze
     private:
         hak_config cfg;
         int3 whp{0, 0, 0};
-        hak_ctx* ctx = nullptr;      // owns the arena (the reference's omem), freed in the destructor
+        hak_ctx* ctx = nullptr;      // owns the arena (the reference's omem; room for the two images of a pair call), freed in the destructor
         int ctx_w = 0, ctx_h = 0;
-        hak_ctx* pair_ctx = nullptr; // two-image context of detectAndComputePair, created on first use
-        int pair_w = 0, pair_h = 0;
         void ensureContext(int w, int h);
     };
 }

@@ -59,6 +59,25 @@ def demo_run(ah, golden, tmp_path_factory):
     return r.stdout, read_dump(dump, ah)
 
 
+def test_pair_calls_through_the_cpp_layer(ah, golden, tmp_path):
+    """`hipakaze_demo --pair`: Akazer::detectAndComputePair in the loop (one launch sequence per pair incl. the match) leaves the same
+    counts and the same records in the two AkazeData as detectAndCompute x 2 + cuMatch"""
+    left, right, dump = str(tmp_path / "left.pgm"), str(tmp_path / "right.pgm"), str(tmp_path / "points.bin")
+    write_pgm(left, golden.lr_u8["left"])
+    write_pgm(right, golden.lr_u8["right"])
+    env = dict(os.environ)
+    for k in ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM"):
+        env.pop(k, None)
+    r = subprocess.run([DEMO, "0", left, right, "3", "--dump", dump, "--pair"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert _counts(r.stdout, "Number of features1:")[0] == 3634 and _counts(r.stdout, "Number of features2:")[0] == 4831
+    assert _counts(r.stdout, "Number of accepted matches:")[0] == 2468
+    a, b = read_dump(dump, ah)[0]
+    assert_points_equal(a, golden.lr["pts1"], fields=("x", "y", "octave", "response", "size", "angle", "features", "match", "distance",
+                                                       "match_x", "match_y"))
+    assert_points_equal(b, golden.lr["pts2"])
+
+
 def _counts(text, label):
     return [int(v) for v in re.findall(re.escape(label) + r"\s*(\d+)", text)]
 
