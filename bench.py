@@ -667,6 +667,69 @@ def pair_call_leg():
     ah.freeAkazeData(r1); ah.freeAkazeData(r2); det.close()
 
 
+def pmc_class_bytes(fdir, wdir, nseq):
+    """HBM bytes per launch sequence and kernel class from one FETCH_SIZE and one WRITE_SIZE pass (rocprofv3 csv): the counters are in
+    KiB; FETCH_SIZE is doubled for the classes whose loads are 16 B/lane streams (gfx950 reports half of such a read,
+    MI355X_MICROARCH.md) and taken as reported for the gather kernels (profiles/r02_gather_calib.txt); WRITE_SIZE as reported"""
+    import csv
+    import glob
+
+    def load(d, counter):
+        tot = {}
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            for r in csv.DictReader(open(path)):
+                if r["Counter_Name"] == counter:
+                    k = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0]
+                    tot[k] = tot.get(k, 0.0) + float(r["Counter_Value"]) * 1024.0
+        return tot
+    fetch, write = load(fdir, "FETCH_SIZE"), load(wdir, "WRITE_SIZE")
+    if not fetch or not write:
+        return None
+    out = {}
+    for k, names in CLASS_KERNELS.items():
+        f = sum(v for n, v in fetch.items() if any(x in n for x in names))
+        w = sum(v for n, v in write.items() if any(x in n for x in names))
+        out[k] = ((2.0 if k in ("fed", "hessian", "prologue") else 1.0) * f + w) / nseq
+    return out
+
+
+def run_pmc_legs(pairs):
+    """`roofline.traffic` measured in THIS run on THIS box: two child runs of the bench's own launch sequence under
+    `rocprofv3 --pmc` -- FETCH_SIZE, then WRITE_SIZE, separate passes, no trace option, the python interpreter itself behind `--`
+    (MI355X_MICROARCH.md) -- started before this process touches the GPU.  Returns ({class: bytes per launch sequence}, pairs per
+    sequence of the profiled run) or None (no rocprofv3, a pass failed): bench.py then falls back to the committed passes."""
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe) or os.environ.get("HAK_BENCH_PMC", "1") == "0":
+        return None
+    tmp = tempfile.mkdtemp(prefix="hak_pmc_", dir=os.environ.get("TMPDIR", "/tmp"))
+    env = dict(os.environ, TMPDIR=tmp)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    shape = None
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable,
+                   os.path.abspath(__file__), "--pmc-leg", "--pairs", str(pairs)]
+            r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None
+            for ln in r.stdout.splitlines():
+                if ln.startswith("{") and '"metric"' in ln:
+                    d = json.loads(ln)
+                    shape = (int(d["config"]["pairs_per_launch_sequence"]), int(d["config"]["float_sequences_enqueued"]))
+        if shape is None:
+            return None
+        cls = pmc_class_bytes(os.path.join(tmp, "FETCH_SIZE"), os.path.join(tmp, "WRITE_SIZE"), shape[1])
+        return None if cls is None else (cls, shape[0])
+    except (OSError, subprocess.SubprocessError, ValueError, KeyError):
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 # --------------------------------------------------------------------------- main
 def main():
     ap = argparse.ArgumentParser()
@@ -701,6 +764,8 @@ def main():
                     help="the octaves of a context on concurrent streams in the timed region (the default for --no-pipeline)")
     ap.add_argument("--single-pair-leg", action="store_true", help="internal: run only the one-pair-at-a-time leg of `configs` and print it")
     ap.add_argument("--pair-call-leg", action="store_true", help="internal: run only the one-pair-per-call leg of `configs` and print it")
+    ap.add_argument("--pmc-leg", action="store_true",
+                    help="internal: two serial launch sequences and the gather pass, nothing else (what run_pmc_legs profiles under rocprofv3 --pmc)")
     ap.add_argument("--launch", action="store_true",
                     help="go through the rank launcher even for --gpus 1 (N > 1 without a launcher always does)")
     args = ap.parse_args()
@@ -708,6 +773,9 @@ def main():
         return single_pair_leg()
     if args.pair_call_leg:
         return pair_call_leg()
+    if args.pmc_leg:
+        args.steps, args.warmup, args.serial, args.no_pipeline = 1, 1, True, True
+        args.no_cpu_baseline = args.no_roofline = args.no_configs = args.no_verify = args.no_upload = args.no_fast = True
     if args.config == 2:
         args.width, args.height, args.octaves, args.upright = 3840, 2160, 5, True
         args.pairs = min(args.pairs, 32)
@@ -727,9 +795,13 @@ def main():
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks", file=sys.stderr)
         sys.exit(2)
-    args.single_pair_result = None
-    if rank == 0 and world == 1 and not args.no_configs and not args.total_pairs and (args.width, args.height, args.octaves) == (1920, 1080, 4):
-        args.single_pair_result = run_single_pair_leg()     # before this process initialises HIP
+    args.single_pair_result, live_pmc = None, None
+    if rank == 0 and world == 1 and not args.total_pairs and (args.width, args.height, args.octaves) == (1920, 1080, 4) and not args.upright:
+        # child processes, before this process initialises HIP
+        if not args.no_configs:
+            args.single_pair_result = run_single_pair_leg()
+        if not args.no_roofline:
+            live_pmc = run_pmc_legs(args.pairs)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     torch.cuda.set_device(local_rank)
     numa_node = pin_to_gpu_numa_node(local_rank, world)
@@ -903,12 +975,18 @@ def main():
         ah.check(ah.lib.hak_op_copy_probe(2 << 30, 10, C.byref(gb)))           # 2 GiB source + 2 GiB destination, far beyond the caches
         copy_gbs = gb.value
         # PMC passes (tools/pmc_traffic.py): bytes per launch sequence of `pmc_pairs` pairs, valid only for the sources they ran on
-        pmc = {}
-        if os.path.exists(PMC_FILE) and (w, h, args.octaves) == (1920, 1080, 4):
+        pmc, pmc_src = {}, None
+        if live_pmc is not None:
+            pmc = {k: v * nim / float(2 * live_pmc[1]) for k, v in live_pmc[0].items()}
+            pmc_src = ("two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of this launch sequence in child processes of THIS run, on this box "
+                       "(bench.run_pmc_legs); durations from this run's HIP events")
+        elif os.path.exists(PMC_FILE) and (w, h, args.octaves) == (1920, 1080, 4):
             tj = json.load(open(PMC_FILE))
             for k, v in tj.get("classes", {}).items():
                 if v.get("source_sha") == class_source_hash(k):
                     pmc[k] = v["hbm_bytes_per_sequence"] * nim / float(2 * tj["pairs_per_launch_sequence"])
+            pmc_src = ("profiles/" + os.path.basename(PMC_FILE) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes on the builder's box, "
+                       "source-hash-guarded; durations are this run's)")
         algo = {"fed": tr.fed_fused_bytes, "hessian": tr.hessian_bytes, "prologue": tr.prologue_bytes,
                 "describe": tr.describe_bytes, "nms": tr.nms_bytes, "match": None}
         prof_of = {"fed": ("fed",), "hessian": ("hessian",), "prologue": ("contrast",), "describe": ("describe",), "nms": ("nms",),
@@ -936,11 +1014,9 @@ def main():
                 "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None if traffic is None else round(traffic),
-                # where `traffic` comes from: NOT a counter read in this run -- the committed rocprofv3 --pmc passes of the builder's
-                # box (tools/pmc_traffic.py), accepted only while the hash of the class's kernel sources + shared header + launch
-                # sequence + Makefile matches, rescaled to this run's images per launch sequence and divided by this run's times
-                "traffic_source": None if traffic is None else "profiles/" + os.path.basename(PMC_FILE) + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
-                                  "passes on the builder's box, source-hash-guarded; durations are this run's)",
+                # where `traffic` comes from: counter passes of this run's own child processes, or (when rocprofv3 is not available /
+                # a pass failed) the committed passes of the builder's box, accepted only while the hash of the class's sources matches
+                "traffic_source": None if traffic is None else pmc_src,
                 "traffic_GBs": None if traffic is None else round(traffic / avg_s / 1e9, 1),
                 "traffic_frac": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1), "frac_copy": round(achieved / copy_gbs, 4),

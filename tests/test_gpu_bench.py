@@ -46,6 +46,9 @@ def test_bench_contract_verified_and_roofline():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert 0.0 < r["frac"] <= 1.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert 3000 < r["copy_ceiling_GBs"] < 8000
+    # the HBM traffic of the FED family is measured inside the run: two child runs under rocprofv3 --pmc (bench.run_pmc_legs)
+    assert r["traffic"] and "THIS run" in r["traffic_source"], r["traffic_source"]
+    assert 1.0 <= r["traffic"] / r["bytes_per_launch"] <= 1.15 and 0.3 < r["traffic_frac"] <= 1.0
     assert r["fusion_gain"] > 1.0
     names = [c["class"] for c in r["classes"]]
     assert names[:4] == ["fed", "hessian", "describe", "prologue"]
