@@ -394,6 +394,9 @@ static bool level_tile_pays(const hak_ctx* c, const HakOct& oc, int nimg)
 {
     const int mode = c->knobs.level_tile;
     if (mode != 1) return mode != 0;
+    // (round 4, measured: taking the tile kernel for the latency-bound small octaves of a LARGE batch as well -- octave 3, or octaves
+    // 2-3, of 512 images -- cuts the FED launches from 46 to 26 / 18 and costs 8-17 ms per sequence: its halo work, (T + 2n)^2 / T^2
+    // of the useful work, is only worth paying where launches, not bytes or arithmetic, are the cost)
     return c->fuse_sf != 2 && (long)oc.w * oc.h * nimg <= HAK_LEVEL_TILE_MAX_PX;
 }
 

@@ -48,7 +48,7 @@ def test_bench_contract_verified_and_roofline():
     assert 3000 < r["copy_ceiling_GBs"] < 8000
     # the HBM traffic of the FED family is measured inside the run: two child runs under rocprofv3 --pmc (bench.run_pmc_legs)
     assert r["traffic"] and "THIS run" in r["traffic_source"], r["traffic_source"]
-    assert 1.0 <= r["traffic"] / r["bytes_per_launch"] <= 1.15 and 0.3 < r["traffic_frac"] <= 1.0
+    assert 1.0 <= r["traffic"] / r["bytes_per_launch"] <= 1.3 and 0.2 < r["traffic_frac"] <= 1.0     # (16-pair sequences: more halo per byte than the 256-pair headline)
     assert r["fusion_gain"] > 1.0
     names = [c["class"] for c in r["classes"]]
     assert names[:4] == ["fed", "hessian", "describe", "prologue"]
