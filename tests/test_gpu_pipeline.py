@@ -414,6 +414,41 @@ def test_match_vs_oracle(ah, okz, torch, synth, match_kernel, n1, n2):
         assert (got["match"] >= 0).sum() > 0
 
 
+@pytest.mark.parametrize("shapes", [[(37, 5), (0, 10), (300, 0), (128, 2047)],                       # <= 12 pairs: sliced, device-side counts
+                                    [(64, 4096)], [(2205, 2382), (1, 1)],
+                                    [(50 + 7 * k, 900 - 31 * k) for k in range(16)]],              # 16 pairs: the unsliced launch
+                         ids=["ragged4", "one", "two", "sixteen"])
+def test_match_batch_ragged_sets_vs_oracle(ah, okz, torch, synth, match_kernel, shapes):
+    """hak_match_batch on hand-made pairs with ragged / empty / tiny sets (n2 < 16 and n2 == 0: D10; n1 == 0): batches of at most
+    12 pairs take the sliced search with the counts on the DEVICE (the slice bounds are cut in the kernel), larger ones the plain
+    launch; repeated train descriptors put equal distances into different slices"""
+    mp = 4100
+    det = ah.Akazer()
+    det.init((320, 240, 384), max_pts=mp, batch=2 * len(shapes))
+    host = np.zeros((2 * len(shapes), mp), ah.POINT_DTYPE)
+    num = np.zeros(2 * len(shapes), np.int32)
+    rng = np.random.default_rng(3)
+    for k, (n1, n2) in enumerate(shapes):
+        base = synth.random_descriptors(max(n2, 1), 20 + k, ah.POINT_DTYPE)[:n2]
+        if n2 > 64:                                     # duplicates: ties across tiles, classes and slices
+            base[n2 // 2:] = base[rng.integers(0, n2 // 2, n2 - n2 // 2)]
+            base["x"] = np.arange(n2, dtype=np.float32)
+        q = synth.random_descriptors(n1, 40 + k, ah.POINT_DTYPE, planted_from=base if n2 else None, nplanted=min(n1, n2) // 2, maxflip=50)
+        host[2 * k, :n1], host[2 * k + 1, :n2] = q, base
+        num[2 * k], num[2 * k + 1] = n1, n2
+    d_pts = torch.from_numpy(host.view(np.uint8).reshape(-1).copy()).cuda()
+    d_num = torch.from_numpy(num).cuda()
+    for _ in range(2):                                  # twice: the scratch must be back in its initial state after a call
+        ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), len(shapes)))
+        ah.check(ah.lib.hak_sync(det.ctx))
+        got = np.frombuffer(d_pts.cpu().numpy().tobytes(), ah.POINT_DTYPE).reshape(2 * len(shapes), mp)
+        for k, (n1, n2) in enumerate(shapes):
+            want = okz.match(host[2 * k, :n1].copy(), host[2 * k + 1, :n2].copy())
+            for f in ("match", "distance", "match_x", "match_y"):
+                assert np.array_equal(got[2 * k, :n1][f], want[f]), (k, n1, n2, f)
+    det.close()
+
+
 def test_match_ties_across_tiles_and_slices(ah, okz, torch, synth, match_kernel):
     """the accept rule counts the residue classes that attain the minimum (akazed.cu:2206) and every class keeps its FIRST minimum:
     a train set made of repeated descriptors puts equal distances into different LDS tiles, different classes and -- for the big
