@@ -53,6 +53,10 @@ def check_thresholds(rep, cal):
     assert mt["fast"]["line_hit"] >= 0.42 and mt["fast"]["line_hit_control"] <= 0.12
     for path in ("float", "fast"):
         assert mt[path]["line_hit"] >= cal["matches"][path]["line_hit"]
+        # the NUMBER of match lines in the picture (overlay pixels of the seam row every line crosses once) is the oracle's:
+        # the same share of the oracle's line pixels is visible as when the oracle itself drew the lines
+        assert 0.88 <= mt[path]["seam_ratio"] <= 1.0, (path, mt[path]["seam_ratio"])
+        assert abs(mt[path]["seam_ratio"] - cal["matches"][path]["seam_ratio"]) <= 0.05
 
 
 def test_committed_report_clears_the_thresholds():

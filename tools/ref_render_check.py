@@ -21,7 +21,8 @@ What this script does with them
           oracle's keypoints (recall within 1.5 px, radius class),
         - the NMS read-cursor lag (akazed.cu:1581-1593): keypoints that exist only under the literal reading
           vs a mirrored control position,
-        - every accepted oracle match's line with the reference's matched rendering (control: perturbed end points).
+        - every accepted oracle match's line with the reference's matched rendering (control: perturbed end points), and the
+          NUMBER of lines through the overlay pixels of the seam row (every match line crosses it once).
   (c) --calibrate: the same measurement on an EMULATION (left.pgm / right.pgm rendered by this script from the oracle's own
       result, JPEG q95 4:2:0): what the figures look like when the oracle IS the program that drew the pictures.
 
@@ -282,7 +283,17 @@ def match_metrics(p1, p2, Ym, Cm, recm, h1, rng):
         ang, rr = rng.uniform(0, 2 * np.pi), rng.uniform(6, 40)
         ctl.append(line_score(Ym, Cm, recm, x0, y0, int(x1 + rr * np.cos(ang)), int(y1 + rr * np.sin(ang))))
     sc, ctl = np.array(sc), np.array(ctl)
-    return dict(oracle_matches=int(len(idx)), line_hit=round(float((sc >= 0.5).mean()), 4), line_hit_control=round(float((ctl >= 0.5).mean()), 4),
+    # how MANY lines the picture holds: every match line crosses the seam between the two stacked images exactly once, so the
+    # overlay pixels of the seam row count the matches (nearly vertical lines: one pixel each; neighbours merge).  Luma only
+    # (no bleed); the calibration gives the share of line pixels that differ visibly from the gray underneath.
+    seam = np.zeros(Ym.shape[1], bool)
+    for i in idx:
+        k = a["match"][i]
+        xs, ys = line_pixels(int(np.rint(a["x"][i])), int(np.rint(a["y"][i])), int(np.rint(b["x"][k])), int(np.rint(b["y"][k])) + h1)
+        seam[np.clip(xs[ys == h1], 0, Ym.shape[1] - 1)] = True
+    seam_ref = int((np.abs(Ym[h1] - recm[h1]) > 8).sum())
+    return dict(oracle_matches=int(len(idx)), seam_pixels_oracle_lines=int(seam.sum()), seam_pixels_picture=seam_ref,
+                seam_ratio=round(seam_ref / max(1, int(seam.sum())), 4), line_hit=round(float((sc >= 0.5).mean()), 4), line_hit_control=round(float((ctl >= 0.5).mean()), 4),
                 line_score_median=round(float(np.median(sc)), 4), line_score_median_control=round(float(np.median(ctl)), 4))
 
 
@@ -382,8 +393,10 @@ def summarize(rep, title):
                  m["ring_hit_random"], m["ring_hit_pm1_by_response_quintile"][-1], ic["n"], ic["recall_1p5px"] or 0,
                  ic["recall_1p5px_same_radius"] or 0, lg["lag_only"], lg["thin_hit_lag_only"], lg["thin_hit_mirrored_control"], lg["thin_hit_all"]))
     for name, m in rep["matches"].items():
-        print("  matches %-6s %d accepted by the oracle | line drawn in the picture: %.3f (control %.3f)"
-              % (name, m["oracle_matches"], m["line_hit"], m["line_hit_control"]))
+        print("  matches %-6s %d accepted by the oracle | line drawn in the picture: %.3f (control %.3f) | seam row: %d overlay pixels in the "
+              "picture / %d pixels of the oracle's lines = %.3f"
+              % (name, m["oracle_matches"], m["line_hit"], m["line_hit_control"], m["seam_pixels_picture"], m["seam_pixels_oracle_lines"],
+                 m["seam_ratio"]))
 
 
 def main():
