@@ -814,14 +814,17 @@ void hak_match_scratch_free(HakMatchScratch* sc)
     *sc = HakMatchScratch();
 }
 
-// slices of a big pair's train set for the matrix-core kernel: query blocks x slices ~ `want` blocks (two per CU: the kernel's
-// occupancy), every slice a whole number of 32-row tiles, none empty.  HAK_MATCH_SLICES overrides the count (tuning).
-static int mfma_slices(int gx, int n2, int* rows_per_slice)
+// slices of a big pair's train set for the matrix-core kernel: query blocks x slices ~ want_blocks, every slice a whole number of
+// 32-row tiles, none empty.  Measured at 10k x 10k (79 query blocks): the 1-NN kernel with 128-row chunks (three blocks per CU
+// resident) is fastest at 13 slices = 1 027 blocks = four per CU, perfectly balanced over the SIMDs (0.0639 ms per call; 6 slices of
+// 256-row chunks at two blocks per CU: 0.0675); the 2-NN kernel (more registers: two blocks per CU) at 6 slices = 474 blocks, all
+// resident at once.  HAK_MATCH_SLICES overrides the count (tuning).
+static int mfma_slices(int gx, int n2, int* rows_per_slice, int want_blocks)
 {
     static const int env = [] { const char* e = getenv("HAK_MATCH_SLICES"); return e ? atoi(e) : 0; }();
     const int tiles = (n2 + 31) / 32;
     if (tiles < 16) { *rows_per_slice = tiles * 32; return 1; }
-    int slices = env > 0 ? env : (512 + gx / 2) / gx;
+    int slices = env > 0 ? env : (want_blocks + gx / 2) / gx;
     if (slices > tiles / 8) slices = tiles / 8;                     // at least 8 tiles (one LDS chunk) per slice
     if (slices < 1) slices = 1;
     const int tps = (tiles + slices - 1) / slices;
@@ -841,7 +844,7 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
         // one big pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set
         if (sc && !nA_dev && npairs == 1 && gx < 384 && (long)gx * 128 >= nA_host) {
             int rps = 0;
-            const int slices = mfma_slices(gx, nB_host, &rps);
+            const int slices = mfma_slices(gx, nB_host, &rps, 512);
             if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
                 k_match_mfma<true, 256><<<dim3(gx, slices), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nullptr, nullptr, nA_host, nB_host, 0, 0,
                                                                     2, rps, out, 0, sc->ticket, sc->part, gx * 128);
@@ -896,10 +899,10 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     if (sc && !n1_dev && npairs == 1 && (long)gx * qb >= nq) {
         if (!valu && gx < 384) {
             int rps = 0;
-            const int slices = mfma_slices(gx, n2_host, &rps);
+            const int slices = mfma_slices(gx, n2_host, &rps, 1024);
             if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
-                k_match_mfma<false, 256><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, rps,
-                                                                     nullptr, 0, sc->ticket, sc->part, gx * 128);
+                k_match_mfma<false, MM_BCH><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, rps,
+                                                                        nullptr, 0, sc->ticket, sc->part, gx * 128);
                 return;
             }
         }
