@@ -37,14 +37,16 @@
 namespace {
 
 template <int S, bool LP> struct HsGeo {
-    static constexpr int PD = 2;                                    // input rows in flight ahead of the current one
+    // input rows in flight ahead of the current one.  Two everywhere but S = 3, which sits at the 168-VGPR cap of its third wave:
+    // with two rows in flight it spilled (1 dword in the interior strips, 7 in the edge strips); one row in flight frees a ring slot
+    // of both register rings (165 VGPRs, no spill) and is 2-3 % faster for the class (A/B on one box, twice: 14.77 / 14.60 ->
+    // 14.26 / 14.30 ms per 512 images).  One row in flight at S = 2 or 4 is slower (+1 %), a third row at any S was (+3 .. +9 %).
+    static constexpr int PD = S == 3 ? 1 : 2;
     static constexpr int R = 2 * S + 1 + PD;                        // ring slots = unroll factor: 2S+1 live rows + PD rows being loaded
     // strip margin: multiple of 4, >= 2S+1 (+2 for the low-pass taps of the LP variant)
     static constexpr int M = LP ? (S <= 2 ? 8 : 12) : (S == 1 ? 4 : S == 4 ? 12 : 8);
     static constexpr int XV = 256 - 2 * M;                          // columns a wave stores
-    // waves per SIMD the register allocator must make room for.  S = 3 needs ~187 VGPRs (2 waves); capping it at 168 for a
-    // third wave spills 26 dwords and measured 3 % SLOWER (A/B on one box), so S >= 3 stays at two waves
-    // (LP: the row-pass ring adds ~24 VGPRs)
+    // waves per SIMD the register allocator must make room for (LP: the row-pass ring adds ~24 VGPRs)
     static constexpr int MINW = LP ? (S <= 1 ? 3 : 2) : (S <= 3 ? 3 : 2);
 };
 
