@@ -44,6 +44,12 @@ def check_thresholds(rep, cal):
         lag = m["nms_lag"]
         assert lag["lag_only"] >= 50 and lag["thin_hit_lag_only"] >= 0.25 and lag["thin_hit_mirrored_control"] <= 0.08, name
         assert abs(m["reference_count"] - m["oracle_count"]) < abs(m["reference_count"] - lag["clean_disc_count"]), name
+        # the drawn radius is the sublevel class: radius-2 circles (sublevels 0, 1) and radius-4 circles (sublevel 3) are found with
+        # exactly that class; radius-3 circles (sublevel 2) are found as sublevel 2 OR 1 -- the two share the dilation 3, their maxima
+        # coincide, and the reference's scatter of the four sublevels into the maps is a race (akazed.cu:1364-1373) that
+        # the weaker sublevel 2 sometimes wins; the oracle (ascending order, strict '<') keeps sublevel 1.  Never the other way round.
+        rc = m["isolated_circles"]["radius_confusion"]
+        assert rc["2"][1] == 0 and rc["2"][2] == 0 and rc["4"][0] == 0 and rc["4"][1] == 0 and rc["3"][2] == 0, (name, rc)
     for name in ("fast_img1", "fast_img2"):
         m = kp[name]
         assert m["ring_hit"] >= 0.60 and m["ring_hit_pm1"] >= 0.75, name

@@ -252,7 +252,10 @@ def keypoint_metrics(pts, pts_clean, Yr, Cr, rec, ref_count, rng):
     m["isolated_circles"] = dict(n=int(len(c)), by_radius={str(r): int((c[:, 2] == r).sum()) for r in (1, 2, 3, 4, 5)},
                                  recall_1p5px=round(float((d <= 1.5).mean()), 4) if len(c) else None,
                                  recall_1p5px_same_radius=round(float(((d <= 1.5) & same).mean()), 4) if len(c) else None,
-                                 exact_pixel_and_radius=round(float(((cx[i] == c[:, 0]) & (cy[i] == c[:, 1]) & same).mean()), 4) if len(c) else None)
+                                 exact_pixel_and_radius=round(float(((cx[i] == c[:, 0]) & (cy[i] == c[:, 1]) & same).mean()), 4) if len(c) else None,
+                                 # drawn radius class -> radius classes (2, 3, 4 = sublevels {0, 1}, 2, 3) of the oracle keypoints found within 1.5 px
+                                 radius_confusion={str(r): [int(((c[:, 2] == r) & (d <= 1.5) & (rad[i] == q)).sum()) for q in (2, 3, 4)]
+                                                   for r in (2, 3, 4)} if len(c) else None)
     # NMS cursor lag: keypoints only the literal reading has, against the position mirrored at their stronger right neighbour
     keyc = set(zip(pts_clean["x"].tolist(), pts_clean["y"].tolist(), pts_clean["octave"].tolist()))
     lag = np.array([(x, y, o) not in keyc for x, y, o in zip(pts["x"].tolist(), pts["y"].tolist(), pts["octave"].tolist())])
