@@ -560,9 +560,10 @@ def other_configs(ah, synth, args, rank, okz=None, u8_pairs=None):
     out["match_10k_ms"] = round(ms, 4)
     out["match_10k_valu_floor_ms"] = round(floor_ms, 4)
     out["match_10k_frac_of_floor"] = round(floor_ms / ms, 4)
-    # the kernel is k_match_mfma since round 3: 1e8 / 1024 tiles of 32 x 32 distances x 16 v_mfma_i32_32x32x32_i8 x 32 cycles on
-    # 1024 SIMDs at 2.4 GHz (the synchronous call also carries a memset, the finish kernel and the host's launch + wait)
-    out["match_10k_mfma_floor_ms"] = round(1e8 / 1024 * 16 * 32 / (1024 * 2.4e9) * 1e3, 4)
+    # the kernel is k_match_mfma: 1e8 / 1024 tiles of 32 x 32 distances x 8 v_mfma_f32_32x32x64_f8f6f4 (fp4 operands, one descriptor
+    # bit per k) x 32 cycles on 1024 SIMDs at 2.4 GHz (rounds 2-4: 16 v_mfma_i32_32x32x32_i8 per tile, twice this); the synchronous
+    # call also carries the host's launch + wait
+    out["match_10k_mfma_floor_ms"] = round(1e8 / 1024 * 8 * 32 / (1024 * 2.4e9) * 1e3, 4)
     # 2-NN ratio test (4/5) + symmetric cross-check + device-side compaction on the same sets (two 10k x 10k searches)
     d_out = torch.zeros(n * ah.MATCH_PAIR_DTYPE.itemsize, dtype=torch.uint8, device="cuda")
     cnt = C.c_int(0)

@@ -8,7 +8,7 @@
 // Distances are over exactly the 61 descriptor bytes (D9: the reference reads
 // 3 bytes past them); n2 < 16 and n2 == 0 are handled (D10).
 //
-// Two kernels with identical results: k_match_mfma (the default, below: Hamming distances as int8 dot products on the matrix
+// Two kernels with identical results: k_match_mfma (the default, below: Hamming distances as fp4 dot products on the matrix
 // cores) and k_match (HAK_MATCH_VALU=1: v_xor / v_bcnt on the vector pipe, kept for A/B runs and as the second reader of the
 // accept rule -- the tests run both).
 //
@@ -188,78 +188,64 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
     }
 }
 
-// ---- matrix-core variant.  Hamming distances are integer dot products: |a ^ b| = sum_k a_k (1 - 2 b_k) + |b|.  The train side
-// supplies x_k = a_k, the query side y_k = 1 - 2 b_k (+1 / -1), and |b| rides along in spare positions of the padded K = 512 (four
-// int8 chunks of |b| against constants), so sixteen v_mfma_i32_32x32x32_i8 leave the exact distances of 32 train x 32 query
-// descriptors in the accumulator: 1 024 distances for 16 x 32 cycles of the matrix pipe instead of 1 024 x 32 VALU
-// lane-operations (v_bcnt_u32_b32 is a slow-rate instruction on this part: the VALU kernel k_match above already sits near what
-// the vector pipe can do with it).  To make the train side's bit -> int8 expansion ONE v_and_b32 per four k, bit t of a nibble
-// stays where it is: x_k = a_k 2^t (mask 0x01010101 << t), y_k = (1 - 2 b_k) 2^(3-t), every product is +-8 a_k and the
-// accumulator holds 8 x the distance (the |b| chunks meet the constant 8).
-//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s: dword s of descriptor j0 + r, shifted right by 4 h,
-//                      AND-ed with 0x01010101 << t, t < 4: bytes = bits 4 h + t + 8 byte of that dword
-//   B (query, cols n): the same bits of query q0 + r as +-2^(3-t); expanded ONCE per wave into 64 VGPRs
+// ---- matrix-core variant.  Hamming distances are dot products: |a ^ b| = sum_k a_k (1 - 2 b_k) + |b|.  The train side supplies
+// x_k = a_k, the query side y_k = 1 - 2 b_k (+1 / -1), both as fp4 (E2M1) operands of v_mfma_f32_32x32x64_f8f6f4 (the scale
+// arguments 0 select the unscaled form): EIGHT matrix instructions of 32 cycles leave the exact distances of 32 train x 32 query
+// descriptors (K = 512 >= 486 bits) in the accumulator -- 1 024 distances for 8 x 32 cycles of the matrix pipe instead of
+// 1 024 x 32 VALU lane-operations (v_bcnt_u32_b32 is a slow-rate instruction on this part: the VALU kernel k_match above already
+// sits near what the vector pipe can do with it).  Rounds 2-4 ran this on v_mfma_i32_32x32x32_i8 (a byte per k: sixteen
+// instructions per tile and one v_and_b32 per FOUR k); a nibble per k halves both the matrix time and the expansion:
+// 10k x 10k 0.0636 -> 0.0488 ms, the match class of the 256-pair sequence 0.51 -> 0.34 ms (same box, profiles/r04_match10k.txt).
+//   E2M1 codes: 0001 = 0.5, 0010 = 1, 0100 = 2, 1000 = the sign.  To make the train side's bit -> fp4 expansion ONE v_and_b32 per
+//   eight k, bit t < 3 of a nibble stays where it is (x_k = a_k 2^(t-1), mask 0x11111111 << t) and bit 3 comes down to bit 2 from a
+//   staged copy shifted right by 1 (x_k = 2 a_k); the query side is y_k = (1 - 2 b_k) 2^(1-t) (0.5 for bit 3): every product is
+//   +-a_k.  tools/fp4_hamming_probe.hip checks exactly this arithmetic against popcounts on the device.
+//   The accumulator STARTS at 2^23 + |b| (C operand of the tile's first instruction; every partial sum is an integer below 2^24,
+//   exact in fp32), so its bit pattern ends as 0x4B000000 + distance, which the key's << 20 reduces to distance << 20: the epilogue
+//   is one v_lshl_add_u32 (+ index base) and one v_min_u32 per element, as in the int8 version.
+//   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s < 8: dword 8 h + s of descriptor j0 + r and its copy >> 1
+//   B (query, cols n): the same dword of query q0 + r; expanded ONCE per wave into 32 VGPRs
 //   C/D: lane (n = l & 31, h) holds train rows (i & 3) + 8 (i >> 2) + 4 h, i < 16, of query n (cdna_hip_programming.md 158)
-// Any assignment of descriptor bits to k positions is fine as long as A and B agree: both come from mm_* below.  Per accumulator
-// element the epilogue is one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32 into the running minimum of
-// ITS register slot -- all rows a slot ever sees are congruent mod 16, i.e. one residue class -- so the reference's "first strict
-// minimum per class" survives as the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set
-// (or its slice); the four waves of a block share the train descriptors through LDS.
+// Any assignment of descriptor bits to k positions is fine as long as A and B agree: both come from mm_* below.  All rows a register
+// slot ever sees are congruent mod 16, i.e. one residue class -- so the reference's "first strict minimum per class" survives as
+// the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set (or its slice); the four waves of a
+// block share the train descriptors through LDS.
 //
-// Round 4: the train set travels in CHUNKS of MM_CH descriptors (rows of 144 bytes: the 16 dwords, the same shifted right by 4 for lane
-// half 1, padding -- conflict-free ds_read_b128), double-buffered: the 8-byte loads of chunk c+1 (MM_CH / 32 per thread, all in
-// flight at once; a lane fetching ITS descriptor row straight from the 104-byte records touches 32 lines per load instruction and ran
-// at a third of the matrix pipe's rate) are issued before the tiles of chunk c are multiplied and written to the other buffer after
-// them: ONE barrier and ONE exposed memory round trip per chunk.  Round 3 staged tile by tile (a barrier and a dependent load per 32
-// rows, two tiles ahead); for one big pair that loop was latency-bound -- 10k x 10k: 80 us against the 24 us of its MFMAs.
-// What the SQ counters say about the loop now (profiles/r04_match10k_sq.txt): a SIMD's vector and matrix instructions do not overlap
-// here -- SQ_VALU_MFMA_BUSY_CYCLES is exactly 32 cycles per MFMA, SQ_ACTIVE_INST_VALU 4 per vector instruction, and the two add up to
-// the kernel's duration -- so a tile costs 16 x 32 cycles of MFMA + ~100 x 4 cycles of bit expansion and epilogue.  Tried against
-// that and measured equal or worse: two independent accumulation chains per step (same time: the chain is not the limit), no
-// pre-shifted copy (one more v_lshrrev per fragment, same time), other chunk sizes and occupancies (the values below are the best).
+// Round 4: the train set travels in CHUNKS of MM_CH descriptors (rows of 144 bytes: per lane half its 8 descriptor dwords and the
+// same shifted right by 1, padding -- conflict-free ds_read_b128), double-buffered: the 8-byte loads of chunk c+1 (MM_CH / 32 per
+// thread, all in flight at once; a lane fetching ITS descriptor row straight from the 104-byte records touches 32 lines per load
+// instruction and ran at a third of the matrix pipe's rate) are issued before the tiles of chunk c are multiplied and written to
+// the other buffer after them: ONE barrier and ONE exposed memory round trip per chunk.  Round 3 staged tile by tile (a barrier and
+// a dependent load per 32 rows, two tiles ahead); for one big pair that loop was latency-bound.
+// What the SQ counters said about the int8 loop (profiles/r04_match10k_sq.txt): a SIMD's vector and matrix instructions did not
+// overlap -- SQ_VALU_MFMA_BUSY_CYCLES exactly 32 cycles per MFMA, SQ_ACTIVE_INST_VALU 4 per vector instruction, the two adding up to
+// the kernel's duration -- so what counts per tile is matrix cycles PLUS vector instructions: 16 x 32 + ~100 x 4 then, 8 x 32 +
+// ~66 x 4 now.  Tried against that on the int8 loop and measured equal or worse: two independent accumulation chains per step, no
+// pre-shifted copy (one more v_lshrrev per fragment), other chunk sizes and occupancies (the values below are the best).
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
-typedef int mm_v16i __attribute__((ext_vector_type(16)));
-#define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0)
+typedef int mm_v8i __attribute__((ext_vector_type(8)));
+typedef float mm_v16f __attribute__((ext_vector_type(16)));
+#define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0)     // cbsz = blgp = 4: fp4 operands
 #define MM_BCH 128      // train descriptors per LDS chunk of the batched (unsliced) launches; the sliced search of one big pair uses 256
-#define MM_ROW 36       // dwords per staged train row: the 16 descriptor dwords, the same 16 shifted right by 4 (lane half 1 reads
-                        // those: no shift in the tile loop, where every VALU instruction counts -- matrix and vector work of a SIMD do
-                        // not overlap here), 4 of padding (144-byte rows make the ds_read_b128 conflict-free)
-__device__ __forceinline__ unsigned mm_chunks3(unsigned p, unsigned& c3)     // p <= 488 as four int8 <= 127: three in bytes 1..3, the fourth in c3
+#define MM_ROW 36       // dwords per staged train row: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | 4 of padding]: lane half h reads its
+                        // 16 dwords at 16 h (no shift in the tile loop, where every VALU instruction counts); 144-byte rows make the
+                        // ds_read_b128 conflict-free
+// train fragment of one descriptor dword w and its copy w1 = w >> 1
+__device__ __forceinline__ mm_v8i mm_frag_a4(unsigned w, unsigned w1)
 {
-    const unsigned c0 = min(p, 127u), c1 = min(p - c0, 127u), c2 = min(p - c0 - c1, 127u);
-    c3 = p - c0 - c1 - c2;
-    return (c0 << 8) | (c1 << 16) | (c2 << 24);
-}
-// train fragment of one descriptor dword (already shifted right by 4 h): x = a 2^t
-__device__ __forceinline__ mm_v4i mm_frag_a(unsigned w)
-{
-    mm_v4i f;
-    f.x = (int)(w & 0x01010101u); f.y = (int)(w & 0x02020202u); f.z = (int)(w & 0x04040404u); f.w = (int)(w & 0x08080808u);
+    mm_v8i f = {0, 0, 0, 0, 0, 0, 0, 0};
+    f[0] = (int)(w & 0x11111111u); f[1] = (int)(w & 0x22222222u); f[2] = (int)(w & 0x44444444u); f[3] = (int)(w1 & 0x44444444u);
     return f;
 }
-// query fragment: y = (1 - 2 b) 2^(3-t) per byte = S ^ (b * (S ^ (256 - S))), S = 2^(3-t) (no carries between the bytes)
-__device__ __forceinline__ mm_v4i mm_frag_b(unsigned dword, int h)
+// query fragment: magnitude code of 2^(1-t) (0.5 for bit 3), sign = the descriptor bit
+__device__ __forceinline__ mm_v4i mm_frag_b4(unsigned q)
 {
-    const unsigned w = dword >> (4 * h);
     mm_v4i f;
-    f.x = (int)(0x08080808u ^ ((w & 0x01010101u) * 0xF0u));
-    f.y = (int)(0x04040404u ^ (((w >> 1) & 0x01010101u) * 0xF8u));
-    f.z = (int)(0x02020202u ^ (((w >> 2) & 0x01010101u) * 0xFCu));
-    f.w = (int)(0x01010101u ^ (((w >> 3) & 0x01010101u) * 0xFEu));
+    f.x = (int)(0x44444444u | ((q & 0x11111111u) << 3));
+    f.y = (int)(0x22222222u | ((q & 0x22222222u) << 2));
+    f.z = (int)(0x11111111u | ((q & 0x44444444u) << 1));
+    f.w = (int)(0x11111111u | (q & 0x88888888u));
     return f;
-}
-__device__ __forceinline__ void mm_load(const hak_point* __restrict__ pts, int j, int jend, unsigned int (&d)[16])
-{
-    if (j < jend) {
-        // features start at byte 24 of the 104-byte record: 8-byte aligned
-        const uint2* f = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts + j) + offsetof(hak_point, features));
-#pragma unroll
-        for (int i = 0; i < 8; i++) { const uint2 v = f[i]; d[2 * i] = v.x; d[2 * i + 1] = v.y; }
-        d[15] &= 0xFFu;                         // byte 60 only; bytes 61..63 are struct padding
-    } else {
-#pragma unroll
-        for (int i = 0; i < 16; i++) d[i] = 0;
-    }
 }
 
 // accept rule of gHammingMatch on a query's 16 class minima (akazed.cu:2190-2223): distances only decide (key >> 20) -- the rule
@@ -322,9 +308,6 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
     }
     const int lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // dword 15 holds byte 60 only, so bytes 1..3 of its fragments are spare k positions: the first four of lane half 0 carry |b|
-    // (train side: the constant 8 = the scale of every other product; query side: four chunks of |b|)
-    const unsigned a15x = h ? 0u : 0x08080800u, a15y = h ? 0u : 0x00000800u;
     __shared__ __attribute__((aligned(16))) unsigned int tile[2][MM_CH * MM_ROW];
     __shared__ int s_last;
     // thread t fetches dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptors j0 + (t >> 3) + 32 i, i < 8: one chunk, all eight
@@ -346,19 +329,28 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
             }
         };
         if (jbeg < jend) fetch(jbeg);                               // the first chunk travels while the query is loaded and expanded
-        mm_v4i B[16];
+        mm_v4i B[8];
+        mm_v16f cinit;
         {
-            unsigned int qd[16];
-            mm_load(pts1, q0 + r, n1, qd);
+            // the lane half's eight dwords 8 h .. 8 h + 7 of query q0 + r (features start at byte 24 of the record: 8-byte aligned)
+            unsigned int qd[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) qd[i] = 0;
+            if (q0 + r < n1) {
+                const uint2* f = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts1 + q0 + r) + offsetof(hak_point, features)) + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 4; i++) { const uint2 v = f[i]; qd[2 * i] = v.x; qd[2 * i + 1] = v.y; }
+                if (h) qd[7] &= 0xFFu;                              // byte 60 only; bytes 61..63 are struct padding
+            }
             unsigned pb = 0;
 #pragma unroll
-            for (int i = 0; i < 16; i++) pb = bcnt_acc(qd[i], pb);
+            for (int i = 0; i < 8; i++) pb = bcnt_acc(qd[i], pb);
+            pb += (unsigned)__shfl_xor((int)pb, 32);
 #pragma unroll
-            for (int s = 0; s < 16; s++) B[s] = mm_frag_b(qd[s], h);
-            unsigned c3;
-            const unsigned c012 = mm_chunks3(pb, c3);
-            // (the spare bytes of B[15] hold +2^(3-t) from the zero bits there: replaced where the train side is non-zero)
-            if (h == 0) { B[15].x = (int)(((unsigned)B[15].x & 0xFFu) | c012); B[15].y = (int)(((unsigned)B[15].y & 0xFFFF00FFu) | (c3 << 8)); }
+            for (int s = 0; s < 8; s++) B[s] = mm_frag_b4(qd[s]);
+            const float c0 = 8388608.0f + (float)pb;                // 2^23 + |b|: exact
+#pragma unroll
+            for (int i = 0; i < 16; i++) cinit[i] = c0;
         }
         unsigned best[16], sec[KNN ? 16 : 1];
 #pragma unroll
@@ -374,20 +366,22 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
                 TD[4 * c] = v.x; TD[4 * c + 1] = v.y; TD[4 * c + 2] = v.z; TD[4 * c + 3] = v.w;             \
             }                                                                                               \
         }
-        // the epilogue of one tile's accumulator: per element one v_lshl_add_u32 (8 d << 17 = d << 20, + index base) and one v_min_u32
+        // the epilogue of one tile's accumulator: per element one v_lshl_add_u32 (d << 20 + index base) and one v_min_u32
+#define MM_KEY(v, jb) ((__float_as_uint(v) << 20) + (jb))      /* 0x4B000000 + d: the << 20 leaves d << 20 */
 #define MM_EPI(ACC, J0)                                                                                     \
         {                                                                                                   \
-            const unsigned jb = (unsigned)((J0) + 4 * h);                                                   \
+            unsigned jb = (unsigned)((J0) + 4 * h);                                                         \
+            asm volatile("" : "+v"(jb));       /* one register: the key stays ONE v_lshl_add_u32 */           \
             if ((J0) + 32 <= jend) {                                                                        \
                 _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
-                    const unsigned key = ((unsigned)ACC[i] << 17) + jb;                                     \
+                    const unsigned key = MM_KEY(ACC[i], jb);                                                \
                     if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
                     best[i] = min(best[i], key);                                                            \
                 }                                                                                           \
             } else {                        /* last, partial tile: rows past jend do not exist */            \
                 _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
                     const int row = (i & 3) + 8 * (i >> 2);                                                 \
-                    const unsigned key = (int)jb + row < jend ? ((unsigned)ACC[i] << 17) + jb : 0xFFFFFFFFu; \
+                    const unsigned key = (int)jb + row < jend ? MM_KEY(ACC[i], jb) : 0xFFFFFFFFu;           \
                     if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
                     best[i] = min(best[i], key);                                                            \
                 }                                                                                           \
@@ -396,23 +390,22 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
         // one tile: 32 train descriptors j0 .. j0 + 31 from registers TD
 #define MM_TILE(TD, J0)                                                                                     \
         {                                                                                                   \
-            mm_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};                                 \
-            _Pragma("unroll") for (int s = 0; s < 15; s++)                                                  \
-                acc = MM_MFMA(mm_frag_a(TD[s]), B[s], acc);                                                 \
-            {                                                                                               \
-                mm_v4i last = mm_frag_a(TD[15]);                                                            \
-                last.x |= (int)a15x; last.y |= (int)a15y;                                                   \
-                acc = MM_MFMA(last, B[15], acc);                                                            \
+            const mm_v4i b0 = B[0];                                                                         \
+            mm_v16f acc = MM_MFMA(mm_frag_a4(TD[0], TD[8]), (mm_v8i{b0.x, b0.y, b0.z, b0.w, 0, 0, 0, 0}), cinit); \
+            _Pragma("unroll") for (int s = 1; s < 8; s++) {                                                 \
+                const mm_v4i bs = B[s];                                                                     \
+                acc = MM_MFMA(mm_frag_a4(TD[s], TD[8 + s]), (mm_v8i{bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0}), acc); \
             }                                                                                               \
             MM_EPI(acc, J0)                                                                                 \
         }
         auto stage = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < MM_CH / 32; i++) {
-                unsigned int* row = tile[buf] + ((threadIdx.x >> 3) + 32 * i) * MM_ROW + 2 * (threadIdx.x & 7);
                 const uint2 v = make_uint2(pre[i].x, pre[i].y & tmask);
+                // row = [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | pad]: lane half h reads its 16 dwords at 16 h
+                unsigned int* row = tile[buf] + ((threadIdx.x >> 3) + 32 * i) * MM_ROW + 16 * ((threadIdx.x & 7) >> 2) + 2 * (threadIdx.x & 3);
                 *reinterpret_cast<uint2*>(row) = v;
-                *reinterpret_cast<uint2*>(row + 16) = make_uint2(v.x >> 4, v.y >> 4);
+                *reinterpret_cast<uint2*>(row + 8) = make_uint2(v.x >> 1, v.y >> 1);
             }
         };
         __syncthreads();                                            // (the previous query group's chunks have been read)
@@ -433,6 +426,7 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
         }
 #undef MM_TILE
 #undef MM_EPI
+#undef MM_KEY
 #undef MM_READ
         const int qi = q0 + r;
         if constexpr (KNN) {
