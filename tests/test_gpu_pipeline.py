@@ -756,6 +756,62 @@ def test_knn2_matches_oracle(ah, okz, torch, synth, match_kernel, n1, n2, ratio,
         assert np.array_equal(h_pts[f], want_pts[f]), f
 
 
+@pytest.mark.parametrize("n2", [40, 300, 5000])
+def test_knn2_extreme_distances(ah, okz, torch, synth, match_kernel, n2):
+    """distances at both ends of the range: all-zero, all-one (61 bytes = 488 bits, D9), alternating and single-bit descriptors on
+    both sides -- the matrix-core kernel forms a distance as 2^23 + |b| + sum of signed fp4 products, so |b| = 488 with 488
+    negative products (distance 0) and |b| = 0 with 488 positive ones (distance 488) are its corner cases; max_dist 600, ratio
+    1/1 and no cross-check, so every query with d1 < d2 reports its two nearest distances unfiltered"""
+    rng = np.random.default_rng(n2)
+    p2 = synth.random_descriptors(n2, 31, ah.POINT_DTYPE)
+    pats = np.zeros((8, 61), np.uint8)
+    pats[1] = 0xFF
+    pats[2] = 0x55
+    pats[3] = 0xAA
+    pats[4, 0] = 0x01                                   # one bit at either end of the descriptor
+    pats[5, 60] = 0x80
+    pats[6] = 0xFF
+    pats[6, 30] = 0x7F                                  # all ones but one
+    pats[7, :31] = 0xFF                                 # the first lane half's dwords set, the second's clear (bar byte 31's dword)
+    where = rng.choice(n2, size=min(n2 // 2, 24), replace=False)
+    p2["features"][where] = pats[rng.integers(0, len(pats), len(where))]
+    p1 = synth.random_descriptors(64, 32, ah.POINT_DTYPE)
+    p1["features"][:32] = pats[np.arange(32) % len(pats)]
+    p1["features"][32:40] ^= 0xFF                       # complements of random descriptors: distances near 488 - 243
+    want_pts = p1.copy()
+    want = okz.match_knn2(want_pts, p2, (1, 1), False, max_dist=600)
+    d1, d2 = _upload_points(ah, torch, p1), _upload_points(ah, torch, p2)
+    d_out = torch.zeros(len(p1) * 32, dtype=torch.uint8, device="cuda")
+    h_out = np.zeros(len(p1), ah.MATCH_PAIR_DTYPE)
+    h_pts = p1.copy()
+    cnt = C.c_int(-1)
+    ah.check(ah.lib.hak_match_knn2(None, d1.data_ptr(), len(p1), d2.data_ptr(), n2, 1, 1, 0, 600,
+                                   h_pts.ctypes.data, d_out.data_ptr(), C.byref(cnt), h_out.ctypes.data))
+    assert cnt.value == len(want)
+    for f in ah.MATCH_PAIR_DTYPE.names:
+        assert np.array_equal(h_out[:cnt.value][f], want[f]), f
+    assert want["distance"].min() == 0 and want["distance"].max() > 100 and want["second"].max() > 200   # exact hits and far-away neighbours
+    # two train points only (all ones, all ones but one): the neighbours of the all-zero query are 487 and 488 bits away
+    t3 = synth.random_descriptors(2, 33, ah.POINT_DTYPE)
+    t3["features"] = pats[[1, 6]]
+    q8 = synth.random_descriptors(8, 34, ah.POINT_DTYPE)
+    q8["features"] = pats
+    w8 = q8.copy()
+    want8 = okz.match_knn2(w8, t3, (1, 1), False, max_dist=600)
+    assert want8["distance"].max() == 487 and want8["second"].max() == 488
+    dq, dt = _upload_points(ah, torch, q8), _upload_points(ah, torch, t3)
+    h8 = np.zeros(8, ah.MATCH_PAIR_DTYPE)
+    ah.check(ah.lib.hak_match_knn2(None, dq.data_ptr(), 8, dt.data_ptr(), 2, 1, 1, 0, 600, None, d_out.data_ptr(), C.byref(cnt), h8.ctypes.data))
+    assert cnt.value == len(want8)
+    for f in ah.MATCH_PAIR_DTYPE.names:
+        assert np.array_equal(h8[:cnt.value][f], want8[f]), f
+    # the 1-NN entry point on the same sets (accepts only distances < 96)
+    got = gpu_match(ah, torch, p1, p2)
+    ref = okz.match(p1.copy(), p2)
+    for f in ("match", "distance", "match_x", "match_y"):
+        assert np.array_equal(got[f], ref[f]), f
+
+
 def test_knn2_batch_on_detected_pairs(ah, okz, torch, synth, match_kernel):
     w, h = 640, 480
     p = ah.iAlignUp(w, 128)
