@@ -1,0 +1,30 @@
+"""Stand-alone device probes the kernels' design rests on (tools/probes/*.hip), built with hipcc on the GPU box and run as child
+processes."""
+import os
+import shutil
+import subprocess
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _hipcc():
+    return shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+
+
+def test_fp4_hamming_probe(tmp_path):
+    """k_match_mfma's arithmetic in isolation: Hamming distances of 32 x 32 descriptors of 488 bits as fp4 (E2M1) dot products on
+    v_mfma_f32_32x32x64_f8f6f4, accumulator started at 2^23 + |b| -- bit patterns 0x4B000000 + popcount(a ^ b) for every pair, both
+    with explicit unit scales and in the unscaled form the kernel uses (all-zero / all-one rows included)"""
+    cc = _hipcc()
+    if cc is None:
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "fp4_probe")
+    b = subprocess.run([cc, "--offload-arch=gfx950", "-O3", "-o", exe, os.path.join(ROOT, "tools", "probes", "fp4_hamming_probe.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.count("0 mismatches of 1024") == 2, r.stdout
