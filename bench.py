@@ -52,6 +52,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+MFMA_FP4_PEAK_TOPS = 10000.0     # dense FP4 / FP6 matrix peak (MI355X_MICROARCH.md: ~10 PF dense; the matcher's operand type)
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 CHECKSUM_FILE = os.path.join(ROOT, "tests", "golden", "bench_pair_checksums.json")
 NDIST = 8                  # distinct seeded pairs; the pair with global id g is drawn from seed 1 + g % NDIST on every rank
@@ -1001,6 +1002,14 @@ def main():
                    "frac_peak": None if ab is None or ms <= 0 else round(ab / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                    "frac_copy": None if ab is None or ms <= 0 else round(ab / (ms * 1e-3) / 1e9 / copy_gbs, 4),
                    "pmc_frac_peak": None if k not in pmc or ms <= 0 else round(pmc[k] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            if k == "match" and ms > 0 and len(table):
+                # the matcher alone runs on the matrix cores: 32 x 32 tiles of distances, 512 fp4 multiply-adds each (8 x
+                # v_mfma_f32_32x32x64_f8f6f4); counts of this rank's first rl_pairs pairs from the gathered table (same seeds as the leg)
+                n12 = table[:rl_pairs, 1]
+                tiles = ((n12 >> 32) + 31) // 32 * (((n12 & 0xFFFFFFFF) + 31) // 32)
+                ops = float(tiles.sum()) * 1024 * 512 * 2 * (rl_pairs / float(max(1, len(n12))))
+                row.update({"bound": "mfma", "matrix_ops": round(ops), "matrix_TOPs": round(ops / (ms * 1e-3) / 1e12, 1),
+                            "matrix_peak_TOPs": MFMA_FP4_PEAK_TOPS, "frac_matrix_peak": round(ops / (ms * 1e-3) / 1e12 / MFMA_FP4_PEAK_TOPS, 4)})
             classes.append(row)
         other_ms = sum(cls_ms[c] for c in ("lowpass", "flow", "down", "extrema"))
         fed_ms, fed_n = cls_ms["fed"], max(1, cls_n["fed"])

@@ -56,6 +56,9 @@ def test_bench_contract_verified_and_roofline():
         assert c["ms"] > 0
         if c["frac_peak"] is not None:
             assert 0.0 < c["frac_peak"] <= 1.0, c
+    mm = [c for c in r["classes"] if c["class"] == "match"][0]       # the one matrix-core class: priced against the dense fp4 peak
+    assert mm["bound"] == "mfma" and mm["matrix_peak_TOPs"] == 10000.0 and 0.0 < mm["frac_matrix_peak"] < 1.0
+    assert abs(mm["matrix_TOPs"] - mm["matrix_ops"] / (mm["ms"] * 1e-3) / 1e12) <= 0.06 * mm["matrix_TOPs"] + 0.1
 
 
 def test_bench_rccl_path_with_one_rank_weak_and_strong():
