@@ -217,16 +217,22 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 // instruction and ran at a third of the matrix pipe's rate) are issued before the tiles of chunk c are multiplied and written to
 // the other buffer after them: ONE barrier and ONE exposed memory round trip per chunk.  Round 3 staged tile by tile (a barrier and
 // a dependent load per 32 rows, two tiles ahead); for one big pair that loop was latency-bound.
-// What the SQ counters said about the int8 loop (profiles/r04_match10k_sq.txt): a SIMD's vector and matrix instructions did not
-// overlap -- SQ_VALU_MFMA_BUSY_CYCLES exactly 32 cycles per MFMA, SQ_ACTIVE_INST_VALU 4 per vector instruction, the two adding up to
-// the kernel's duration -- so what counts per tile is matrix cycles PLUS vector instructions: 16 x 32 + ~100 x 4 then, 8 x 32 +
-// ~66 x 4 now.  Tried against that on the int8 loop and measured equal or worse: two independent accumulation chains per step, no
-// pre-shifted copy (one more v_lshrrev per fragment), other chunk sizes and occupancies (the values below are the best).
+// What bounds the loop: vector-instruction ISSUE.  tools/probes/mfma_valu_overlap.hip: beside one v_mfma_f32_32x32x64_f8f6f4 (32
+// cycles, 14-15 ns per SIMD) up to 6 independent vector instructions are free, 8 cost 17-19 ns per MFMA, 12 cost 22-24, 16 cost
+// 26-28 -- with 1, 2 or 3 waves per SIMD alike; the matcher's own mix (4 v_and + 2 x (v_lshl_add_u32 + v_min_u32) per MFMA) 19.6-20.
+// The batched kernel issues ~11 vector instructions per MFMA (SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 in the tile loop, the rest staging,
+// address arithmetic and the per-query-block prologue / finish) and its SIMDs are busy issuing ~98 % of the time (SQ_ACTIVE_INST_ANY
+// of two waves): 266 ns per tile and SIMD against 8 x 14.5 = 116 ns of matrix time.  The int8 loop showed the same picture as a sum
+// (profiles/r04_match10k_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES = 32 per MFMA, SQ_ACTIVE_INST_VALU = 4 per vector instruction, adding up to
+// the kernel's duration).  So: fewer vector instructions per distance (fp4: half the expansion; the software pipeline below lets
+// the compiler fold two tiles' keys into one v_min3_u32), 256-row chunks (half the staging per tile).  Tried and measured equal or
+// worse: two independent accumulation chains per step, no pre-shifted copy (one more v_lshrrev per fragment), three or four waves
+// per SIMD with 128-row chunks.
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v8i __attribute__((ext_vector_type(8)));
 typedef float mm_v16f __attribute__((ext_vector_type(16)));
 #define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0)     // cbsz = blgp = 4: fp4 operands
-#define MM_BCH 128      // train descriptors per LDS chunk of the batched (unsliced) launches; the sliced search of one big pair uses 256
+#define MM_BCH 256      // train descriptors per LDS chunk (two 36 KB buffers per block, two blocks per CU)
 #define MM_ROW 36       // dwords per staged train row: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | 4 of padding]: lane half h reads its
                         // 16 dwords at 16 h (no shift in the tile loop, where every VALU instruction counts); 144-byte rows make the
                         // ds_read_b128 conflict-free
@@ -284,7 +290,7 @@ __device__ __forceinline__ void mm_accept(hak_point* p1, const hak_point* __rest
 // element), nearest neighbour = the smallest key of all slots (smallest index among equal distances), d2 = the smallest
 // distance of every OTHER train point; results go to knn_out[query] = {index, d1, d2, 0} instead of the point records.
 template <bool KNN, int MM_CH>
-__global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
+__global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
                                                        int rows_per_slice,
@@ -398,6 +404,30 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
             }                                                                                               \
             MM_EPI(acc, J0)                                                                                 \
         }
+        // two tiles in flight (software pipeline): the eight matrix instructions of tile k run with the key epilogue of tile k-1
+        // between them (two accumulator elements = four vector instructions per MFMA, beside the four v_and of its own fragment)
+        // and with tile k+1's ds_read_b128 already issued.  The plain loop above had every wave wait for its LDS reads, run its
+        // MFMAs, wait for the last one and then spend 32 vector instructions on the epilogue: 273 ns per tile and SIMD, although
+        // 8 vector instructions per MFMA cost 17-19 ns per MFMA when they are interleaved (tools/probes/mfma_valu_overlap.hip).
+#define MM_EPI2(PREV, JB, I)                                                                                \
+        {                                                                                                   \
+            const unsigned key = MM_KEY(PREV[I], JB);                                                       \
+            if constexpr (KNN) sec[I] = min(sec[I], max(best[I], key));                                     \
+            best[I] = min(best[I], key);                                                                    \
+        }
+#define MM_PIPE(TD, CUR, PREV, JP, EPI)                                                                     \
+        {                                                                                                   \
+            unsigned jb = (unsigned)((JP) + 4 * h);                                                         \
+            asm volatile("" : "+v"(jb));                                                                    \
+            _Pragma("unroll") for (int s = 0; s < 8; s++) {                                                 \
+                const mm_v4i bs = B[s];                                                                     \
+                const mm_v8i bf = {bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0};                                     \
+                if (s == 0) CUR = MM_MFMA(mm_frag_a4(TD[0], TD[8]), bf, cinit);                             \
+                else CUR = MM_MFMA(mm_frag_a4(TD[s], TD[8 + s]), bf, CUR);                                  \
+                if (EPI) { MM_EPI2(PREV, jb, 2 * s) MM_EPI2(PREV, jb, 2 * s + 1) }                          \
+                __builtin_amdgcn_sched_barrier(0);                                                          \
+            }                                                                                               \
+        }
         auto stage = [&](int buf) {
 #pragma unroll
             for (int i = 0; i < MM_CH / 32; i++) {
@@ -412,18 +442,39 @@ __global__ __launch_bounds__(256, (MM_CH >= 256 ? 2 : 3)) void k_match_mfma(hak_
         if (jbeg < jend) stage(0);
         __syncthreads();
         int buf = 0;
+        mm_v16f accA = cinit, accB = cinit;                         // accumulators of the even / odd tile of a pair of tiles
+        bool have_prev = false;                                     // accB holds a finished full tile whose epilogue is still due (uniform)
+        int jprev = 0;                                              // ... its first train row
         for (int j0 = jbeg; j0 < jend; j0 += MM_CH, buf ^= 1) {
             const bool more = j0 + MM_CH < jend;                    // (uniform)
             if (more) fetch(j0 + MM_CH);                            // lands while this chunk is multiplied
             const int nt = min(MM_CH / 32, (jend - j0 + 31) >> 5);  // tiles of this chunk (uniform)
-            unsigned int ta[16];
-            for (int k = 0; k < nt; k++) {
-                MM_READ(buf, k, ta)
-                MM_TILE(ta, j0 + 32 * k)
+            const int npair = min(MM_CH / 32, (jend - j0) >> 5) >> 1;   // pairs of FULL tiles (every chunk but the slice's last: all of it)
+            unsigned int ta[16], tb[16];
+            if (npair) MM_READ(buf, 0, ta)
+            for (int kk = 0; kk < npair; kk++) {
+                const int J = j0 + 64 * kk;
+                MM_READ(buf, 2 * kk + 1, tb)
+                if (have_prev) MM_PIPE(ta, accA, accB, jprev, true)
+                else MM_PIPE(ta, accA, accB, jprev, false)
+                if (kk + 1 < npair) MM_READ(buf, 2 * kk + 2, ta)
+                MM_PIPE(tb, accB, accA, J, true)
+                jprev = J + 32;
+                have_prev = true;
+            }
+            if (2 * npair < nt) {                                   // the slice's last chunk: an odd full tile and / or the partial tile
+                if (have_prev) { MM_EPI(accB, jprev) have_prev = false; }
+                for (int k = 2 * npair; k < nt; k++) {
+                    MM_READ(buf, k, ta)
+                    MM_TILE(ta, j0 + 32 * k)
+                }
             }
             if (more) stage(buf ^ 1);                               // (that buffer was last read a chunk ago, before the barrier below)
             __syncthreads();
         }
+        if (have_prev) MM_EPI(accB, jprev)
+#undef MM_PIPE
+#undef MM_EPI2
 #undef MM_TILE
 #undef MM_EPI
 #undef MM_KEY
@@ -809,10 +860,9 @@ void hak_match_scratch_free(HakMatchScratch* sc)
 }
 
 // slices of a big pair's train set for the matrix-core kernel: query blocks x slices ~ want_blocks, every slice a whole number of
-// 32-row tiles, none empty.  Measured at 10k x 10k (79 query blocks): the 1-NN kernel with 128-row chunks (three blocks per CU
-// resident) is fastest at 13 slices = 1 027 blocks = four per CU, perfectly balanced over the SIMDs (0.0639 ms per call; 6 slices of
-// 256-row chunks at two blocks per CU: 0.0675); the 2-NN kernel (more registers: two blocks per CU) at 6 slices = 474 blocks, all
-// resident at once.  HAK_MATCH_SLICES overrides the count (tuning).
+// 32-row tiles, none empty.  Two blocks per CU are resident (launch bounds, 2 x 72 KB of LDS): 512 blocks fill the chip once, and
+// 10k x 10k (79 query blocks) is fastest at 6 slices = 474 blocks for both searches (1-NN, ms per call at 4 5 6 7 8 10 13 slices:
+// 0.0541 0.0491 0.0462 0.0532 0.0504 0.0504 0.0510).  HAK_MATCH_SLICES overrides the count (tuning).
 static int mfma_slices(int gx, int n2, int* rows_per_slice, int want_blocks)
 {
     static const int env = [] { const char* e = getenv("HAK_MATCH_SLICES"); return e ? atoi(e) : 0; }();
@@ -893,7 +943,7 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     if (sc && !n1_dev && npairs == 1 && (long)gx * qb >= nq) {
         if (!valu && gx < 384) {
             int rps = 0;
-            const int slices = mfma_slices(gx, n2_host, &rps, 1024);
+            const int slices = mfma_slices(gx, n2_host, &rps, 512);
             if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
                 k_match_mfma<false, MM_BCH><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, rps,
                                                                         nullptr, 0, sc->ticket, sc->part, gx * 128);
