@@ -609,6 +609,9 @@ def run_single_pair_leg():
     if "HAK_PAIR_HW_QUEUES" in os.environ:
         env2["GPU_MAX_HW_QUEUES"] = os.environ["HAK_PAIR_HW_QUEUES"]
     leg.update(_run_leg("--pair-call-leg", env2))
+    leg["single_pair_note"] = ("one synchronous pair at a time, two ways: pair_call_latency_ms = the pair-level launch sequence (both images + the match in "
+                               "ONE call, hak_detect_and_compute_pair / Akazer::detectAndComputePair); single_pair_latency_ms = the reference demo's "
+                               "literal THREE calls (detectAndCompute x 2 + cuMatch, main.cpp:199-209), each synchronous")
     return leg
 
 
