@@ -19,7 +19,7 @@ barrier, the max-over-ranks time and the trivial result-summary gather.
                    ("pairs/s at G = 1, 2, 4, 8 on the same 512 pairs", BASELINE configs[3])
 
 Extra objects in the line:
-  "verified"      the CPU oracle runs on ALL distinct pairs of the batch (8 pairs = 16 images); every slot of the last download of
+  "verified"      the CPU oracle runs on ALL distinct pairs of the batch (16 pairs = 32 images); every slot of the last download of
                   every pipeline context, and every pair of an untimed summary pass, is digested (sha256 over the record fields)
                   and must equal the oracle's digest of its seed; same for the integer FAST leg (exit code 3 on a mismatch)
   "gather"        SURVEY 8e's verification gather: per-pair 32-byte summaries {pair_id, n1, n2, n_matches, 64-bit checksum}
@@ -55,7 +55,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s
 MFMA_FP4_PEAK_TOPS = 10000.0     # dense FP4 / FP6 matrix peak (MI355X_MICROARCH.md: ~10 PF dense; the matcher's operand type)
 PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 CHECKSUM_FILE = os.path.join(ROOT, "tests", "golden", "bench_pair_checksums.json")
-NDIST = 8                  # distinct seeded pairs; the pair with global id g is drawn from seed 1 + g % NDIST on every rank
+NDIST = 16                 # distinct seeded pairs; the pair with global id g is drawn from seed 1 + g % NDIST on every rank
 # kernel-name substrings and the sources whose hash ties a PMC pass to the kernels it measured (tools/pmc_traffic.py)
 CLASS_KERNELS = {
     "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic", "k_level_tile"),
@@ -255,6 +255,34 @@ def host_cores():
     return max(1, min(16, n))
 
 
+def host_topology():
+    """what the box has, beside the `cores` (OpenMP threads) the baseline actually used: logical CPUs, CPUs this process may run on,
+    physical cores (distinct (package, core id) pairs of /sys) and the model name"""
+    info = {"logical_cpus": os.cpu_count()}
+    try:
+        info["allowed_cpus"] = len(os.sched_getaffinity(0))
+    except AttributeError:
+        pass
+    try:
+        import glob
+        cores = set()
+        for d in glob.glob("/sys/devices/system/cpu/cpu[0-9]*/topology"):
+            cores.add((open(d + "/physical_package_id").read().strip(), open(d + "/core_id").read().strip()))
+        if cores:
+            info["physical_cores"] = len(cores)
+            info["sockets"] = len({c[0] for c in cores})
+    except OSError:
+        pass
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                info["model"] = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
+
+
 def oracle_setup():
     """the oracle for this run: the committed build, or the same sources compiled for this host when a compiler is here.
     OMP_NUM_THREADS must be set before libgomp initialises (first oracle call)."""
@@ -359,7 +387,7 @@ def cpu_baseline(okz, synth, cores, flags, u8_pairs, w, p, max_pts, first_times,
     det = statistics.median(t[0] for t in times)
     mat = statistics.median(t[1] for t in times)
     tot = statistics.median(t[0] + t[1] for t in times)
-    return {"value": round(1.0 / tot, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
+    return {"value": round(1.0 / tot, 4), "unit": "pairs/s", "cores": cores, "kind": "port", "host": host_topology(),
             "detect_ms_per_pair": round(det * 1e3, 2), "match_ms_per_pair": round(mat * 1e3, 2),
             "opencv": opencv_baseline(u8_pairs, cores),
             "sample": f"median of {len(times)} synthetic {w}-px-wide pairs (detect+describe both images, then match), "
@@ -808,8 +836,18 @@ def main():
         if not args.no_roofline:
             live_pmc = run_pmc_legs(args.pairs)
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    torch.cuda.set_device(local_rank)
-    numa_node = pin_to_gpu_numa_node(local_rank, world)
+    # HAK_BENCH_DIST_BACKEND=gloo: the REHEARSAL of a multi-rank run on a node with fewer GPUs than ranks (one MI355X): every
+    # rank computes on device local_rank % device_count, and the job's three collectives (barrier, MAX of the step time, the
+    # all-gather of the 32-byte pair summaries) run over gloo on CPU tensors.  Everything else -- sharding, seeds, per-rank
+    # launch sequences, the gathered table and rank 0's checks -- is the code an 8-GPU RCCL run executes.
+    backend = os.environ.get("HAK_BENCH_DIST_BACKEND", "nccl")
+    if backend not in ("nccl", "gloo"):
+        print(f"bench.py: HAK_BENCH_DIST_BACKEND={backend!r} (nccl or gloo)", file=sys.stderr)
+        sys.exit(2)
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend == "gloo" else local_rank
+    dist_dev = "cpu" if backend == "gloo" else "cuda"
+    torch.cuda.set_device(dev_index)
+    numa_node = pin_to_gpu_numa_node(dev_index, world)
     # HAK_BENCH_FORCE_DIST=1 exercises the RCCL code path (barrier / MAX all-reduce / summary all-gather) with one rank too
     use_dist = world > 1 or os.environ.get("HAK_BENCH_FORCE_DIST") == "1"
     if use_dist:
@@ -817,11 +855,14 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import akaze_hip as ah
     from akaze_hip import synth
-    ah.check(ah.lib.hak_set_device(local_rank))
+    ah.check(ah.lib.hak_set_device(dev_index))
 
     w, h = args.width, args.height
     p = ah.iAlignUp(w, 128)
@@ -863,7 +904,7 @@ def main():
     t0 = time.perf_counter()
     pipe.run(step_jobs * args.steps)
     fence(use_dist)
-    elapsed = max_over_ranks(time.perf_counter() - t0, "cuda", use_dist)
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist_dev, use_dist)
     # the last download of EVERY context of the timed region (checked slot by slot against the oracle below)
     timed_digests, first_slots = [], None
     for k in range(NCTX):
@@ -904,7 +945,7 @@ def main():
         tu = time.perf_counter()
         pipe.run(up_jobs(args.steps), pre=up)
         fence(use_dist)
-        el_u = max_over_ranks(time.perf_counter() - tu, "cuda", use_dist)
+        el_u = max_over_ranks(time.perf_counter() - tu, dist_dev, use_dist)
         upload_rate = (args.total_pairs if strong else world * B) * args.steps / el_u
         torch.cuda.synchronize()
         for k in range(1, NCTX):                              # back to the contexts' own streams before the torch streams go away
@@ -931,7 +972,7 @@ def main():
         tf = time.perf_counter()
         fast_run(args.steps)
         fence(use_dist)
-        fast_rate = (args.total_pairs if strong else world * B) * args.steps / max_over_ranks(time.perf_counter() - tf, "cuda", use_dist)
+        fast_rate = (args.total_pairs if strong else world * B) * args.steps / max_over_ranks(time.perf_counter() - tf, dist_dev, use_dist)
         for k in range(NCTX):
             if pipe.last_pairs[k]:
                 ck, pk = pipe.results(k)
@@ -946,9 +987,14 @@ def main():
         pipe.enqueue(0, d_imgs, c)
         pipe.download(0, c)
         ck, pk = pipe.results(0)
+        if os.environ.get("HAK_BENCH_CORRUPT_RANK") == str(rank) and c0 == 0 and ck[0] > 0:
+            # test hook (tests/test_gpu_bench.py): one descriptor bit of this rank's first pair flipped AFTER the download -- rank 0's
+            # table checks must catch it (exit code 3)
+            pk = pk.copy()
+            pk["features"][0, 0, 0] ^= 1
         local_rows.append(summarize_pairs(ck, pk, [lo + c0 + k for k in range(c)]))
         c0 += c
-    table = gather_pair_summaries(np.concatenate(local_rows) if local_rows else np.zeros((0, 4), np.int64), "cuda", use_dist)
+    table = gather_pair_summaries(np.concatenate(local_rows) if local_rows else np.zeros((0, 4), np.int64), dist_dev, use_dist)
     golden_tab = None
     if os.path.exists(CHECKSUM_FILE) and args.octaves == 4 and not args.upright:
         golden_tab = json.load(open(CHECKSUM_FILE)).get(f"{w}x{h}")
@@ -1095,7 +1141,9 @@ def main():
         total_pairs = (args.total_pairs if strong else world * B) * args.steps
         out = {
             "metric": f"pairs_per_sec_detect_describe_match_{h}p", "value": round(total_pairs / elapsed, 2),
-            "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist else 0,
+            "unit": "pairs/s", "n_gpus": world, "rccl_ranks": dist.get_world_size() if use_dist and backend == "nccl" else 0,
+            **({"rehearsal": f"HAK_BENCH_DIST_BACKEND=gloo: {world} ranks share {torch.cuda.device_count()} device(s); collectives over gloo"}
+               if backend == "gloo" and use_dist else {}),
             "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": "f32",

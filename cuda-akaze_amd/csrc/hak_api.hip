@@ -413,7 +413,7 @@ static bool spine_pays(const hak_ctx* c, int nimg)
 }
 
 static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                          hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_points = nullptr)
+                          hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_points = nullptr, int cap0 = 0, int cap1 = 0)
 {
     const hak_config& cfg = c->cfg;
     const HakLayout& L = c->L;
@@ -424,6 +424,7 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     float* A = c->arena;
     const long S = L.arena;
     HakBatch b{A, S, nimg, c->state, c->maps, L.oct[0].plane, c->bitmap, c->rowcount, c->cand, c->cand_cap, &c->knobs, c->perm, cfg.max_pts};
+    b.cap0 = cap0; b.cap1 = cap1;
     c->last_fast = false;
     c->fed_launches = 0;
     c->fed_fused_bytes = 0;
@@ -794,27 +795,28 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
 
 // enqueue one detect+describe sequence: replay the captured graph when the arguments repeat, else capture it
 static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned);
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned, int cap0, int cap1);
 // h_pinned: device-visible host destination of the records (and c->h_num of the counts) written by the sequence itself, or NULL
+// max_pts: the record stride between images and their clamp; cap0 / cap1 > 0 (two images): smaller clamps per image
 static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                      hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned = nullptr)
+                      hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned = nullptr, int cap0 = 0, int cap1 = 0)
 {
     maps_guard_begin(c);
-    return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned));
+    return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned, cap0, cap1));
 }
 static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
-                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned)
+                            hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned, int cap0, int cap1)
 {
     // A launch-bound sequence (single images: the spine order of enqueue_detect) is issued eagerly: with ~50 launches on four
     // streams the host keeps ahead of the GPU, and the graph replay of ROCm 7.2 submits queue by queue in an order of its own
     // (measured on the C++ demo, ms per 1080p pair: eager 1.18, replay 1.31; HAK_GRAPH=2 forces the replay).
     const bool launch_bound = c->concurrent && c->L.noct > 1 && spine_pays(c, nimg);
     if (!c->use_graph || c->prof_on || (launch_bound && c->graph_mode != 2))
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned, cap0, cap1);
     hak_ctx::GraphKey key;
     memset(&key, 0, sizeof(key));
     key.img = d_images; key.stride = image_stride; key.pitch = pitch; key.nimg = nimg; key.pts = d_points;
-    key.num = d_num_pts; key.desc = desc; key.max_pts = max_pts; key.conc = c->concurrent ? 1 : 0; key.st = c->stream; key.hpts = h_pinned;
+    key.num = d_num_pts; key.desc = desc; key.max_pts = max_pts; key.conc = c->concurrent ? 1 : 0; key.st = c->stream; key.hpts = h_pinned; key.cap0 = cap0; key.cap1 = cap1;
     int slot = -1, victim = 0;
     for (int i = 0; i < hak_ctx::NGRAPH; i++) {
         if (c->graph_exec[i] && memcmp(&key, &c->gkey[i], sizeof(key)) == 0) slot = i;
@@ -831,9 +833,9 @@ static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride
     if (hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
         (void)hipGetLastError();
         c->use_graph = false;                                   // e.g. legacy default stream: fall back to eager launches
-        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
+        return enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned, cap0, cap1);
     }
-    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned);
+    const int rc = enqueue_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned, cap0, cap1);
     const hipError_t e = hipStreamEndCapture(c->stream, &graph);
     if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (e != hipSuccess || !graph) return fail(std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
@@ -941,13 +943,13 @@ extern "C" int hak_detect_and_compute_pair(hak_ctx* c, const float* d_image1, co
     const long mp = c->cfg.max_pts;
     if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");
     if (!c->pair_pts) HIP_TRY(hipMalloc((void**)&c->pair_pts, sizeof(hak_point) * 2 * (size_t)mp));
-    // the clamp of the call: the smaller of the two AkazeData capacities and the context's (akaze.cpp:246, 451)
-    int clamp = max_pts1 < max_pts2 ? max_pts1 : max_pts2;
-    if (clamp > mp) clamp = (int)mp;
-    if (run_detect(c, d_image1, (long)(d_image2 - d_image1), pitch, 2, c->pair_pts, c->d_num, desc, clamp)) return 1;
+    // each image keeps its own clamp, as in the three calls (setMaxNumPoints(result.max_pts), akaze.cpp:246, 451), bounded by the
+    // context's max_pts -- the record stride of the pair buffer, which every kernel of the sequence and the matcher index with
+    const int cap0 = max_pts1 < mp ? max_pts1 : (int)mp, cap1 = max_pts2 < mp ? max_pts2 : (int)mp;
+    if (run_detect(c, d_image1, (long)(d_image2 - d_image1), pitch, 2, c->pair_pts, c->d_num, desc, (int)mp, nullptr, cap0, cap1)) return 1;
     if (match) {
         ProfScope ps(c, HAK_PROF_MATCH);
-        hak_launch_match(c->sync_stream, c->pair_pts, c->pair_pts + mp, c->d_num, c->d_num + 1, 0, 0, 2 * mp, 2 * mp, 1, &c->msc);
+        hak_launch_match(c->sync_stream, c->pair_pts, c->pair_pts + mp, c->d_num, c->d_num + 1, (int)mp, (int)mp, 2 * mp, 2 * mp, 1, &c->msc);
     }
     HakPairDst dst{{d_points1, d_points2}, {host_pinned(h_points1) ? h_points1 : nullptr, host_pinned(h_points2) ? h_points2 : nullptr},
                    {max_pts1, max_pts2}};
@@ -996,7 +998,7 @@ extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num
     const long mp = c->cfg.max_pts;
     if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");   // k_match packs distance << 20 | index
     { ProfScope ps(c, HAK_PROF_MATCH);
-      hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs, &c->msc); }
+      hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, (int)mp, (int)mp, 2 * mp, 2 * mp, npairs, &c->msc); }
     if (hipGetLastError() != hipSuccess) return fail("match launch failed");
     return 0;
 }

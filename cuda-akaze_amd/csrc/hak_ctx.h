@@ -59,7 +59,7 @@ struct hak_ctx {
     // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
     bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly
     int graph_mode = 1;             // HAK_GRAPH: 0 never, 1 replay except for launch-bound single-image sequences, 2 always
-    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; hak_point* hpts; };
+    struct GraphKey { const float* img; long stride; int pitch, nimg; hak_point* pts; int* num; int desc; int max_pts; int conc; hipStream_t st; hak_point* hpts; int cap0, cap1; };
     static constexpr int NGRAPH = 4;                    // e.g. the two images of a pair, alternating (main.cpp:201-205)
     hipGraphExec_t graph_exec[NGRAPH] = {};
     GraphKey gkey[NGRAPH] = {};

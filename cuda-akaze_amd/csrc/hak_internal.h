@@ -33,11 +33,11 @@ struct HakLayout {
 
 // Per-image device scalars.
 struct HakImgState {
-    unsigned int hmax_bits;                     // max Scharr gradient magnitude (float bits), floored at 0.03f
+    unsigned int hmax_bits;                     // max Scharr gradient magnitude over the 16-px lattice (float bits), floored at 0.03f
     int hist[HAK_NBINS];
     float kcontrast[HAK_MAX_OCTAVES];           // per octave: k0, k0*0.75, ...
     float ikc[HAK_MAX_OCTAVES];                 // 1/(k*k)
-    int ihmax;                                  // FAST path: max integer gradient magnitude (floored at 1)
+    int ihmax;                                  // FAST path: max integer gradient magnitude over the 16-px lattice (floored at 1)
     int ikcontrast[HAK_MAX_OCTAVES];            // FAST path: integer contrast factor per octave
     int ncand;                                  // entries in the image's extrema candidate list
     int total_pts;                              // NMS survivors before clamping to max_pts
@@ -69,6 +69,21 @@ struct HakTables {
 void hak_describe_plan(HakTables* t, int patsize);
 
 // ---------------------------------------------------------------- device helpers
+// hScharrContrast as the reference's kernels actually compute it (akazed.cu:827-877, 901-938 / 3245-3336; derivation:
+// DESIGN.md 2, D2 / D3):
+//   the maximum -- gFindMaxContrastU4's "reduction" compares with absolute pixels of the image's top-left tile, not with the
+//   block's other threads, and only thread 0 of each 32 x 32 block feeds atomicMax: what arrives deterministically is the maximum
+//   over the pixels x % 16 == 0 && y % 16 == 0 that grid1 = ceil((n / 2) / 16) blocks of 32 cover (an odd n with
+//   (n - 1) % 32 == 0 leaves its last column / row out);
+//   the histogram -- the guard `ix >= width && iy >= height` returns only when BOTH are outside, so the 32 x 16 blocks' threads
+//   right of and below the image count as well, zeros of the reused arena (akaze.cpp:142-149): hak_hist_extra0 entries in bin 0.
+__host__ __device__ inline int hak_lattice_cov(int n) { const int c = 32 * ((n / 2 + 15) / 16); return c < n ? c : n; }
+__host__ __device__ inline bool hak_on_lattice(int x, int y, int w, int h)
+{
+    return ((x | y) & 15) == 0 && x < hak_lattice_cov(w) && y < hak_lattice_cov(h);
+}
+__host__ __device__ inline int hak_hist_extra0(int w, int h) { return ((w + 31) / 32 * 32 - w) * h + ((h + 15) / 16 * 16 - h) * w; }
+
 // reflect-101 as the reference: left/top abs(i), right/bottom borderAdd (akazed.cu:162-170)
 __device__ __forceinline__ int hak_refl(int i, int m)
 {
@@ -259,6 +274,9 @@ struct HakBatch {
     const HakKnobs* knobs = nullptr;   // the owning context's; nullptr (stage operators): hak_knobs_from_env()
     int* perm = nullptr;          // [nimg][perm_cap] visiting order of the keypoint kernels (k_desc_perm), or nullptr: output order
     int perm_cap = 0;
+    // per-image clamps of a PAIR call (hak_detect_and_compute_pair: the two AkazeData capacities, akaze.cpp:246, 451); 0: every
+    // image is clamped at the launch's max_pts, which is always the record stride between images
+    int cap0 = 0, cap1 = 0;
 };
 
 // scale space (kernels_scalespace.hip)

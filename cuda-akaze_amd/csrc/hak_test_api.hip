@@ -81,7 +81,9 @@ extern "C" int hak_op_kcontrast(const float* smooth, int w, int h, int p, float 
     HIP_TRY(hipFree(st));
     if (kc) *kc = hs.kcontrast[0];
     if (hmax) memcpy(hmax, &hs.hmax_bits, 4);
-    if (hist) memcpy(hist, hs.hist, sizeof(hs.hist));
+    // the reference's h_hist: the w x h pixels plus what the threads beside / below the image add to bin 0 (hak_hist_extra0; the
+    // kernels carry that constant into `thresh` instead of adding it to the device histogram)
+    if (hist) { memcpy(hist, hs.hist, sizeof(hs.hist)); hist[0] += hak_hist_extra0(w, h); }
     return 0;
 }
 

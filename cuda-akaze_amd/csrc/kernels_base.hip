@@ -144,7 +144,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
             const int r = idx >> 6, c = idx & 63;
             if (x0 + c < w && y0 + r < h) {
                 const float g = scharr_mag<G::PW>(sm + (r + 1) * G::PW + c + 1);
-                tmax = fmaxf(tmax, g);
+                if (hak_on_lattice(x0 + c, y0 + r, w, h)) tmax = fmaxf(tmax, g);
                 if (go) go[(long)(y0 + r) * p + x0 + c] = g;      // kept for the histogram pass (k_grad_hist_plane)
             }
         }
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(256) void k_base_a(const float* __restrict__ img, l
     hak_lds_barrier();
     if (tid == 0) {
         const float m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
-        if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));   // D2: the intended reduction
+        if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));   // lattice maximum (akazed.cu:827-877)
     }
 }
 
@@ -213,12 +213,12 @@ __global__ __launch_bounds__(256) void k_base_b(const float* __restrict__ img, l
                                 // bins, and LDS atomics on one address serialise
 // host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay (akaze.cpp:371) and ikc = 1/(k*k)
 // (akazed.cu:2493), kept on the device.  hist_words: the image's 300 bins (global memory, or an LDS copy fetched coherently).
-__device__ __forceinline__ void hak_finish_kcontrast(HakImgState* st, const int* hist_words, int npix, float per, int noct)
+__device__ __forceinline__ void hak_finish_kcontrast(HakImgState* st, const int* hist_words, int npix, int extra0, float per, int noct)
 {
     auto hist = [&](int k) { return hist_words[k]; };
     const float hmax = __uint_as_float(st->hmax_bits);
     const float hfactor = HAK_NBINS / hmax;
-    int thresh = (int)((npix - hist(0)) * per);
+    int thresh = (int)((npix - (hist(0) + extra0)) * per);                  // akazed.cu:2468; extra0: hak_hist_extra0
     int cumuv = 0, k = 1;
     while (k < HAK_NBINS) {
         if (cumuv >= thresh) break;
@@ -283,15 +283,15 @@ __global__ __launch_bounds__(256) void k_grad_hist_plane(const float* __restrict
             for (int i = tid; i < HAK_NBINS; i += 256)
                 shist[i] = __hip_atomic_load(&state[im].hist[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __syncthreads();
-            if (tid == 0) hak_finish_kcontrast(state + im, shist, w * h, per, noct);
+            if (tid == 0) hak_finish_kcontrast(state + im, shist, w * h, hak_hist_extra0(w, h), per, noct);
         }
     }
 }
 
-__global__ void k_kcontrast2(HakImgState* state, int npix, float per, int noct)
+__global__ void k_kcontrast2(HakImgState* state, int npix, int extra0, float per, int noct)
 {
     if (threadIdx.x != 0) return;
-    hak_finish_kcontrast(state + blockIdx.x, state[blockIdx.x].hist, npix, per, noct);
+    hak_finish_kcontrast(state + blockIdx.x, state[blockIdx.x].hist, npix, extra0, per, noct);
 }
 
 // img -> Lt(0,0) and the per-image contrast factors.  Returns false when R is not supported here.
@@ -329,6 +329,6 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     } else {
         k_base_b<<<grid, 256, 0, st>>>(img, img_stride, sp, w, h, t, state, tpb, ntx, nby, nimg);
     }
-    k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
     return true;
 }

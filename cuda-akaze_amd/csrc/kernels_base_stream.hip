@@ -113,7 +113,7 @@ struct BsmState {
 template <typename V, int R, int U, bool XE>
 __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT,
                                          V* __restrict__ GR, const int sp, const int p, const int xl, const int x0, const int h,
-                                         const int ybeg, const int yend, const bool owns, const bool edge, const int c0, const int c1,
+                                         const int ybeg, const int yend, const bool owns, const bool lat, const int hcov, const bool edge, const int c0, const int c1,
                                          const int c2, const int c3, const BsmTaps<V>& tp, const BsmOut& O)
 {
     using V4 = typename BsT<V>::V4;
@@ -192,7 +192,8 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
         g.w = bsm_mag(su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR);
         const bool inr = b >= ybeg && b < yend;
         hak_buf_store_nt(O.r, O.gr + (inr ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
-        if (inr && owns) S.tmax = bsm_max(S.tmax, bsm_max(bsm_max(g.x, g.y), bsm_max(g.z, g.w)));
+        // the reference's maximum runs over the 16-px lattice only (hak_on_lattice): x0 % 4 == 0, so only g.x can be on it
+        if (inr && lat && (b & 15) == 0 && b < hcov) S.tmax = bsm_max(S.tmax, g.x);
     }
 }
 
@@ -216,6 +217,9 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
     }
     const int t0 = ybeg - RR;
     const int tend = yend - 1 + RR;
+    // this lane's first pixel is a lattice column the reference's maximum kernel covers (rows: tested per row, b < hcov below)
+    const bool lat = owns && (x0 & 15) == 0 && x0 < hak_lattice_cov(w);
+    const int hcov = hak_lattice_cov(h);
     BsmState<V> S;
     const V z = 0;
     const V4 z4 = mk4(z, z, z, z);
@@ -227,15 +231,15 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
 #pragma unroll
     for (int i = 0; i < BS_PD; i++) S.Lq[i] = bsm_load<V, XE>(s, hak_refl(min(t0 + i, h + 3), h), sp, xl, edge, c0, c1, c2, c3);
     for (int tb = t0; tb <= tend; tb += BS_RING) {
-        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
     }
     return S.tmax;
 }
@@ -264,7 +268,7 @@ __global__ __launch_bounds__(256) void k_base_stream(const typename BsT<V>::In* 
     for (int off = 32; off > 0; off >>= 1) m = bsm_max(m, __shfl_xor(m, off));
     if (lane == 0) {
         if constexpr (std::is_same<V, float>::value) {
-            if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // D2: the intended reduction
+            if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // lattice maximum (akazed.cu:827-877)
         } else {
             if (m > 1) atomicMax(&state[im].ihmax, m);
         }

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void k_nms_cand(const unsigned long long* __re
 }
 
 // exclusive scan of the per-row survivor counts (one block per image)
-__global__ __launch_bounds__(256) void k_row_scan(int* rowcount, int h, HakImgState* state, int max_pts, int* num_out)
+__global__ __launch_bounds__(256) void k_row_scan(int* rowcount, int h, HakImgState* state, int max_pts, int cap0, int cap1, int* num_out)
 {
     __shared__ int part[256];
     int* rc = rowcount + (long)blockIdx.x * h;
@@ -155,7 +155,9 @@ __global__ __launch_bounds__(256) void k_row_scan(int* rowcount, int h, HakImgSt
         int run = 0;
         for (int i = 0; i < 256; i++) { int t = part[i]; part[i] = run; run += t; }
         state[blockIdx.x].total_pts = run;
-        int n = run < max_pts ? run : max_pts;
+        // the clamp of this image: the call's max_pts, or the image's own capacity in a pair call (never above max_pts)
+        const int cap = cap0 > 0 ? (blockIdx.x == 0 ? cap0 : cap1) : max_pts;
+        int n = run < cap ? run : cap;
         state[blockIdx.x].num_pts = n;
         if (num_out) num_out[blockIdx.x] = n;
     }
@@ -192,7 +194,7 @@ __global__ __launch_bounds__(256) void k_emit(const float* __restrict__ base, lo
         while (word) {
             int bit = __ffsll((long long)word) - 1;
             word &= word - 1;
-            if (idx < max_pts) {
+            if (idx < max_pts) {                        // (a pair call's smaller per-image clamp: the surplus records are never counted)
                 int x = (w0 + lane) * 64 + bit;
                 unsigned long long k = map[(long)y * p0 + x];
                 int layer = key_layer(k);
@@ -328,7 +330,7 @@ void hak_launch_nms_emit(hipStream_t st, const HakBatch& b, const HakLayout& L, 
     dim3 g1(b.nimg >= 8 ? 128 : 256, b.nimg);
     k_nms_cand<<<g1, 256, 0, st>>>(b.maps, b.map_stride, b.cand, b.cand_cap, b.state, tab, psz, w, h, p,
                                    b.bitmap, words, b.rowcount);
-    k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, num_out);
+    k_row_scan<<<b.nimg, 256, 0, st>>>(b.rowcount, h, b.state, max_pts, b.nimg == 2 ? b.cap0 : 0, b.cap1, num_out);
     dim3 g3((h + 3) / 4, 1, b.nimg);
     k_emit<<<g3, 256, 0, st>>>(b.base, b.stride, b.maps, b.map_stride, L, tab, b.bitmap, words, b.rowcount, points, max_pts, fast);
     if (!fast && refine)                                            // (the FAST path refines on its int planes: k_orient<int>)

@@ -137,6 +137,7 @@ __global__ __launch_bounds__(256) void kf_grad_max(const int* __restrict__ smoot
     int m = 0;
     if (x < w)
         for (int y = y0; y < blockIdx.y * FT_Y + FT_Y && y < h; y += 4) {
+            if (!hak_on_lattice(x, y, w, h)) continue;                                           // akazed.cu:3245-3296
             int dx, dy;
             fscharr(s, x, y, w, h, p, dx, dy);
             m = max(m, fgrad(dx, dy));
@@ -164,11 +165,11 @@ __global__ __launch_bounds__(256) void kf_grad_hist(const int* __restrict__ smoo
     for (int i = threadIdx.x; i < HAK_NBINS; i += 256)
         if (shist[i]) atomicAdd(&state[blockIdx.z].hist[i], shist[i]);
 }
-__global__ void kf_kcontrast(HakImgState* state, int npix, float per, int noct)
+__global__ void kf_kcontrast(HakImgState* state, int npix, int extra0, float per, int noct)
 {
     HakImgState* st = state + blockIdx.x;
     if (threadIdx.x != 0) return;
-    int thresh = (int)((npix - st->hist[0]) * per);
+    int thresh = (int)((npix - (st->hist[0] + extra0)) * per);                                  // akazed.cu:4146, 3305
     int cumuv = 0, k = 1;
     while (k < HAK_NBINS) {
         if (cumuv >= thresh) break;
@@ -188,7 +189,7 @@ void hakf_launch_contrast(hipStream_t st, const int* smooth, long stride, int w,
     dim3 grid((w + FT_X - 1) / FT_X, (h + FT_Y - 1) / FT_Y, nimg);
     kf_grad_max<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
     kf_grad_hist<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
-    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
 }
 // ---- fused octave-0 prologue of the FAST path (akaze.cpp:589-612): one pass over the uint8 image gives Lt(0,0) = the base
 // Gaussian, the maximum Scharr magnitude of the sigma=1 image, and that magnitude as a plane for the histogram pass.  The
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(256) void kf_base(const unsigned char* __restrict__
             const int dy = 10 * (q[PW] - q[-PW]) + 3 * (q[PW - 1] + q[PW + 1] - q[-PW - 1] - q[-PW + 1]);
             const int g = fgrad(dx, dy);
             go[(long)y * p + x] = g;
-            m = max(m, g);
+            if (hak_on_lattice(x, y, w, h)) m = max(m, g);                                        // akazed.cu:3245-3296
         }
     }
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off));
@@ -318,7 +319,7 @@ bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_s
     int rpb = 8;
     while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < 2048) rpb >>= 1;
     kf_grad_hist_plane<<<dim3((h + rpb - 1) / rpb, nimg), 256, 0, st>>>(grad_scratch, stride, w, h, p, state, rpb);
-    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
     return true;
 }
 

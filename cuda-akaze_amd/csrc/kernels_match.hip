@@ -512,7 +512,14 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
             // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
-            // s_waitcnt orders them in front of the ticket)
+            // s_waitcnt orders them in front of the ticket.
+            // HARDWARE ASSUMPTION, not the HIP memory model: a workgroup-scope fence does not formally synchronise with another
+            // workgroup, so the finisher's reads of `part` have no happens-before edge on paper.  What orders them on gfx950: an
+            // agent-scope atomic store is issued sc1 (write-through to the device coherence point), __syncthreads() waits for
+            // vmcnt(0) -- the stores have been acknowledged there -- before thread 0's ticket RMW (performed at the same
+            // coherence point) is issued, and the finisher's agent-scope atomic loads bypass its own L1 / non-coherent L2 lines.
+            // tests/test_gpu_pipeline.py::test_match_sliced_handoff_stress repeats 10k x 10k and the sliced pair path against
+            // the VALU kernel to catch a compiler or cache-policy change that breaks this.)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
             if (threadIdx.x == 0) {
@@ -939,6 +946,10 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     int gx = n1_dev ? (valu ? (two ? 320 : 640) : 83) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
+    // with device-side counts n1_host carries the CAPACITY of a query set (the context's max_pts; 0: unknown).  The sliced path
+    // below gives every 128-query block its own ticket and partial-result rows, so its grid must cover the capacity -- the plain
+    // kernel's blocks loop over the queries and need no such bound.
+    const int cap_blocks = n1_dev && n1_host > 0 ? (n1_host + 127) / 128 : 0;
     // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well
     if (sc && !n1_dev && npairs == 1 && (long)gx * qb >= nq) {
         if (!valu && gx < 384) {
@@ -965,7 +976,8 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
     }
     // few pairs with device-side counts (the pair call, batches of a handful of images): 18 of a pair's 83 blocks find queries,
     // each walks the whole train set (71 tiles, ~40 us) while most of the chip idles -- slice the train sets as for one big pair
-    if (!valu && sc && n1_dev && npairs <= 12) {
+    if (!valu && sc && n1_dev && npairs <= 12 && cap_blocks > 0 && cap_blocks <= 4096) {
+        if (cap_blocks > gx) gx = cap_blocks | 3;                   // (odd, as 83: not a multiple of the eight XCDs)
         const int slices = npairs <= 2 ? 8 : npairs <= 4 ? 4 : npairs <= 8 ? 3 : 2;
         if (hak_match_scratch_reserve(sc, st, 0, (long)npairs * gx, (long)npairs * slices * gx * 128, 0, 0)) {
             k_match_mfma<false, MM_BCH><<<dim3(gx, slices, npairs), 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2,

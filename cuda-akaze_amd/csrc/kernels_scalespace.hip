@@ -165,7 +165,7 @@ void hak_launch_reset_state(hipStream_t st, HakImgState* state, int nimg)
     k_reset_state<<<nimg, 256, 0, st>>>(state);
 }
 
-// pass 1: maximum gradient magnitude (the reference's intended reduction, D2)
+// pass 1: maximum gradient magnitude over the 16-px lattice (what gFindMaxContrastU4 delivers, hak_internal.h)
 __global__ __launch_bounds__(256) void k_grad_max(const float* __restrict__ smooth, long stride, int w, int h, int p,
                                                   HakImgState* state)
 {
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void k_grad_max(const float* __restrict__ smoo
     float m = 0.f;
     if (x < w)
         for (int y = y0; y < blockIdx.y * TILE_Y + TILE_Y && y < h; y += 4) {
+            if (!hak_on_lattice(x, y, w, h)) continue;
             float dx, dy;
             scharr_dxdy(s, x, y, w, h, p, dx, dy);
             m = fmaxf(m, sqrtf(dx * dx + dy * dy));
@@ -212,13 +213,13 @@ __global__ __launch_bounds__(256) void k_grad_hist(const float* __restrict__ smo
 
 // host half of hScharrContrast (akazed.cu:2467-2481) + the per-octave 0.75 decay
 // (akaze.cpp:371) and ikc = 1/(k*k) (akazed.cu:2493), kept on the device.
-__global__ void k_kcontrast(HakImgState* state, int npix, float per, int noct)
+__global__ void k_kcontrast(HakImgState* state, int npix, int extra0, float per, int noct)
 {
     HakImgState* st = state + blockIdx.x;
     if (threadIdx.x != 0) return;
     const float hmax = __uint_as_float(st->hmax_bits);
     const float hfactor = HAK_NBINS / hmax;
-    int thresh = (int)((npix - st->hist[0]) * per);
+    int thresh = (int)((npix - (st->hist[0] + extra0)) * per);
     int cumuv = 0, k = 1;
     while (k < HAK_NBINS) {
         if (cumuv >= thresh) break;
@@ -239,7 +240,7 @@ void hak_launch_contrast(hipStream_t st, const float* smooth, long stride, int w
     dim3 grid((w + TILE_X - 1) / TILE_X, (h + TILE_Y - 1) / TILE_Y, nimg);
     k_grad_max<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
     k_grad_hist<<<grid, 256, 0, st>>>(smooth, stride, w, h, p, state);
-    k_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, per, noct);
+    k_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
 }
 
 // --------------------------------------------------------------------- flow

@@ -132,7 +132,8 @@ int hak_fast_detect_and_compute_batch(hak_ctx* ctx, const unsigned char* d_image
  * 1080p pair: 0.94 ms through the three calls).  The context must have been created with batch >= 2.  d_points1 / d_points2
  * (device, max_pts1 / max_pts2 records), h_points1 / h_points2 (host or NULL; pinned host arrays are written by the launch
  * sequence itself) and the counts are filled exactly as two hak_detect_and_compute calls followed by hak_match(ctx, 1, 2) would;
- * the clamp of the call is min(max_pts1, max_pts2, the context's max_pts).  match = 0 skips the matcher. */
+ * each image keeps its own clamp min(max_pts_i, the context's max_pts) (setMaxNumPoints(result.max_pts), akaze.cpp:246, 451), and
+ * the matcher sees the clamped sets.  match = 0 skips the matcher. */
 int hak_detect_and_compute_pair(hak_ctx* ctx, const float* d_image1, const float* d_image2, int pitch,
                                 hak_point* d_points1, hak_point* d_points2, int max_pts1, int max_pts2,
                                 int* num_pts1, int* num_pts2, hak_point* h_points1, hak_point* h_points2, int desc, int match);

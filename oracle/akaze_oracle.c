@@ -13,8 +13,13 @@
  *
  * Deterministic choices where the reference is racy or undefined
  * (SURVEY.md 2.3):
- *   D2  hmax = max(0.03f, true maximum of grad over w x h)
- *   D3  histogram counts exactly the w x h valid pixels
+ *   D2  hmax = max(0.03f, maximum of grad over the 16-px LATTICE x % 16 == 0 && y % 16 == 0): the deterministic core of
+ *       gFindMaxContrastU4 (akazed.cu:827-877), followed literally since round 5 -- see okz_kcontrast.  The kernel's racy
+ *       remainder (block-local maxima swapped against absolute pixels of the image's top-left tile) can only raise hmax, and
+ *       by no more than the maximum of the top-left 32 x 32 region; the oracle takes none of it.
+ *   D3  the histogram guard `ix >= width && iy >= height` (akazed.cu:909) lets the threads beyond the right and bottom edge
+ *       count too; in the steady state of a reused Akazer (arena zeroed at the end of every call, akaze.cpp:142-149) they
+ *       read zeros: (ceil32(w) - w) * h + (ceil16(h) - h) * w extra entries in bin 0.  Followed since round 5.
  *   D4  clean reflect-101 separable Gaussian (no partial-block defect)
  *   D5  sublevels scatter into the maps in ascending order, strict '<'
  *   D6  keypoints are emitted in raster order of the full-resolution map
@@ -69,7 +74,13 @@ typedef struct OkzParams {
 /* Alternative READINGS of the reference, selectable for tools/ref_render_check.py only (it scores each reading against the
  * keypoint circles the reference's own CUDA run drew into data/akaze_show*.jpg).  0 = the reading every test, golden and
  * the HIP library follow.  bit 0: gNmsRNaive's read cursor also advances at the skipped centre (a "clean disc": what the
- * kernel would do if `new_idx++` stood in front of the `continue`, akazed.cu:1581-1593). */
+ * kernel would do if `new_idx++` stood in front of the `continue`, akazed.cu:1581-1593).  bit 1: hmax is the TRUE maximum of
+ * the gradient over w x h (what gFindMaxContrastU4 was meant to compute; the reading of rounds 1-4).  bit 2: the histogram
+ * counts exactly the w x h valid pixels (the guard of akazed.cu:909 read as `||`; rounds 1-4).  bits 3-5 exist for the power
+ * table of the statistical pin only (deliberately WRONG readings whose visibility in the reference's pictures is measured):
+ * bit 3: k + 1 histogram bins; bit 4: in the scatter of one octave's sublevels into the maps the LAST writer wins whatever the
+ * responses (the extreme outcome of the unsynchronised compare-then-write of akazed.cu:1368-1373, D5); bit 5: main orientation
+ * + 5 degrees (float path). */
 int okz_reading_variant = 0;
 void okz_set_reading_variant(int v) { okz_reading_variant = v; }
 
@@ -231,13 +242,40 @@ void okz_scharr_grad(const float* src, float* grad, int w, int h, int p)
         }
 }
 
-/* akazed.cu:2410-2484 hScharrContrast host half + 901-938 histogram, with the
- * D2/D3 choices.  hist (300 ints) and hmax are optional outputs. */
+/* akazed.cu:2410-2484 hScharrContrast host half + 827-877 gFindMaxContrastU4 + 901-938 gConstrastHistShared.
+ * hist (300 ints) and hmax are optional outputs.
+ *
+ * hmax (D2).  gFindMaxContrastU4 runs 16 x 16 threads per 32 x 32 pixel block (grid1 :2435).  Thread (tix, tiy) swaps the
+ * largest of its four pixels (ix0 + {0,16}, iy0 + {0,16}) into x0y0 (:842-857, in place).  The "reduction" (:860-873) then
+ * sorts x0y0 against nidx = (nid / 16) * pitch + nid % 16 -- an ABSOLUTE pixel of the image's top-left 16 x 16 tile, not
+ * another thread's value -- and only thread 0 of each block feeds atomicMax (:874-877).  Thread 0's four pixels are
+ * (32 bx + {0,16}, 32 by + {0,16}): over all blocks, exactly the pixels with x % 16 == 0 && y % 16 == 0 inside the image.
+ * No other thread ever writes them (every thread's four pixels are its own; the tile pixels it writes have nid >= 1, and
+ * block (0,0)'s thread 0 owns pixel 0), so the value block b contributes is at least the maximum of its lattice pixels, and
+ * exactly that unless one of the eight tile pixels nid = 128, 64, .., 1 holds something larger at the moment thread 0 reads
+ * it.  Those pixels only ever receive the smaller side of a swap from blocks other than (0,0), and from block (0,0) values
+ * of the image's top-left 32 x 32 region: the racy excess is bounded by max(grad[0..31][0..31]) and vanishes whenever that
+ * is below the lattice maximum.  The oracle takes the deterministic core.
+ *
+ * histogram (D3).  gConstrastHistShared (32 x 16 threads, grid2 :2454) returns only when BOTH ix >= width and iy >= height
+ * (:909), so columns [w, ceil32(w)) of rows < h and rows [h, ceil16(h)) of columns < w are counted as well.  grad is the
+ * octave's `temp` plane 0 (akaze.cpp:319, 326): the columns are pitch padding nobody writes, the rows are the head of temp
+ * plane 1 -- all zero once a reused Akazer has finished one call (cudaMemset(omem, 0, ..), akaze.cpp:142-149; the very
+ * first call, or a call with another image size, reads a fresh cudaMalloc).  They land in bin 0 and lower `thresh` (:2468).
+ * With a caller pitch below ceil32(w) -- main.cpp:174 aligns to 128 -- (ceil32(w) - pitch) * (h - 1) of the column reads
+ * fall on real pixels of the swap-permuted plane instead; their values depend on the race above, the oracle keeps zeros.
+ * The swaps leave the multiset of gradient values unchanged when they do not collide, so the histogram itself is taken over
+ * the un-permuted plane. */
 float okz_kcontrast(const float* grad, int w, int h, int p, float per, float* hmax_out, int* hist_out)
 {
     float hmax = 0.03f;                                                 /* :2413 */
-    for (int y = 0; y < h; y++)
-        for (int x = 0; x < w; x++) {
+    /* grid1 (:2435) has ceil((w / 2) / 16) blocks of 32 columns: an odd w with (w - 1) % 32 == 0 leaves its last column --
+     * a lattice column -- to no block at all; rows alike */
+    const int lat = (okz_reading_variant & 2) ? 1 : 16;
+    const int wcov = (okz_reading_variant & 2) ? w : (32 * ((w / 2 + 15) / 16) < w ? 32 * ((w / 2 + 15) / 16) : w);
+    const int hcov = (okz_reading_variant & 2) ? h : (32 * ((h / 2 + 15) / 16) < h ? 32 * ((h / 2 + 15) / 16) : h);
+    for (int y = 0; y < hcov; y += lat)
+        for (int x = 0; x < wcov; x += lat) {
             float g = grad[(size_t)y * p + x];
             if (g > hmax) hmax = g;
         }
@@ -253,6 +291,8 @@ float okz_kcontrast(const float* grad, int w, int h, int p, float per, float* hm
             if (hi >= OKZ_NBINS) hi = OKZ_NBINS - 1;
             hist[hi]++;
         }
+    if (!(okz_reading_variant & 4))                                     /* :909 with grid2 :2454 */
+        hist[0] += ((w + 31) / 32 * 32 - w) * h + ((h + 15) / 16 * 16 - h) * w;
     int thresh = (int)((w * h - hist[0]) * per);                        /* :2468 */
     int cumuv = 0, k = 1;
     while (k < OKZ_NBINS) {                                             /* :2472-2480 */
@@ -260,6 +300,7 @@ float okz_kcontrast(const float* grad, int w, int h, int p, float per, float* hm
         cumuv += hist[k];
         k++;
     }
+    if ((okz_reading_variant & 8) && k < OKZ_NBINS) k++;                /* power table only */
     if (hmax_out) *hmax_out = hmax;
     if (hist_out) memcpy(hist_out, hist, sizeof(hist));
     return k / hfactor;                                                 /* :2481 */
@@ -392,7 +433,9 @@ void okz_extrema_map(const float* dets, float* response_map, float* size_map, in
                 if (v > threshold && v > *vp0 && v > *vp2 && v > vp[-1] && v > vp[1] &&
                     v > vp0[-1] && v > vp0[1] && v > vp2[-1] && v > vp2[1]) {
                     size_t oidx = (size_t)(iy << octave) * opitch + (size_t)(ix << octave);
-                    if (response_map[oidx] < v) {                        /* :1368 */
+                    /* (variant bit 4, power table only: a later sublevel of the SAME octave overwrites unconditionally) */
+                    if (response_map[oidx] < v ||                        /* :1368 */
+                        ((okz_reading_variant & 16) && layer_map[oidx] >= octave * max_scale)) {
                         response_map[oidx] = v;
                         size_map[oidx] = size;
                         layer_map[oidx] = octave * max_scale + s;
@@ -532,6 +575,10 @@ void okz_orient_point(OkzPoint* pt, const float* dxd, const float* dyd, int o, i
     r = (xv < 0 ? (float)(OKZ_PI_D - r) : r);
     r = (yv < 0 ? -r : r);
     pt->angle = (r < 0.0f ? (float)(r + 2.0f * OKZ_PI_D) : r);          /* :1734 */
+    if (okz_reading_variant & 32) {                                     /* power table only */
+        pt->angle += (float)(5.0 * OKZ_PI_D / 180.0);
+        if (pt->angle >= (float)(2.0 * OKZ_PI_D)) pt->angle -= (float)(2.0 * OKZ_PI_D);
+    }
 }
 
 /* akazed.cu:65-159 setCompareIndices: 486 pairs into idx1/idx2 (>= 488 ints) */

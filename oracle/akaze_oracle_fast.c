@@ -145,18 +145,27 @@ static inline void fscharr(const int* src, int x, int y, int w, int h, int p, in
     *dy = 10 * (r2[x] - r0[x]) + 3 * (r2[x0] + r2[x2] - r0[x0] - r0[x2]);
 }
 
-/* akazed.cu:3208-3232 gScharrContrastNaive + 4098-4165 hScharrContrast (D2/D3 choices) */
+/* akazed.cu:3208-3232 gScharrContrastNaive + 4098-4165 hScharrContrast + 3245-3296 gFindMaxContrastU4 + 3299-3336
+ * gConstrastHistShared: the same two kernels as the float path on int32 (akaze_oracle.c, okz_kcontrast, has the derivation).
+ * D2: hmax = max(1, maximum over the lattice x % 16 == 0 && y % 16 == 0 inside grid1's coverage), the deterministic core;
+ * D3: the threads beyond the right / bottom edge count zeros of the zeroed arena into bin 0.  A wrapped-negative bin index
+ * (grad * hfactor overflows int32 when grad > ~109 hmax: possible now that hmax is a subsample) is an out-of-bounds shared
+ * atomicAdd in the reference (:3321-3326 checks only the upper end); counted in bin 0 here. */
 int fkz_kcontrast(const int* smooth, int w, int h, int p, float per, int* hmax_out, int* hist_out)
 {
     int* grad = (int*)malloc(sizeof(int) * (size_t)w * h);
     int hmax = 1;                                                       /* :4101 */
+    const int full = okz_reading_variant & 2;
+    const int lat = full ? 1 : 16;
+    const int wcov = full ? w : (32 * ((w / 2 + 15) / 16) < w ? 32 * ((w / 2 + 15) / 16) : w);   /* grid1 :4122 */
+    const int hcov = full ? h : (32 * ((h / 2 + 15) / 16) < h ? 32 * ((h / 2 + 15) / 16) : h);
     for (int y = 0; y < h; y++)
         for (int x = 0; x < w; x++) {
             int dx, dy;
             fscharr(smooth, x, y, w, h, p, &dx, &dy);
             int g = (int)(sqrtf((float)wadd(wmul(dx, dx), wmul(dy, dy))) + 0.5f);   /* :3231 */
             grad[(size_t)y * w + x] = g;
-            if (g > hmax) hmax = g;
+            if (g > hmax && x % lat == 0 && y % lat == 0 && x < wcov && y < hcov) hmax = g;   /* :3245-3296 */
         }
     int hist[FK_NBINS];
     memset(hist, 0, sizeof(hist));
@@ -168,6 +177,8 @@ int fkz_kcontrast(const int* smooth, int w, int h, int p, float per, int* hmax_o
         hist[hi]++;
     }
     free(grad);
+    if (!(okz_reading_variant & 4))                                     /* :3305 with grid2 :4142 */
+        hist[0] += ((w + 31) / 32 * 32 - w) * h + ((h + 15) / 16 * 16 - h) * w;
     int thresh = (int)((w * h - hist[0]) * per);
     int cumuv = 0, k = 1;
     while (k < FK_NBINS) {
@@ -175,6 +186,7 @@ int fkz_kcontrast(const int* smooth, int w, int h, int p, float per, int* hmax_o
         cumuv += hist[k];
         k++;
     }
+    if ((okz_reading_variant & 8) && k < FK_NBINS) k++;                 /* power table only */
     if (hmax_out) *hmax_out = hmax;
     if (hist_out) memcpy(hist_out, hist, sizeof(hist));
     return k * hmax / FK_NBINS;                                         /* :4162 */

@@ -299,16 +299,35 @@ MATCH_CASES = [
 
 
 # ----------------------------------------------------------------------------------------- contrast factor
-def kcontrast_literal(grad_values, per):
-    """hScharrContrast host half akazed.cu:2413, 2450, 2468-2481 + bins of gConstrastHistShared :924-928 on a flat list of gradients"""
-    g = np.asarray(grad_values, np.float32)
-    hmax = max(f32(0.03), g.max())                                  # :2413 floor, D2 true maximum
+def kcontrast_literal(grad, per):
+    """hScharrContrast on a gradient plane grad[h][w], as its kernels and host half literally compute it:
+    the maximum (akazed.cu:2413 floor; gFindMaxContrastU4 :827-877 launched :2435): only thread 0 of every 32 x 32-pixel block
+    feeds atomicMax, with the largest of ITS four pixels (32 bx + {0,16}, 32 by + {0,16}) -- the "reduction" loop compares against
+    absolute pixels of the image's top-left tile, never against the block's other threads -- so what arrives deterministically is the
+    maximum over x % 16 == 0 and y % 16 == 0, for the ceil((n / 2) / 16) blocks per axis the grid has;
+    the bins (gConstrastHistShared :901-938, grid :2454): 32 x 16 threads per block, `if (ix >= width && iy >= height) return` --
+    threads right of the image (rows < h) and below it (columns < w) still count what they read, zeros of the reused arena
+    (akaze.cpp:142-149), into bin 0;
+    the host half :2450, 2468-2481."""
+    g = np.asarray(grad, np.float32)
+    h, w = g.shape
+    hmax = f32(0.03)                                                # :2413
+    for by in range((h // 2 + 15) // 16):                           # :2435 grid1
+        for bx in range((w // 2 + 15) // 16):
+            for y in (32 * by, 32 * by + 16):                       # thread 0: iy0, iy1 (:832-835); the guards :836, 843, 847, 853
+                for x in (32 * bx, 32 * bx + 16):
+                    if x < w and y < h:
+                        hmax = max(hmax, g[y, x])
     hfactor = f32(300) / f32(hmax)                                  # :2450 NBINS / h_max_contrast
     hist = np.zeros(300, np.int64)
-    for v in g:
-        hi = int(np.float64(v) * np.float64(hfactor))               # :924 __fmul_rz then float -> int: truncation of the exact product
-        hist[min(hi, 299)] += 1                                     # :925-928
-    thresh = int(f32(f32(len(g) - hist[0]) * f32(per)))             # :2468 (int * float -> float -> int)
+    for iy in range((h + 15) // 16 * 16):                           # :2454 grid2 x block2 (32, 16)
+        for ix in range((w + 31) // 32 * 32):
+            if ix >= w and iy >= h:                                 # :909
+                continue
+            v = g[iy, ix] if (ix < w and iy < h) else f32(0)        # outside: pitch padding / the head of the next (zeroed) plane
+            hi = int(np.float64(v) * np.float64(hfactor))           # :924 __fmul_rz then float -> int: truncation of the exact product
+            hist[min(hi, 299)] += 1                                 # :925-928
+    thresh = int(f32(f32(w * h - hist[0]) * f32(per)))              # :2468 (int * float -> float -> int, towards zero)
     cumuv, k = 0, 1
     while k < 300:                                                  # :2472-2480: k ends one past the bin that reached the threshold
         if cumuv >= thresh:

@@ -34,8 +34,8 @@ def test_bench_contract_verified_and_roofline():
     assert out["n_gpus"] == 1 and out["steps"] == 2 and out["scaling"] == "weak" and out["dtype"] == "f32"
     assert out["value"] > 100 and abs(out["value"] - 16 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 0.01
     v = out["verified"]
-    # the oracle on all 8 distinct pairs; every slot of both contexts' last timed downloads; the FAST leg the same way
-    assert v["images"] == 16 and v["points_equal"] and v["matches_equal"]
+    # the oracle on all 16 distinct pairs; every slot of both contexts' last timed downloads; the FAST leg the same way
+    assert v["images"] == 32 and v["points_equal"] and v["matches_equal"]
     assert v["slots"] == 32 and v["contexts"] == 2 and v["slots_equal"] and v["gathered_pairs"] == 16 and v["gathered_pairs_equal"]
     assert v["fast"]["slots"] == 32 and v["fast"]["slots_equal"]
     g = out["gather"]
@@ -95,3 +95,45 @@ def test_bench_refuses_more_ranks_than_devices():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n + 1)], capture_output=True, text=True, timeout=300,
                        cwd=ROOT, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert r.returncode == 2 and f"{n + 1} ranks requested, {n} device" in r.stderr
+
+
+def _run_two_ranks(extra_env, port):
+    """torch.distributed.run with two ranks on the one MI355X of the GPU box (HAK_BENCH_DIST_BACKEND=gloo: both ranks compute on
+    cuda:0, the collectives run over gloo): the launcher is started before anything touches the GPU in this child tree"""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM")}
+    env.update({"HAK_BENCH_DIST_BACKEND": "gloo"})
+    env.update(extra_env)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "3", "--total-pairs", "37", "--pairs", "16", "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-configs", "--no-roofline"]
+    return subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+
+
+def test_two_ranks_end_to_end_on_one_gpu_unequal_shards():
+    """world = 2 on real results: 37 pairs of 1280x720 = shards of 19 (rank 0, lo = 0) and 18 (rank 1, lo = 19 -- not a multiple of the
+    16 seeds, so seed_of, the slot digests with lo != 0 and the unequal last chunks (16 + 3 and 16 + 2 pairs) all run); rank 0 checks the gathered table against
+    the oracle and the committed G = 1 table"""
+    r = _run_two_ranks({}, 29621)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and "rehearsal" in out and out["rccl_ranks"] == 0
+    assert out["config"]["total_pairs_per_step"] == 37 and out["config"]["pairs_per_step_per_gpu"] == 19
+    assert abs(out["value"] - 37 * 2 / (out["ms_per_step"] * 2e-3)) / out["value"] < 0.01
+    g = out["gather"]
+    assert g["pairs"] == 37 and g["complete"] and g["equal_seed_equal_checksum"] and g["equals_g1_table"] is True and g["distinct_seeds"] == 16
+    v = out["verified"]
+    assert v["slots_equal"] and v["gathered_pairs"] == 37 and v["gathered_pairs_equal"]
+    assert v["fast"] is None or v["fast"]["slots_equal"]
+
+
+def test_two_ranks_a_corrupted_pair_on_rank_1_is_caught():
+    """the same run with one descriptor bit of rank 1's first pair flipped after its download: rank 0 must refuse (exit code 3)"""
+    r = _run_two_ranks({"HAK_BENCH_CORRUPT_RANK": "1"}, 29622)
+    assert r.returncode != 0 and "results differ" in r.stderr, r.stdout[-1000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["gather"]["complete"] and (not out["gather"]["equal_seed_equal_checksum"] or out["gather"]["equals_g1_table"] is False)
+    assert out["verified"]["gathered_pairs_equal"] is False and out["verified"]["slots_equal"]      # rank 0's own slots are fine

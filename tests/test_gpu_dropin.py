@@ -70,8 +70,8 @@ def test_pair_calls_through_the_cpp_layer(ah, golden, tmp_path):
         env.pop(k, None)
     r = subprocess.run([DEMO, "0", left, right, "3", "--dump", dump, "--pair"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert _counts(r.stdout, "Number of features1:")[0] == 3634 and _counts(r.stdout, "Number of features2:")[0] == 4831
-    assert _counts(r.stdout, "Number of accepted matches:")[0] == 2468
+    assert _counts(r.stdout, "Number of features1:")[0] == 3631 and _counts(r.stdout, "Number of features2:")[0] == 4834
+    assert _counts(r.stdout, "Number of accepted matches:")[0] == 2464
     a, b = read_dump(dump, ah)[0]
     assert_points_equal(a, golden.lr["pts1"], fields=("x", "y", "octave", "response", "size", "angle", "features", "match", "distance",
                                                        "match_x", "match_y"))
@@ -84,9 +84,9 @@ def _counts(text, label):
 
 def test_demo_prints_the_oracle_counts(demo_run):
     out, _ = demo_run
-    assert _counts(out, "Number of features1:") == [3634, 3815]          # float path, then FAST path
-    assert _counts(out, "Number of features2:") == [4831, 5137]
-    assert _counts(out, "Number of accepted matches:")[0] == 2468
+    assert _counts(out, "Number of features1:") == [3631, 3798]          # float path, then FAST path
+    assert _counts(out, "Number of features2:") == [4834, 5169]
+    assert _counts(out, "Number of accepted matches:")[0] == 2464
     assert "Image size = (1280,960)" in out
 
 

@@ -213,17 +213,54 @@ def test_match_swap_reduce_and_flags(ah, name, dists, exp):
 
 
 # ----------------------------------------------------------------------------------------- contrast factor
+def _kcontrast_op(ah, torch, smooth, w, per):
+    h = smooth.shape[0]
+    sm = np.zeros((h, 128), np.float32); sm[:, :w] = smooth
+    kc, hmax = C.c_float(), C.c_float()
+    hist = np.zeros(300, np.int32)
+    d_sm = torch.from_numpy(sm).cuda()
+    ah.check(ah.lib.hak_op_kcontrast(d_sm.data_ptr(), w, h, 128, per, C.byref(kc), C.byref(hmax), hist.ctypes.data_as(C.POINTER(C.c_int))))
+    return f32(kc.value), f32(hmax.value), hist
+
+
 @pytest.mark.parametrize("per", [0.5, 0.7, 0.25, 0.9])
 def test_kcontrast_threshold_loop(ah, torch, per):
+    """the maximum is the LATTICE maximum (2.0; the true maximum 4.0 lies between lattice columns), akazed.cu:827-877"""
     s = np.zeros(129)
     s[48:88] = 2.0 ** -10; s[88:118] = 2.0 ** -4; s[118:128] = 2.0 ** -3
     smooth, grad = lf.ramp_plane(128, 32, s)
-    kc, hmax = C.c_float(), C.c_float()
-    hist = np.zeros(300, np.int32)
-    d_sm = torch.from_numpy(smooth).cuda()
-    ah.check(ah.lib.hak_op_kcontrast(d_sm.data_ptr(), 128, 32, 128, per, C.byref(kc), C.byref(hmax), hist.ctypes.data_as(C.POINTER(C.c_int))))
-    ekc, ehmax, ehist = lf.kcontrast_literal(grad.reshape(-1), per)
-    assert f32(hmax.value) == ehmax and np.array_equal(hist, ehist) and f32(kc.value) == ekc
+    kc, hmax, hist = _kcontrast_op(ah, torch, smooth, 128, per)
+    ekc, ehmax, ehist = lf.kcontrast_literal(grad, per)
+    assert ehmax == f32(2.0)
+    assert hmax == ehmax and np.array_equal(hist, ehist) and kc == ekc
+
+
+@pytest.mark.parametrize("per", [0.7, 0.25])
+def test_kcontrast_threads_outside_the_image_count_zeros(ah, torch, per):
+    """40 x 24: 896 threads of the 32 x 16 histogram blocks lie beside / below the image and count zeros (akazed.cu:909): thresh < 0, k = 1"""
+    s = np.zeros(41)
+    s[10:18] = 2.0 ** -5; s[18:26] = 2.0 ** -4; s[26:36] = 2.0 ** -7
+    smooth, grad = lf.ramp_plane(40, 24, s)
+    kc, hmax, hist = _kcontrast_op(ah, torch, smooth, 40, per)
+    ekc, ehmax, ehist = lf.kcontrast_literal(grad, per)
+    assert ehmax == f32(1.0) and ehist[0] == 13 * 24 + 896 and ekc == f32(1) / f32(300)
+    assert hmax == ehmax and np.array_equal(hist, ehist) and kc == ekc
+
+
+def test_kcontrast_lattice_stops_where_the_grid_stops(ah, torch):
+    """w = 97: gFindMaxContrastU4's grid (akazed.cu:2435) has 3 blocks of 32 columns; lattice column 96 belongs to none"""
+    rng = np.random.default_rng(5)
+    smooth = rng.random((32, 97)).astype(np.float32)
+    smooth[17:, 90:] += 50.0                                         # a step under row 16 in the last columns: |grad(96, 16)| ~ 800
+    kc, hmax, hist = _kcontrast_op(ah, torch, smooth, 97, 0.7)
+    # the gradient plane by the literal Scharr of the fixtures' own reflect-101 indexing (akazed.cu:664-666, 162-170)
+    pad = np.pad(smooth.astype(np.float32), 1, mode="reflect")
+    dx = f32(10) * (pad[1:-1, 2:] - pad[1:-1, :-2]) + f32(3) * (pad[:-2, 2:] + pad[2:, 2:] - pad[:-2, :-2] - pad[2:, :-2])
+    dy = f32(10) * (pad[2:, 1:-1] - pad[:-2, 1:-1]) + f32(3) * (pad[2:, :-2] + pad[2:, 2:] - pad[:-2, :-2] - pad[:-2, 2:])
+    grad = np.sqrt((dx * dx + dy * dy).astype(np.float32)).astype(np.float32)
+    ekc, ehmax, ehist = lf.kcontrast_literal(grad, 0.7)
+    assert ehmax == grad[0:32:16, 0:96:16].max() and grad[16, 96] > 100 * ehmax                 # column 96 is not consulted
+    assert hmax == ehmax and np.array_equal(hist, ehist) and kc == ekc
 
 
 # ----------------------------------------------------------------------------------------- down + smooth

@@ -69,7 +69,8 @@ def test_kcontrast(ah, okz, torch, w, h):
                                      hist.ctypes.data_as(C.POINTER(C.c_int))))
     okc, ohmax, ohist = okz.kcontrast(okz.scharr_grad(sm, w), w, 0.7)
     assert np.float32(hmax.value) == ohmax
-    assert np.array_equal(hist, ohist) and hist.sum() == w * h
+    extra = ((w + 31) // 32 * 32 - w) * h + ((h + 15) // 16 * 16 - h) * w          # akazed.cu:909: threads outside the image count zeros
+    assert np.array_equal(hist, ohist) and hist.sum() == w * h + extra
     assert np.float32(kc.value).view(np.uint32) == okc.view(np.uint32)
 
 

@@ -296,21 +296,65 @@ def _slopes():
 
 @pytest.mark.parametrize("per", [0.5, 0.7, 0.25, 0.9])
 def test_kcontrast_threshold_loop(okz, per):
-    """one row of hand-made gradient values repeated: bins, threshold and the `k` that is one past the stopping bin (:2468-2481)"""
+    """one row of hand-made gradient values repeated: the LATTICE maximum (the true maximum 4.0 sits off the 16-px lattice), bins,
+    threshold and the `k` that is one past the stopping bin (:827-877, 2468-2481)"""
     smooth, grad = lf.ramp_plane(128, 32, _slopes())
     # the ramp's gradient is what the comment of ramp_plane says (Scharr, akazed.cu:664-666)
     g = okz.scharr_grad(_pitched(smooth, 128), 128)
     assert np.array_equal(g, grad)
     kc, hmax, hist = okz.kcontrast(g, 128, per)
-    ekc, ehmax, ehist = lf.kcontrast_literal(grad.reshape(-1), per)
-    assert hmax == ehmax == f32(4.0) and np.array_equal(hist, ehist) and kc == ekc
-    # worked example: hmax = 16 * (1/8 + 1/8) = 4 -> hfactor 75; per row 48 zeros (bin 0), one 2^-6 (bin 1), 39 x 2^-5 (bin 2),
-    # one 1.015625 (bin 76), 29 x 2.0 (bin 150), one 3.0 (bin 225), 9 x 4.0 (bin 300 -> 299)
+    ekc, ehmax, ehist = lf.kcontrast_literal(grad, per)
+    # worked example: the row is 47 zeros, 2^-6 at x = 47, 2^-5 at 48..86, 1.015625 at 87, 2.0 at 88..116, 3.0 at 117, 4.0 at 118..126,
+    # 0 at 127.  Thread 0 of the blocks sees columns 0, 16, .., 112 only: 0, 0, 0, 2^-5, 2^-5, 2^-5, 2.0, 2.0 -> hmax = 2, hfactor = 150
+    # (a true maximum would give 4 and 75).  Bins: 2^-6 -> 2, 2^-5 -> 4, 1.015625 -> 152, everything from 2.0 up -> 300 -> 299.
+    # 128 = 4 * 32 and 32 = 2 * 16: no thread outside the image, no extra zeros.
+    assert hmax == ehmax == f32(2.0) and np.array_equal(hist, ehist) and kc == ekc
     row = ehist // 32
-    assert row[0] == 48 and row[1] == 1 and row[2] == 39 and row[76] == 1 and row[150] == 29 and row[225] == 1 and row[299] == 9
+    assert row[0] == 48 and row[2] == 1 and row[4] == 39 and row[152] == 1 and row[299] == 39 and row.sum() == 128
     if per == 0.5:
-        # thresh = (int)(80 * 32 * 0.5f) = 1280 = bins 1 + 2 exactly: the loop adds bin 2, k becomes 3, then breaks: 3 / 75
-        assert kc == f32(3) / f32(75)
+        # thresh = (int)(80 * 32 * 0.5f) = 1280 = bins 2 + 4 exactly: the loop adds bin 4, k becomes 5, then breaks: 5 / 150
+        assert kc == f32(5) / f32(150)
+
+
+def _slopes_40():
+    s = np.zeros(41, np.float64)
+    s[10:18] = 2.0 ** -5
+    s[18:26] = 2.0 ** -4
+    s[26:36] = 2.0 ** -7
+    return s
+
+
+@pytest.mark.parametrize("per", [0.7, 0.25])
+def test_kcontrast_threads_outside_the_image_count_zeros(okz, per):
+    """40 x 24: the histogram blocks are 32 x 16 threads and return only when BOTH coordinates are outside (akazed.cu:909), so
+    (64 - 40) * 24 + (32 - 24) * 40 = 896 threads beside and below the image add zeros to bin 0 -- more than the 648 non-zero pixels,
+    `thresh` (:2468) goes negative and the loop stops at once: k = 1"""
+    smooth, grad = lf.ramp_plane(40, 24, _slopes_40())
+    g = okz.scharr_grad(_pitched(smooth, 128), 40)
+    assert np.array_equal(g[:, :40], grad)
+    kc, hmax, hist = okz.kcontrast(g, 40, per)
+    ekc, ehmax, ehist = lf.kcontrast_literal(grad, per)
+    # the row: 9 zeros, 0.5 at x = 9, 1.0 at 10..16, 1.5 at 17, 2.0 at 18..24, 1.125 at 25, 0.25 at 26..34, 0.125 at 35, 4 zeros.
+    # lattice columns 0, 16, 32 hold 0, 1.0, 0.25: hmax = 1 (true maximum 2), hfactor = 300; bins 0.125 -> 37, 0.25 -> 75, 0.5 -> 150,
+    # 1.0 and above -> 299
+    assert hmax == ehmax == f32(1.0) and np.array_equal(hist, ehist) and kc == ekc
+    assert ehist[0] == 13 * 24 + 896 and ehist[37] == 24 and ehist[75] == 216 and ehist[150] == 24 and ehist[299] == 384
+    assert ehist.sum() == 40 * 24 + 896
+    # thresh = (int)((960 - 1208) * per) < 0 -> cumuv = 0 >= thresh at k = 1 (with the guard read as `||`: (int)(648 * 0.7f) = 453,
+    # reached only in bin 299 -> k = 300, kcontrast 1.0 instead of 1 / 300)
+    assert kc == f32(1) / f32(300)
+
+
+def test_kcontrast_lattice_stops_where_the_grid_stops(okz):
+    """grid1 = ceil((w / 2) / 16) blocks of 32 columns (akazed.cu:2435): w = 97 -> (48 + 15) / 16 = 3 blocks = columns 0..95; the
+    lattice column x = 96 belongs to no block, although it is inside the image"""
+    g = np.zeros((32, 97), np.float32)
+    g[16, 96] = 5.0                                                  # on the lattice, outside the grid
+    g[16, 80] = 0.5                                                  # on the lattice, inside
+    g[3, 7] = 9.0                                                    # off the lattice
+    kc, hmax, hist = okz.kcontrast(_pitched(g, 128), 97, 0.7)
+    ekc, ehmax, ehist = lf.kcontrast_literal(g, 0.7)
+    assert hmax == ehmax == f32(0.5) and np.array_equal(hist, ehist) and kc == ekc
 
 
 def test_kcontrast_floor(okz):

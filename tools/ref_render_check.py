@@ -355,12 +355,16 @@ def _draw_matches(u1, u2, a, b, rng, extra=0):
     return img
 
 
-def calibrate(u, seed=5):
+def calibrate(u, seed=5, draw_variant=0, mutate=None):
     """u = {1: img, 2: img} (uint8): the oracle's own result on them drawn the way main.cpp draws, JPEG-compressed the way
-    cv::imwrite does, then measured exactly like the reference's pictures.  'reference counts' = the oracle's counts on u."""
+    cv::imwrite does, then measured exactly like the reference's pictures.  'reference counts' = the oracle's counts on u.
+    draw_variant / mutate (power table): the DRAWING program reads the reference differently (okz_reading_variant bits) or has its
+    descriptors rewritten by mutate(points) before it matches; the measuring oracle is always the default reading."""
     import okz
     rng = np.random.default_rng(seed)
-    truth = {(path, k): run_oracle(u[k], path) for path in ("float", "fast") for k in (1, 2)}
+    truth = {(path, k): run_oracle(u[k], path, variant=draw_variant) for path in ("float", "fast") for k in (1, 2)}
+    if mutate:
+        truth = {key: mutate(v.copy()) for key, v in truth.items()}
     shows = {k: [] for k in (1, 2)}
     matched = {}
     for path in ("float", "fast"):
@@ -381,6 +385,124 @@ def calibrate(u, seed=5):
     for k in (1, 2):
         rep["reconstruction"]["img%d" % k]["rms_vs_original"] = round(float(np.sqrt(((recs[k].astype(np.float32) - u[k]) ** 2).mean())), 3)
     return rep
+
+
+# ------------------------------------------------------------------ which reading of hScharrContrast do the pictures prefer?
+READINGS = {0: "literal: lattice maximum + threads outside the image count zeros (default since round 5)",
+            2: "true maximum of the gradient (rounds 1-4), histogram guard literal",
+            4: "lattice maximum, histogram over the w x h pixels only (guard read as ||)",
+            6: "true maximum + w x h histogram (rounds 1-4)"}
+
+
+def score_readings(stacks, matched, recs, ref_counts, seed=0):
+    """counts / ring hits / match lines of the reference's pictures under the four readings of akazed.cu:827-877 + 909"""
+    out = {}
+    for v in READINGS:
+        rng = np.random.default_rng(seed)
+        row = {"reading": READINGS[v]}
+        pts = {}
+        for path, ri in (("float", 0), ("fast", 1)):
+            for k in (1, 2):
+                Y, C = stacks[k]
+                p = run_oracle(recs[k], path, variant=v)
+                pts[path, k] = p
+                rec = recs[k].astype(np.float32)
+                ov = overlay_mask(Y[ri], C[ri], rec)
+                cx, cy, rad = keypoint_circle(p)
+                s1 = ring_scores(ov, cx, cy, rad)
+                for dx in (-1, 0, 1):
+                    for dy in (-1, 0, 1):
+                        if dx or dy:
+                            s1 = np.maximum(s1, ring_scores(ov, cx + dx, cy + dy, rad))
+                row["%s_img%d" % (path, k)] = dict(count=int(len(p)), reference_count=int(ref_counts[path][k - 1]),
+                                                   count_ratio=round(len(p) / ref_counts[path][k - 1], 4),
+                                                   ring_hit_pm1=round(float((s1 >= 0.85).mean()), 4),
+                                                   ring_hits=int((s1 >= 0.85).sum()))
+            Ym, Cm = matched[path]
+            recm = np.concatenate([recs[1], recs[2]]).astype(np.float32)
+            mm = match_metrics(pts[path, 1], pts[path, 2], Ym, Cm, recm, recs[1].shape[0], rng)
+            row["matches_" + path] = dict(oracle_matches=mm["oracle_matches"], line_hit=mm["line_hit"], seam_ratio=mm["seam_ratio"],
+                                          line_hits=int(round(mm["line_hit"] * mm["oracle_matches"])))
+        out[str(v)] = row
+    return out
+
+
+# ------------------------------------------------------------------ what the pin can and cannot see (power table)
+def _permute_descriptor_bits(points, seed=99):
+    """a consistent permutation of the 486 descriptor bits (the same for every keypoint of both images): Hamming distances, hence
+    every match, are unchanged"""
+    perm = np.random.default_rng(seed).permutation(486)
+    bits = np.unpackbits(points["features"], axis=1, bitorder="little")
+    out = bits.copy()
+    out[:, :486] = bits[:, perm]
+    points["features"] = np.packbits(out, axis=1, bitorder="little")
+    return points
+
+
+POWER_CASES = [  # name, okz_reading_variant bits of the DRAWER, descriptor mutation
+    ("clean disc NMS (cursor advances at the skipped centre)", 1, None),
+    ("true-maximum hmax (rounds 1-4) instead of the lattice maximum", 2, None),
+    ("histogram over w x h only (guard as ||)", 4, None),
+    ("k + 1 histogram bins", 8, None),
+    ("sublevel scatter: last writer wins (the D5 race at its extreme)", 16, None),
+    ("main orientation + 5 degrees", 32, None),
+    ("descriptor bits permuted consistently", 0, _permute_descriptor_bits),
+]
+POWER_METRICS = [("count_ratio", lambda r, i: r["keypoints"]["float_img%d" % i]["count_ratio"]),
+                 ("ring_hit_pm1", lambda r, i: r["keypoints"]["float_img%d" % i]["ring_hit_pm1"]),
+                 ("isolated_recall", lambda r, i: r["keypoints"]["float_img%d" % i]["isolated_circles"]["recall_1p5px"]),
+                 ("isolated_same_radius", lambda r, i: r["keypoints"]["float_img%d" % i]["isolated_circles"]["recall_1p5px_same_radius"]),
+                 ("lag_thin_hit", lambda r, i: r["keypoints"]["float_img%d" % i]["nms_lag"]["thin_hit_lag_only"]),
+                 ("line_hit", lambda r, i: r["matches"]["float"]["line_hit"]),
+                 ("seam_ratio", lambda r, i: r["matches"]["float"]["seam_ratio"])]
+
+
+def power_table(recs, null_seeds=(5, 6, 7, 8)):
+    """The oracle under reading X draws the pictures (on the reconstructed pair, the reference's density), the DEFAULT oracle is
+    measured against them exactly like against the reference's.  A metric 'separates' X from the default reading when its value
+    leaves the band the default-vs-default runs span (different colours / control draws: `null_seeds`) by more than that band's
+    width again.  Float path, mean over img1 / img2."""
+    def vec(rep):
+        return {name: float(np.mean([f(rep, i) for i in (1, 2)])) for name, f in POWER_METRICS}
+    null = [vec(calibrate(recs, seed=sd)) for sd in null_seeds]
+    band = {name: (min(n[name] for n in null), max(n[name] for n in null)) for name, _ in POWER_METRICS}
+    rows = {}
+    for title, bits, mut in POWER_CASES:
+        v = vec(calibrate(recs, seed=null_seeds[0], draw_variant=bits, mutate=mut))
+        sep = {}
+        for name, _ in POWER_METRICS:
+            lo, hi = band[name]
+            slack = max(hi - lo, 0.005)
+            sep[name] = bool(v[name] < lo - slack or v[name] > hi + slack)
+        rows[title] = dict(variant_bits=bits, metrics={k: round(x, 4) for k, x in v.items()}, separates=sep,
+                           seen_by=[k for k, b in sep.items() if b])
+    return dict(null_band={k: [round(a, 4), round(b, 4)] for k, (a, b) in band.items()}, null_runs=len(null_seeds), cases=rows)
+
+
+# ------------------------------------------------------------------ why are radius-3 circles found as sublevel 1?  (noise hypothesis)
+def _jpeg_gray_generation(u8):
+    """one JPEG generation of a gray image the way the demo's pictures went through it (3-channel, q95, 4:2:0), luma back"""
+    return np.clip(np.rint(_ycc(_jpeg(np.repeat(u8[..., None], 3, axis=2)))[0]), 0, 255).astype(np.uint8)
+
+
+def sublevel_class_drift(u8, generations=1):
+    """keypoints of the pristine image vs keypoints of the same image after JPEG generation(s), ALL keypoints (no isolation
+    filter): for every pristine keypoint of radius class r (2 = sublevels 0 / 1, 3 = sublevel 2, 4 = sublevel 3) the class of
+    the keypoint found within 1.5 px afterwards.  If JPEG noise is what turns drawn radius-3 circles into sublevel-1 keypoints,
+    3 -> 2 must be common here and 2 -> 3 rare -- with no CUDA race anywhere in the experiment."""
+    a = run_oracle(u8, "float")
+    v = u8
+    for _ in range(generations):
+        v = _jpeg_gray_generation(v)
+    b = run_oracle(v, "float")
+    _, _, ra = keypoint_circle(a)
+    _, _, rb = keypoint_circle(b)
+    d, i = cKDTree(np.c_[b["x"], b["y"]]).query(np.c_[a["x"], a["y"]])
+    conf = {str(r): [int(((ra == r) & (d <= 1.5) & (rb[i] == q)).sum()) for q in (2, 3, 4)] + [int(((ra == r) & (d > 1.5)).sum())] for r in (2, 3, 4)}
+    # the coarser octaves' sublevel 1 vs 2 only (same dilation: where the reference's pictures show the effect)
+    return dict(pristine=int(len(a)), after=int(len(b)), rms_noise=round(float(np.sqrt(((v.astype(np.float32) - u8) ** 2).mean())), 3),
+                class_after_by_class_before=conf, columns=["2", "3", "4", "lost"],
+                frac_3_to_2=round(conf["3"][0] / max(1, sum(conf["3"][:3])), 4), frac_2_to_3=round(conf["2"][1] / max(1, sum(conf["2"][:3])), 4))
 
 
 def summarize(rep, title):
@@ -406,6 +528,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--write-fixture", action="store_true")
     ap.add_argument("--no-calibrate", action="store_true")
+    ap.add_argument("--no-readings", action="store_true")
+    ap.add_argument("--no-power", action="store_true")
     ap.add_argument("--out", default=os.path.join(GOLDEN, "ref_render_report.json"))
     args = ap.parse_args()
     from PIL import Image
@@ -427,6 +551,27 @@ def main():
         out["calibration_self"] = calibrate(recs)
         summarize(out["calibration_self"], "calibration B: the same on the reconstructed img1 / img2 themselves (same density; second-generation "
                   "JPEG noise only)")
+    if not args.no_readings:
+        out["readings"] = score_readings(stacks, matched, recs, REF_COUNTS)
+        print("== the four readings of hScharrContrast (akazed.cu:827-877, 909) against the reference's pictures")
+        for v, row in out["readings"].items():
+            print("  variant %s  float %d / %d (ring hits %d / %d), FAST %d / %d (ring hits %d / %d), lines float %d of %d, FAST %d of %d -- %s"
+                  % (v, row["float_img1"]["count"], row["float_img2"]["count"], row["float_img1"]["ring_hits"], row["float_img2"]["ring_hits"],
+                     row["fast_img1"]["count"], row["fast_img2"]["count"], row["fast_img1"]["ring_hits"], row["fast_img2"]["ring_hits"],
+                     row["matches_float"]["line_hits"], row["matches_float"]["oracle_matches"], row["matches_fast"]["line_hits"],
+                     row["matches_fast"]["oracle_matches"], row["reading"]))
+    if not args.no_power:
+        out["power"] = power_table(recs)
+        print("== power of the pin: the oracle under reading X draws, the default oracle is measured (float path, mean of img1 / img2)")
+        print("  default vs default band:", out["power"]["null_band"])
+        for title, row in out["power"]["cases"].items():
+            print("  %-62s seen by: %s\n      %s" % (title, ", ".join(row["seen_by"]) or "NOTHING (reading-only)", row["metrics"]))
+        lr = np.load(os.path.join(GOLDEN, "left_right_u8.npz"))
+        out["sublevel_class_drift"] = {"left_1gen": sublevel_class_drift(lr["left"]), "right_1gen": sublevel_class_drift(lr["right"]),
+                                       "recon_img1_1gen": sublevel_class_drift(recs[1]), "recon_img2_1gen": sublevel_class_drift(recs[2])}
+        print("== radius class of a keypoint before / after one JPEG generation (all keypoints; rows 2, 3, 4 -> columns 2, 3, 4, lost)")
+        for k, v in out["sublevel_class_drift"].items():
+            print("  %-16s %s   3->2: %.3f, 2->3: %.3f (noise rms %.2f)" % (k, v["class_after_by_class_before"], v["frac_3_to_2"], v["frac_2_to_3"], v["rms_noise"]))
     json.dump(out, open(args.out, "w"), indent=1)
     print("wrote", args.out)
     if args.write_fixture:
