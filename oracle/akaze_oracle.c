@@ -28,16 +28,14 @@
  *   D9  Hamming distance over exactly 61 bytes
  *   D10 n2 < 16 handled (lanes without a candidate do not take part)
  *
- * PARITY PINNING: the reference has no tests and no golden vectors; its CUDA
- * path cannot be built here.  The only compilable piece (fed.cpp) is built by
- * oracle/Makefile into oracle/_ref/ and pins okz_fed_tau().  Constants are
- * pinned by the KATs of SURVEY.md 4.  Everything else is bit-unpinned against
- * a real CUDA run; since round 4 it is pinned STATISTICALLY against the
- * reference's own run through the result pictures in its data/ directory
- * (tools/ref_render_check.py, tests/test_ref_render_cpu.py):
- * keypoint counts within -0.1 .. -3.6 % of the printed ones, 86-89 % of the
- * keypoints at the drawn pixel +-1 with the drawn radius class (as many as
- * the oracle scores against its own drawing), the NMS cursor lag confirmed.
+ * PARITY PINNING (oracle/README.md has the table): the reference has no tests and no golden vectors; its CUDA path cannot be
+ * built here.  The only compilable piece (fed.cpp) is built by oracle/Makefile into oracle/_ref/ and pins okz_fed_tau() bit for
+ * bit.  Constants are pinned by the KATs of SURVEY.md 4, every control-flow-heavy stage by hand-derived literal fixtures
+ * (tests/literal_fixtures.py).  The whole path is pinned STATISTICALLY against the reference's own CUDA run through the result
+ * pictures in its data/ directory (tools/ref_render_check.py, tests/test_ref_render_cpu.py): keypoint counts
+ * within -1.0 .. -3.6 % of the printed ones, 86-89 % of the keypoints at the drawn pixel +-1 with the drawn radius class (as
+ * many as the oracle scores against its own drawing), the NMS cursor lag confirmed.  That pin cannot see the contrast factor to
+ * better than +-1 bin, response values or the descriptor's bit layout (measured: its power table): those are reading-only.
  */
 #include <math.h>
 #include <stdint.h>
