@@ -1068,9 +1068,9 @@ extern "C" int hak_match_knn2_batch(hak_ctx* c, hak_point* d_points, const int* 
     int4* fwd = c->knn;
     int4* rev = c->knn + (size_t)((c->cfg.batch + 1) / 2) * mp;
     { ProfScope ps(c, HAK_PROF_MATCH);
-      hak_launch_knn2(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, 0, 0, 2 * mp, 2 * mp, npairs, fwd, mp);
+      hak_launch_knn2(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, (int)mp, (int)mp, 2 * mp, 2 * mp, npairs, fwd, mp);
       if (cross_check)
-          hak_launch_knn2(c->stream, d_points + mp, d_points, d_num_pts + 1, d_num_pts, 0, 0, 2 * mp, 2 * mp, npairs, rev, mp);
+          hak_launch_knn2(c->stream, d_points + mp, d_points, d_num_pts + 1, d_num_pts, (int)mp, (int)mp, 2 * mp, 2 * mp, npairs, rev, mp);
       hak_launch_knn2_finish(c->stream, d_points, d_points + mp, d_num_pts, 0, 2 * mp, 2 * mp, npairs, fwd, cross_check ? rev : nullptr,
                              mp, ratio_num, ratio_den, cross_check ? 1 : 0, max_dist, d_out, mp, d_counts); }
     if (hipGetLastError() != hipSuccess) return fail("knn2 launch failed");

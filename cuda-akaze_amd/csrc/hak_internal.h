@@ -450,6 +450,7 @@ void hak_launch_describe(hipStream_t st, const HakBatch& b, const HakLayout& L, 
 int hak_launch_copy_probe(long bytes, int iters, double* ms_per_copy, double* shapes_ms = nullptr);
 int hak_launch_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch);
 int hak_launch_stream_probe(int w, int h, int nimg, int nwrite, int warm, int iters, double* ms, double* bytes);
+int hak_launch_hess_probe(int w, int h, int nimg, int step, int iters, double* ms, double* bytes);
 
 // matcher (kernels_match.hip)
 // Scratch of the SLICED searches (one big pair through hak_match / hak_match_knn2, e.g. 10k x 10k: the train set is cut into

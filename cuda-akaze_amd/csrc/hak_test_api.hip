@@ -305,6 +305,17 @@ extern "C" int hak_op_stream_probe(int w, int h, int nimg, int nwrite, int warm_
     return 0;
 }
 
+extern "C" int hak_op_hess_probe(int w, int h, int nimg, int step, int iters, double* ms_per_launch, double* gbytes_per_s)
+{
+    if (!ms_per_launch || !gbytes_per_s) return fail("null argument");
+    if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    double ms = 0, bytes = 0;
+    if (hak_launch_hess_probe(w, h, nimg, step, iters, &ms, &bytes) || ms <= 0) return fail("hessian probe failed (w % 4, step 1..4, sizes, memory?)");
+    *ms_per_launch = ms;
+    *gbytes_per_s = bytes / (ms * 1e-3) / 1e9;
+    return 0;
+}
+
 extern "C" int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double* ms_per_launch)
 {
     if (bytes < 4096 || blocks < 1 || per_lane < 4 || iters < 1 || !ms_per_launch) return fail("bad probe argument");

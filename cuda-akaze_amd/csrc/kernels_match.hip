@@ -198,11 +198,11 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 // 10k x 10k 0.0636 -> 0.0488 ms, the match class of the 256-pair sequence 0.51 -> 0.34 ms (same box, profiles/r04_match10k.txt).
 //   E2M1 codes: 0001 = 0.5, 0010 = 1, 0100 = 2, 1000 = the sign.  To make the train side's bit -> fp4 expansion ONE v_and_b32 per
 //   eight k, bit t < 3 of a nibble stays where it is (x_k = a_k 2^(t-1), mask 0x11111111 << t) and bit 3 comes down to bit 2 from a
-//   staged copy shifted right by 1 (x_k = 2 a_k); the query side is y_k = (1 - 2 b_k) 2^(1-t) (0.5 for bit 3): every product is
-//   +-a_k.  tools/fp4_hamming_probe.hip checks exactly this arithmetic against popcounts on the device.
-//   The accumulator STARTS at 2^23 + |b| (C operand of the tile's first instruction; every partial sum is an integer below 2^24,
-//   exact in fp32), so its bit pattern ends as 0x4B000000 + distance, which the key's << 20 reduces to distance << 20: the epilogue
-//   is one v_lshl_add_u32 (+ index base) and one v_min_u32 per element, as in the int8 version.
+//   staged copy shifted right by 1 (x_k = 2 a_k); the query side is y_k = (1 - 2 b_k) 2^(2-t) (1 for bit 3): every product is
+//   +-2 a_k (round 4: 2^(1-t), +-a_k).  tools/fp4_hamming_probe.hip checks this arithmetic against popcounts on the device.
+//   Round 4: the accumulator started at 2^23 + |b| and ended as 0x4B000000 + distance; the key epilogue attached the train index
+//   to every distance (one v_lshl_add_u32 + one v_min_u32 per element).  Round 5: the accumulator comes out of the matrix unit as
+//   the finished key, index included (MM_BASE below) -- one v_min3_u32 per element and PAIR of tiles.
 //   A (train, rows m): lane (r = l & 31, h = l >> 5), k-step s < 8: dword 8 h + s of descriptor j0 + r and its copy >> 1
 //   B (query, cols n): the same dword of query q0 + r; expanded ONCE per wave into 32 VGPRs
 //   C/D: lane (n = l & 31, h) holds train rows (i & 3) + 8 (i >> 2) + 4 h, i < 16, of query n (cdna_hip_programming.md 158)
@@ -211,28 +211,45 @@ __global__ __launch_bounds__(256, 4) void k_match(hak_point* pts1_base, const ha
 // the minimum of packed keys exactly as in k_match.  A wave = 32 queries x the whole train set (or its slice); the four waves of a
 // block share the train descriptors through LDS.
 //
-// Round 4: the train set travels in CHUNKS of MM_CH descriptors (rows of 144 bytes: per lane half its 8 descriptor dwords and the
+// Rounds 4-5: the train set travels in CHUNKS of MM_CH descriptors (rows of 144 bytes: per lane half its 8 descriptor dwords and the
 // same shifted right by 1, padding -- conflict-free ds_read_b128), double-buffered: the 8-byte loads of chunk c+1 (MM_CH / 32 per
 // thread, all in flight at once; a lane fetching ITS descriptor row straight from the 104-byte records touches 32 lines per load
 // instruction and ran at a third of the matrix pipe's rate) are issued before the tiles of chunk c are multiplied and written to
 // the other buffer after them: ONE barrier and ONE exposed memory round trip per chunk.  Round 3 staged tile by tile (a barrier and
 // a dependent load per 32 rows, two tiles ahead); for one big pair that loop was latency-bound.
-// What bounds the loop: vector-instruction ISSUE.  tools/probes/mfma_valu_overlap.hip: beside one v_mfma_f32_32x32x64_f8f6f4 (32
-// cycles, 14-15 ns per SIMD) up to 6 independent vector instructions are free, 8 cost 17-19 ns per MFMA, 12 cost 22-24, 16 cost
-// 26-28 -- with 1, 2 or 3 waves per SIMD alike; the matcher's own mix (4 v_and + 2 x (v_lshl_add_u32 + v_min_u32) per MFMA) 19.6-20.
-// The batched kernel issues ~11 vector instructions per MFMA (SQ_INSTS_VALU / SQ_INSTS_MFMA: 8 in the tile loop, the rest staging,
-// address arithmetic and the per-query-block prologue / finish) and its SIMDs are busy issuing ~98 % of the time (SQ_ACTIVE_INST_ANY
-// of two waves): 266 ns per tile and SIMD against 8 x 14.5 = 116 ns of matrix time.  The int8 loop showed the same picture as a sum
-// (profiles/r04_match10k_sq.txt: SQ_VALU_MFMA_BUSY_CYCLES = 32 per MFMA, SQ_ACTIVE_INST_VALU = 4 per vector instruction, adding up to
-// the kernel's duration).  So: fewer vector instructions per distance (fp4: half the expansion; the software pipeline below lets
-// the compiler fold two tiles' keys into one v_min3_u32), 256-row chunks (half the staging per tile).  Tried and measured equal or
-// worse: two independent accumulation chains per step, no pre-shifted copy (one more v_lshrrev per fragment), three or four waves
-// per SIMD with 128-row chunks.
+// What bounds the kernel (round 5: measured with wall-clock stamps inside it, tools/mm_timing.py on a -DHAK_MM_TIMING build;
+// 10k x 10k = 474 blocks, all resident, every block starts within 1.6 us):
+//   a block lives 22.5 us: 3.3 us until its first chunk is in LDS (cold query + train loads), 9 chunks x 1.9-2.0 us, 1.5 us for its
+//   summary + ticket; the block that draws the last ticket of a query block merges the slices and ends 3-6 us later (the kernel's
+//   tail: 40 % of the blocks end after 25 us, the last at 29.7);
+//   a chunk = 48 matrix instructions per wave = 1.28 us of matrix time per SIMD with its two waves at 2.4 GHz: the loop runs at
+//   0.65 of the matrix rate.  What it still issues per matrix instruction: 4 v_and (the bit -> fp4 expansion), 1 v_min3_u32, the
+//   LDS reads and the staging of the next chunk -- at the edge of the 6 vector instructions that are free beside one MFMA
+//   (tools/probes/mfma_valu_overlap.hip).
+// Round 4 read its instruction counters as "vector-issue-bound, 11 per MFMA": that was the int8 kernel; experiments that removed
+// the epilogue also removed the matrix instructions (dead code) and said nothing.  What round 5 changed, in measured order:
+//   the key out of the accumulator (8.25 -> 5.25 vector instructions per MFMA), three accumulator sets with the minima pinned
+//   between the matrix instructions (the compiler otherwise reassociates them to the chunk's end and keeps six sets alive),
+//   two chunks in flight and the next chunk staged beside the tiles instead of behind them (barrier wait 0.55 -> 0.08 us per
+//   chunk -- but the chunk got as much longer: the CU is short of issue slots, not waiting), the merge's loads in one round trip:
+//   kernel 37.9 -> 30.5 us, call 0.0437 -> 0.0409 ms.  Still open: a 64-query wave (each expanded train fragment feeds two
+//   matrix instructions: 2 v_and per MFMA) and staggering the two resident blocks so that one's prologue meets the other's loop.
 typedef int mm_v4i __attribute__((ext_vector_type(4)));
 typedef int mm_v8i __attribute__((ext_vector_type(8)));
 typedef float mm_v16f __attribute__((ext_vector_type(16)));
 #define MM_MFMA(a, b, c) __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 4, 4, 0, 0, 0, 0)     // cbsz = blgp = 4: fp4 operands
-#define MM_BCH 256      // train descriptors per LDS chunk (two 36 KB buffers per block, two blocks per CU)
+#define MM_BCH 192      // train descriptors per LDS chunk = six tiles (two 27 KB buffers per block, two blocks per CU)
+// Round 5: the accumulator is the key.  It starts at 2^10 + 2 |b| + q 2^-13 (q = the chunk's number, < 2048) and every descriptor
+// bit contributes +-2, so it ends as 2^10 + 2 d + P / 4 + q 2^-13, where P / 4 comes out of the matrix unit as well: three k
+// positions that hold struct padding in every descriptor (bits 8, 12, 16 of dword 15) carry the staged row's tile number P < 8 on
+// the train side (fp4 value 0.5 each) against magnitudes 0.5, 1, 2 on the query side.  Every partial sum is a multiple of 2^-13
+// in [2^10, 2^11): exact in fp32.  Bit pattern - bits(2^10) = d << 14 | P << 11 | q: ordered like (distance, train index) for the
+// rows one accumulator slot sees (the kernel feeds the rows so that their index grows with (P, q)), hence min over the raw bit
+// patterns = the reference's first minimum, and the index is decoded once per query block instead of attached to every distance.
+#define MM_BASE 1024.0f
+#define MM_BASE_BITS 0x44800000u
+#define MM_QSTEP 0.0001220703125f        /* 2^-13 */
+#define MM_MAX_ROWS (2047 * MM_BCH)     /* train rows one block pass can number (q < 2048): larger sets take the vector-pipe kernels */
 #define MM_ROW 36       // dwords per staged train row: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | 4 of padding]: lane half h reads its
                         // 16 dwords at 16 h (no shift in the tile loop, where every VALU instruction counts); 144-byte rows make the
                         // ds_read_b128 conflict-free
@@ -243,14 +260,15 @@ __device__ __forceinline__ mm_v8i mm_frag_a4(unsigned w, unsigned w1)
     f[0] = (int)(w & 0x11111111u); f[1] = (int)(w & 0x22222222u); f[2] = (int)(w & 0x44444444u); f[3] = (int)(w1 & 0x44444444u);
     return f;
 }
-// query fragment: magnitude code of 2^(1-t) (0.5 for bit 3), sign = the descriptor bit
+// query fragment: magnitude code of 2^(2-t) (1 for bit 3: E2M1 codes 6, 4, 2, 2 = 4, 2, 1, 1), sign = the descriptor bit; against the
+// train side's 2^(t-1) (2 for bit 3) every set train bit contributes +-2
 __device__ __forceinline__ mm_v4i mm_frag_b4(unsigned q)
 {
     mm_v4i f;
-    f.x = (int)(0x44444444u | ((q & 0x11111111u) << 3));
-    f.y = (int)(0x22222222u | ((q & 0x22222222u) << 2));
-    f.z = (int)(0x11111111u | ((q & 0x44444444u) << 1));
-    f.w = (int)(0x11111111u | (q & 0x88888888u));
+    f.x = (int)(0x66666666u | ((q & 0x11111111u) << 3));
+    f.y = (int)(0x44444444u | ((q & 0x22222222u) << 2));
+    f.z = (int)(0x22222222u | ((q & 0x44444444u) << 1));
+    f.w = (int)(0x22222222u | (q & 0x88888888u));
     return f;
 }
 
@@ -289,6 +307,19 @@ __device__ __forceinline__ void mm_accept(hak_point* p1, const hak_point* __rest
 // KNN = true: the 2-NN search of hak_match_knn2 on the same tiles -- per register slot the two smallest keys (min / max / min per
 // element), nearest neighbour = the smallest key of all slots (smallest index among equal distances), d2 = the smallest
 // distance of every OTHER train point; results go to knn_out[query] = {index, d1, d2, 0} instead of the point records.
+#ifdef HAK_MM_TIMING
+// variant builds only (tools/build_variant_one.sh ... -DHAK_MM_TIMING): shader-clock stamps of block (0, 0)'s wave 0 at the phase
+// boundaries of its first query group
+__device__ unsigned long long hak_mm_times[64];
+__device__ unsigned long long hak_mm_blk[2][1024];          // every block's start / end stamp
+extern "C" int hak_debug_mm_times(unsigned long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(hak_mm_times), sizeof(hak_mm_times)) != hipSuccess; }
+extern "C" int hak_debug_mm_blocks(unsigned long long* host) { return hipMemcpyFromSymbol(host, HIP_SYMBOL(hak_mm_blk), sizeof(hak_mm_blk)) != hipSuccess; }
+#define MM_BLK(k) do { const unsigned b_ = blockIdx.y * gridDim.x + blockIdx.x; if (threadIdx.x == 0 && b_ < 1024) hak_mm_blk[k][b_] = wall_clock64(); } while (0)
+#define MM_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == HAK_MM_TIMING && threadIdx.x == 0 && (i) < 64) hak_mm_times[i] = wall_clock64(); } while (0)
+#else
+#define MM_STAMP(i) do { } while (0)
+#define MM_BLK(k) do { } while (0)
+#endif
 template <bool KNN, int MM_CH>
 __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
@@ -299,6 +330,8 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
 {
     // unsliced: grid (query blocks, pairs); sliced: grid (query blocks, slices, pairs)
     const bool sliced = ticket != nullptr;
+    MM_STAMP(0);
+    MM_BLK(0);
     const int pair = sliced ? blockIdx.z : blockIdx.y;
     const int n1 = n1_dev ? n1_dev[pair * count_stride] : n1_host;
     const int n2 = n2_dev ? n2_dev[pair * count_stride] : n2_host;
@@ -320,23 +353,49 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
     // loads in flight together; byte offsets in 32 bits from the (uniform) set base (n2 < 2^20 records, checked by the launcher)
     const unsigned toff = (unsigned)(threadIdx.x >> 3) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) +
                           8u * (threadIdx.x & 7);
-    const unsigned tmask = (threadIdx.x & 7) == 7 ? 0xFFu : 0xFFFFFFFFu;                // byte 60 only; bytes 61..63 are struct padding
+
     for (int qb = blockIdx.x * 128; qb < n1; qb += gridDim.x * 128) {                   // block-uniform: every wave takes part in the staging
         const int q0 = qb + 32 * wv;                                                    // (a wave past n1 computes on zeros and stores nothing)
-        uint2 pre[MM_CH / 32];
-        auto fetch = [&](int j0) {
+        // ---- the order in which the slice's rows meet the matrix unit (round 5).  The slice [jbeg, jend) is cut into a MAIN part of
+        // nmain = 192 NQ rows and a tail of < 192 rows.  The main part is six SIXTHS of E = 32 NQ rows; chunk q (192 rows = 6 tiles)
+        // holds tile q of every sixth: tile P of chunk q = rows jbeg + P E + 32 q .. + 31.  For a fixed accumulator slot the train
+        // index therefore grows with (P, q) lexicographically -- and that pair is what the accumulator itself carries below its
+        // distance (see the header: P through three spare k positions of the staged row, q through the C operand), so the whole
+        // key epilogue of a tile is ONE unsigned minimum per element, shared between two tiles by v_min3_u32.
+        const int nrows = max(jend - jbeg, 0);
+        const int NQ = nrows / MM_CH;                                                   // chunks of the main part (uniform)
+        const int E = 32 * NQ;                                                          // rows per sixth
+        const int jtail = jbeg + MM_CH * NQ;                                            // first row of the tail
+        // two chunks travel at a time: chunk q + 2 is requested when chunk q starts and written to LDS when chunk q + 1 ends (round 5:
+        // with one chunk in flight the loop was a chain of exposed memory round trips -- a build without any arithmetic still took
+        // 20 of the kernel's 35 us for 10k x 10k).  pre[c & 1] holds chunk c; the chunk loop is unrolled by two, so the index is static.
+        uint2 pre[2][MM_CH / 32];
+        const int NC = NQ + (jtail < jend ? 1 : 0);                                     // chunks incl. the tail (uniform)
+        // chunk c: a main chunk (every row exists) or, c == NQ, the tail (consecutive tiles, rows past jend do not exist)
+        auto fetch = [&](int c, auto par) {
+            constexpr int PAR = decltype(par)::value;
+            if (c < NQ) {
 #pragma unroll
-            for (int i = 0; i < MM_CH / 32; i++) {
-                uint2 v = make_uint2(0u, 0u);
-                if (j0 + (int)(threadIdx.x >> 3) + 32 * i < jend)
-                    v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2) +
-                                                        ((unsigned)(j0 + 32 * i) * (unsigned)sizeof(hak_point) + toff));
-                pre[i] = v;                                         // (raw: masking here would make the wave wait for the load at once)
+                for (int i = 0; i < MM_CH / 32; i++)
+                    pre[PAR][i] = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2) +
+                                                                  ((unsigned)(jbeg + i * E + 32 * c) * (unsigned)sizeof(hak_point) + toff));
+            } else {
+#pragma unroll
+                for (int i = 0; i < MM_CH / 32; i++) {
+                    uint2 v = make_uint2(0u, 0u);
+                    if (jtail + (int)(threadIdx.x >> 3) + 32 * i < jend)
+                        v = *reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts2) +
+                                                            ((unsigned)(jtail + 32 * i) * (unsigned)sizeof(hak_point) + toff));
+                    pre[PAR][i] = v;                                // (raw: masking here would make the wave wait for the load at once)
+                }
             }
         };
-        if (jbeg < jend) fetch(jbeg);                               // the first chunk travels while the query is loaded and expanded
+        using mm_c0 = std::integral_constant<int, 0>;
+        using mm_c1 = std::integral_constant<int, 1>;
+        if (NC > 0) fetch(0, mm_c0{});                              // the first chunks travel while the query is loaded and expanded
+        if (NC > 1) fetch(1, mm_c1{});
         mm_v4i B[8];
-        mm_v16f cinit;
+        float c0;                                                   // 2^10 + 2 |b|: the accumulators' start without the chunk number
         {
             // the lane half's eight dwords 8 h .. 8 h + 7 of query q0 + r (features start at byte 24 of the record: 8-byte aligned)
             unsigned int qd[8];
@@ -354,9 +413,10 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             pb += (unsigned)__shfl_xor((int)pb, 32);
 #pragma unroll
             for (int s = 0; s < 8; s++) B[s] = mm_frag_b4(qd[s]);
-            const float c0 = 8388608.0f + (float)pb;                // 2^23 + |b|: exact
-#pragma unroll
-            for (int i = 0; i < 16; i++) cinit[i] = c0;
+            // the three index positions (bits 8, 12, 16 of descriptor dword 15: struct padding, zero in every query): magnitudes 0.5,
+            // 1, 2 against the staged row's 0.5 -> P / 4
+            if (h) B[7].x = (int)(((unsigned)B[7].x & ~0x000FFF00u) | 0x00042100u);
+            c0 = MM_BASE + 2.0f * (float)pb;
         }
         unsigned best[16], sec[KNN ? 16 : 1];
 #pragma unroll
@@ -372,112 +432,138 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                 TD[4 * c] = v.x; TD[4 * c + 1] = v.y; TD[4 * c + 2] = v.z; TD[4 * c + 3] = v.w;             \
             }                                                                                               \
         }
-        // the epilogue of one tile's accumulator: per element one v_lshl_add_u32 (d << 20 + index base) and one v_min_u32
-#define MM_KEY(v, jb) ((__float_as_uint(v) << 20) + (jb))      /* 0x4B000000 + d: the << 20 leaves d << 20 */
-#define MM_EPI(ACC, J0)                                                                                     \
+        // two finished tiles X, Y -> the slot's smallest (and, 2-NN, second smallest) key: one v_min3_u32 per element and pair of
+        // tiles (2-NN: five instructions).  The accumulators ARE the keys: positive floats order like their bit patterns.
+#define MM_EPI2(X, Y, I)                                                                                    \
         {                                                                                                   \
-            unsigned jb = (unsigned)((J0) + 4 * h);                                                         \
-            asm volatile("" : "+v"(jb));       /* one register: the key stays ONE v_lshl_add_u32 */           \
-            if ((J0) + 32 <= jend) {                                                                        \
-                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
-                    const unsigned key = MM_KEY(ACC[i], jb);                                                \
-                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
-                    best[i] = min(best[i], key);                                                            \
-                }                                                                                           \
-            } else {                        /* last, partial tile: rows past jend do not exist */            \
-                _Pragma("unroll") for (int i = 0; i < 16; i++) {                                            \
-                    const int row = (i & 3) + 8 * (i >> 2);                                                 \
-                    const unsigned key = (int)jb + row < jend ? MM_KEY(ACC[i], jb) : 0xFFFFFFFFu;           \
-                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));                             \
-                    best[i] = min(best[i], key);                                                            \
-                }                                                                                           \
-            }                                                                                               \
+            const unsigned ka = __float_as_uint(X[I]), kb = __float_as_uint(Y[I]);                          \
+            if constexpr (KNN) {                                                                            \
+                const unsigned lo = min(ka, kb), hi = max(ka, kb);                                          \
+                sec[I] = min(min(sec[I], hi), max(best[I], lo));                                            \
+                best[I] = min(best[I], lo);                                                                 \
+                asm volatile("" : "+v"(sec[I]));                                                            \
+            } else best[I] = min(min(best[I], ka), kb);                                                     \
+            /* (the minimum is associative and the compiler knows it: left alone it keeps SIX accumulator sets alive and takes   \
+               all minima of a chunk at its end -- 96 registers and no overlap with the matrix instructions) */                  \
+            asm volatile("" : "+v"(best[I]));                                                               \
         }
-        // one tile: 32 train descriptors j0 .. j0 + 31 from registers TD
-#define MM_TILE(TD, J0)                                                                                     \
+        // the eight matrix instructions of one tile (train rows from TD) into CUR, with the epilogue of the finished tiles EX, EY
+        // between them when EPI (two accumulator elements per MFMA: beside the four v_and of its own fragment that is six vector
+        // instructions per MFMA, what tools/probes/mfma_valu_overlap.hip found to be free)
+#define MM_PIPE(TD, CUR, EPI, EX, EY)                                                                       \
         {                                                                                                   \
-            const mm_v4i b0 = B[0];                                                                         \
-            mm_v16f acc = MM_MFMA(mm_frag_a4(TD[0], TD[8]), (mm_v8i{b0.x, b0.y, b0.z, b0.w, 0, 0, 0, 0}), cinit); \
-            _Pragma("unroll") for (int s = 1; s < 8; s++) {                                                 \
-                const mm_v4i bs = B[s];                                                                     \
-                acc = MM_MFMA(mm_frag_a4(TD[s], TD[8 + s]), (mm_v8i{bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0}), acc); \
-            }                                                                                               \
-            MM_EPI(acc, J0)                                                                                 \
-        }
-        // two tiles in flight (software pipeline): the eight matrix instructions of tile k run with the key epilogue of tile k-1
-        // between them (two accumulator elements = four vector instructions per MFMA, beside the four v_and of its own fragment)
-        // and with tile k+1's ds_read_b128 already issued.  The plain loop above had every wave wait for its LDS reads, run its
-        // MFMAs, wait for the last one and then spend 32 vector instructions on the epilogue: 273 ns per tile and SIMD, although
-        // 8 vector instructions per MFMA cost 17-19 ns per MFMA when they are interleaved (tools/probes/mfma_valu_overlap.hip).
-#define MM_EPI2(PREV, JB, I)                                                                                \
-        {                                                                                                   \
-            const unsigned key = MM_KEY(PREV[I], JB);                                                       \
-            if constexpr (KNN) sec[I] = min(sec[I], max(best[I], key));                                     \
-            best[I] = min(best[I], key);                                                                    \
-        }
-#define MM_PIPE(TD, CUR, PREV, JP, EPI)                                                                     \
-        {                                                                                                   \
-            unsigned jb = (unsigned)((JP) + 4 * h);                                                         \
-            asm volatile("" : "+v"(jb));                                                                    \
             _Pragma("unroll") for (int s = 0; s < 8; s++) {                                                 \
                 const mm_v4i bs = B[s];                                                                     \
                 const mm_v8i bf = {bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0};                                     \
                 if (s == 0) CUR = MM_MFMA(mm_frag_a4(TD[0], TD[8]), bf, cinit);                             \
                 else CUR = MM_MFMA(mm_frag_a4(TD[s], TD[8 + s]), bf, CUR);                                  \
-                if (EPI) { MM_EPI2(PREV, jb, 2 * s) MM_EPI2(PREV, jb, 2 * s + 1) }                          \
+                if (EPI) { MM_EPI2(EX, EY, 2 * s) MM_EPI2(EX, EY, 2 * s + 1) }                              \
                 __builtin_amdgcn_sched_barrier(0);                                                          \
             }                                                                                               \
         }
-        auto stage = [&](int buf) {
+        // rows of chunk buffer `buf`: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | pad]: lane half h reads its 16 dwords at 16 h.
+        // The thread that holds dword 15 plants the tile's number P (tail: 7) into its bits 8, 12, 16.
+        auto stage = [&](int c, auto par) {                         // chunk c (held in pre[c & 1]) -> tile[c & 1]
+            constexpr int PAR = decltype(par)::value;
+            const bool tail = c >= NQ;
 #pragma unroll
             for (int i = 0; i < MM_CH / 32; i++) {
-                const uint2 v = make_uint2(pre[i].x, pre[i].y & tmask);
-                // row = [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | pad]: lane half h reads its 16 dwords at 16 h
-                unsigned int* row = tile[buf] + ((threadIdx.x >> 3) + 32 * i) * MM_ROW + 16 * ((threadIdx.x & 7) >> 2) + 2 * (threadIdx.x & 3);
+                const unsigned P = tail ? 7u : (unsigned)i;
+                const unsigned pbits = ((P & 1u) << 8) | ((P & 2u) << 11) | ((P & 4u) << 14);
+                const uint2 v = make_uint2(pre[PAR][i].x, (threadIdx.x & 7) == 7 ? (pre[PAR][i].y & 0xFFu) | pbits : pre[PAR][i].y);
+                unsigned int* row = tile[PAR] + ((threadIdx.x >> 3) + 32 * i) * MM_ROW + 16 * ((threadIdx.x & 7) >> 2) + 2 * (threadIdx.x & 3);
                 *reinterpret_cast<uint2*>(row) = v;
                 *reinterpret_cast<uint2*>(row + 8) = make_uint2(v.x >> 1, v.y >> 1);
             }
         };
         __syncthreads();                                            // (the previous query group's chunks have been read)
-        if (jbeg < jend) stage(0);
+        MM_STAMP(1);
+        if (NC > 0) stage(0, mm_c0{});
         __syncthreads();
-        int buf = 0;
-        mm_v16f accA = cinit, accB = cinit;                         // accumulators of the even / odd tile of a pair of tiles
-        bool have_prev = false;                                     // accB holds a finished full tile whose epilogue is still due (uniform)
-        int jprev = 0;                                              // ... its first train row
-        for (int j0 = jbeg; j0 < jend; j0 += MM_CH, buf ^= 1) {
-            const bool more = j0 + MM_CH < jend;                    // (uniform)
-            if (more) fetch(j0 + MM_CH);                            // lands while this chunk is multiplied
-            const int nt = min(MM_CH / 32, (jend - j0 + 31) >> 5);  // tiles of this chunk (uniform)
-            const int npair = min(MM_CH / 32, (jend - j0) >> 5) >> 1;   // pairs of FULL tiles (every chunk but the slice's last: all of it)
+        MM_STAMP(2);
+        mm_v16f cinit;
+#pragma unroll
+        for (int i = 0; i < 16; i++) cinit[i] = c0;
+        mm_v16f X0 = cinit, X1 = cinit, X2 = cinit;                 // three accumulator sets: tile t of the stream lives in set t mod 3
+        bool pend = false;                                          // X1, X2 hold the last two tiles of the previous chunk (uniform)
+        // one main chunk q out of tile[q & 1]: six tiles; the minima of tiles (4, 5) of the previous chunk ride on tile 0, those of
+        // (0, 1) on tile 2, those of (2, 3) on tile 4
+        auto chunk = [&](int q, auto par) {
+            constexpr int PAR = decltype(par)::value;
+            using nxt = std::integral_constant<int, PAR ^ 1>;
+            // chunk q + 1 (requested two chunks ago) goes to the other buffer FIRST -- its last readers passed the barrier at the end of
+            // chunk q - 1 -- so that the LDS writes run beside this chunk's matrix instructions and the barrier below only collects
+            // stragglers (staging behind the tiles left the matrix unit idle for 0.55 of every 2.1 us); then chunk q + 2 is requested
+            if (q + 1 < NC) stage(q + 1, nxt{});
+            if (q + 2 < NC) fetch(q + 2, par);                      // (pre[PAR] went to LDS one chunk ago)
             unsigned int ta[16], tb[16];
-            if (npair) MM_READ(buf, 0, ta)
-            for (int kk = 0; kk < npair; kk++) {
-                const int J = j0 + 64 * kk;
-                MM_READ(buf, 2 * kk + 1, tb)
-                if (have_prev) MM_PIPE(ta, accA, accB, jprev, true)
-                else MM_PIPE(ta, accA, accB, jprev, false)
-                if (kk + 1 < npair) MM_READ(buf, 2 * kk + 2, ta)
-                MM_PIPE(tb, accB, accA, J, true)
-                jprev = J + 32;
-                have_prev = true;
-            }
-            if (2 * npair < nt) {                                   // the slice's last chunk: an odd full tile and / or the partial tile
-                if (have_prev) { MM_EPI(accB, jprev) have_prev = false; }
-                for (int k = 2 * npair; k < nt; k++) {
-                    MM_READ(buf, k, ta)
-                    MM_TILE(ta, j0 + 32 * k)
+            MM_READ(PAR, 0, ta)
+            MM_READ(PAR, 1, tb)
+            if (pend) MM_PIPE(ta, X0, true, X1, X2)
+            else MM_PIPE(ta, X0, false, X1, X2)
+            MM_READ(PAR, 2, ta)
+            MM_PIPE(tb, X1, false, X0, X0)
+            MM_READ(PAR, 3, tb)
+            MM_PIPE(ta, X2, true, X0, X1)
+            MM_READ(PAR, 4, ta)
+            MM_PIPE(tb, X0, false, X1, X1)
+            MM_READ(PAR, 5, tb)
+            MM_PIPE(ta, X1, true, X2, X0)
+            MM_PIPE(tb, X2, false, X0, X0)
+            pend = true;
+#pragma unroll
+            for (int i = 0; i < 16; i++) cinit[i] += MM_QSTEP;      // the next chunk's number (exact: one ulp of the accumulators' binade)
+            MM_STAMP(3 + 2 * q);
+            __syncthreads();
+            MM_STAMP(4 + 2 * q);
+        };
+        for (int q = 0; q < NQ; q += 2) {
+            chunk(q, mm_c0{});
+            if (q + 1 < NQ) chunk(q + 1, mm_c1{});
+        }
+        if (pend) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) MM_EPI2(X1, X2, i)
+        }
+        // the tail: up to six consecutive tiles, tile k carries (P, q) = (7, k); rows past jend do not exist
+        if (jtail < jend) {
+            const int nt = (jend - jtail + 31) >> 5;
+            const unsigned int* tbase = tile[NQ & 1];
+            for (int k = 0; k < nt; k++) {
+                unsigned int ta[16];
+                {
+                    const uint4* row = reinterpret_cast<const uint4*>(tbase + (32 * k + r) * MM_ROW + 16 * h);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { const uint4 v = row[c]; ta[4 * c] = v.x; ta[4 * c + 1] = v.y; ta[4 * c + 2] = v.z; ta[4 * c + 3] = v.w; }
+                }
+#pragma unroll
+                for (int i = 0; i < 16; i++) cinit[i] = c0 + (float)k * MM_QSTEP;
+                MM_PIPE(ta, X0, false, X0, X0)
+                const int jb = jtail + 32 * k + 4 * h;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned key = jb + (i & 3) + 8 * (i >> 2) < jend ? __float_as_uint(X0[i]) : 0xFFFFFFFFu;
+                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));
+                    best[i] = min(best[i], key);
                 }
             }
-            if (more) stage(buf ^ 1);                               // (that buffer was last read a chunk ago, before the barrier below)
-            __syncthreads();
+            __syncthreads();                                        // (the tail's buffer is free for the next query group's first chunk)
         }
-        if (have_prev) MM_EPI(accB, jprev)
+        MM_STAMP(40);
 #undef MM_PIPE
 #undef MM_EPI2
-#undef MM_TILE
-#undef MM_EPI
-#undef MM_KEY
+        // decode: bits - bits(2^10) = d 2^14 + P 2^11 + q  ->  d << 20 | first row of the slot's lane half in that tile
+        auto decode = [&](unsigned k) -> unsigned {
+            if (k == 0xFFFFFFFFu) return k;
+            const unsigned u = k - MM_BASE_BITS;
+            const unsigned P = (u >> 11) & 7u, q = u & 2047u;
+            const unsigned row = (unsigned)jbeg + min(P, 6u) * (unsigned)E + 32u * q + 4u * (unsigned)h;
+            return ((u >> 14) << 20) + row;
+        };
+#pragma unroll
+        for (int i = 0; i < 16; i++) best[i] = decode(best[i]);
+#pragma unroll
+        for (int i = 0; i < (KNN ? 16 : 0); i++) sec[i] = decode(sec[i]);
 #undef MM_READ
         const int qi = q0 + r;
         if constexpr (KNN) {
@@ -533,14 +619,22 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                 const int q = qb + (int)threadIdx.x;
                 if (threadIdx.x < 128 && q < n1) {
                     unsigned M1 = 0xFFFFFFFFu, M2 = 0xFFFFFFFFu;
-                    for (int s = 0; s < (int)gridDim.y; s++) {
-                        const unsigned long long pv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)s * n1_pad + q),
-                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned a1 = (unsigned)pv, a2 = (unsigned)(pv >> 32);
-                        // union of {M1, M2} and {a1, a2}, each ascending: its two smallest
-                        const unsigned lo = min(M1, a1), hi = max(M1, a1);
-                        M2 = min(hi, lo == M1 ? M2 : a2);
-                        M1 = lo;
+                    for (int s0 = 0; s0 < (int)gridDim.y; s0 += 8) {        // (eight summaries in flight: see the 1-NN merge below)
+                        unsigned long long pv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            pv[j] = s0 + j < (int)gridDim.y
+                                        ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)(s0 + j) * n1_pad + q),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0xFFFFFFFFFFFFFFFFull;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const unsigned a1 = (unsigned)pv[j], a2 = (unsigned)(pv[j] >> 32);
+                            // union of {M1, M2} and {a1, a2}, each ascending: its two smallest
+                            const unsigned lo = min(M1, a1), hi = max(M1, a1);
+                            M2 = min(hi, lo == M1 ? M2 : a2);
+                            M1 = lo;
+                        }
                     }
                     out[q] = M1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
                                                : make_int4((int)(M1 & 0xFFFFFu), (int)(M1 >> 20), M2 == 0xFFFFFFFFu ? 512 : (int)(M2 >> 20), 0);
@@ -578,24 +672,36 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             // s_waitcnt orders them in front of the ticket)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             __syncthreads();
+            MM_STAMP(41);
             if (threadIdx.x == 0) {
                 const int tk = __hip_atomic_fetch_add(&ticket[qb >> 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 s_last = tk == (int)gridDim.y - 1;
                 if (s_last) __hip_atomic_store(&ticket[qb >> 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             __syncthreads();
+            MM_STAMP(42);
             if (s_last) {                                           // (block-uniform) the last block of the query block decides
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 const int q = qb + (int)threadIdx.x;
                 if (threadIdx.x < 128 && q < n1) {
                     unsigned K = 0xFFFFFFFFu, M = 0u;
-                    for (int s = 0; s < (int)gridDim.y; s++) {
-                        const unsigned long long pv = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)s * n1_pad + q),
-                                                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        const unsigned k2 = (unsigned)pv, m2 = (unsigned)(pv >> 32);
-                        if ((k2 >> 20) < (K >> 20)) M = m2;          // a smaller distance: its classes alone attain it
-                        else if ((k2 >> 20) == (K >> 20)) M |= m2;
-                        K = min(K, k2);
+                    // (eight slices' summaries in flight at a time: one memory round trip instead of one per slice -- the finishing
+                    // blocks are the kernel's tail, round 5: they ended 4-8 us after the others)
+                    for (int s0 = 0; s0 < (int)gridDim.y; s0 += 8) {
+                        unsigned long long pv[8];
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            pv[j] = s0 + j < (int)gridDim.y
+                                        ? __hip_atomic_load(reinterpret_cast<const unsigned long long*>(part + (long)(s0 + j) * n1_pad + q),
+                                                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                        : 0xFFFFFFFFull;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const unsigned k2 = (unsigned)pv[j], m2 = (unsigned)(pv[j] >> 32);
+                            if ((k2 >> 20) < (K >> 20)) M = m2;      // a smaller distance: its classes alone attain it
+                            else if ((k2 >> 20) == (K >> 20)) M |= m2;
+                            K = min(K, k2);
+                        }
                     }
                     hak_point* p1 = pts1 + q;
                     const int dmin = (int)(K >> 20);
@@ -615,6 +721,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         for (int k = 0; k < 8; k++) { all[k] = cls[k]; all[8 + k] = (unsigned)__shfl_xor((int)cls[k], 32); }
         if (h == 0 && qi < n1) mm_accept(pts1 + qi, pts2, all, n2);
     }
+    MM_BLK(1);
 }
 
 // accept rule of gHammingMatch (akazed.cu:2190-2223) on the merged class minima of the sliced search of the VALU kernel
@@ -878,7 +985,8 @@ static int mfma_slices(int gx, int n2, int* rows_per_slice, int want_blocks)
     int slices = env > 0 ? env : (want_blocks + gx / 2) / gx;
     if (slices > tiles / 8) slices = tiles / 8;                     // at least 8 tiles (one LDS chunk) per slice
     if (slices < 1) slices = 1;
-    const int tps = (tiles + slices - 1) / slices;
+    int tps = (tiles + slices - 1) / slices;
+    tps = (tps + 5) / 6 * 6;                                        // whole 6-tile chunks: only the last slice has a tail
     *rows_per_slice = tps * 32;
     return (tiles + tps - 1) / tps;
 }
@@ -887,7 +995,8 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
                      int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride, HakMatchScratch* sc)
 {
     const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call, as in hak_launch_match)
-    if (!(env_valu && atoi(env_valu) != 0) && nB_host < (1 << 20)) {
+    // (with device-side counts nA_host / nB_host carry the CAPACITY of the sets)
+    if (!(env_valu && atoi(env_valu) != 0) && nB_host <= MM_MAX_ROWS) {
         // the matrix-core kernel with its 2-NN epilogue (the point records are only read: ptsA is not written)
         int gx = nA_dev ? 83 : (nA_host + 127) / 128;
         if (gx < 1) gx = 1;
@@ -897,7 +1006,7 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
             int rps = 0;
             const int slices = mfma_slices(gx, nB_host, &rps, 512);
             if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
-                k_match_mfma<true, 256><<<dim3(gx, slices), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nullptr, nullptr, nA_host, nB_host, 0, 0,
+                k_match_mfma<true, MM_BCH><<<dim3(gx, slices), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nullptr, nullptr, nA_host, nB_host, 0, 0,
                                                                     2, rps, out, 0, sc->ticket, sc->part, gx * 128);
                 return;
             }
@@ -936,7 +1045,7 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
 {
     // k_match_mfma: a wave = 32 queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
     const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call: the tests run both kernels in one process)
-    const bool valu = env_valu && atoi(env_valu) != 0;
+    const bool valu = (env_valu && atoi(env_valu) != 0) || n2_host > MM_MAX_ROWS;       // (device-side counts: n2_host = the capacity)
     const int nq = n1_dev ? 0 : n1_host;
     const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;    // (k_match only: queries per thread)
     const int qb = valu ? (two ? 2 * MQ : MQ) : 128;                // queries per block

@@ -106,6 +106,72 @@ __global__ __launch_bounds__(256) void k_stream_probe(const float* __restrict__ 
     }
 }
 
+// ---- the streaming Hessian's access shape with the arithmetic taken out (k_hessian_stream<float, S, false>, kernels_hessian_stream.hip):
+// strips of 256 - 2 M columns (M = 4 / 8 / 8 / 12 for S = 1..4), row segments cut by hak_stream_rows, 2 S + 1 warm-up rows above and
+// 2 S rows below every segment, one 16-byte load per lane and row with PD rows in flight, and per row the interleaved {Lx, Ly} store
+// exactly as the kernel issues it: the lane's four pixels of both derivatives turned through per-wave LDS (one staging row + a ring
+// row), read back as pixel pairs, two dense 16-byte nt buffer stores per lane.  The block carries the kernel's LDS footprint
+// (rings of R = 2 S + 1 + PD rows per wave + staging + candidate buffer) and its __launch_bounds__ occupancy target, so it runs at
+// the waves per SIMD the real kernel reaches (3 for S <= 3, 2 for S = 4).  12 B/px compulsory: what the class could do if its
+// ~250-300 vector instructions per row cost nothing.
+template <int S>
+__global__ __launch_bounds__(256, (S <= 3 ? 3 : 2)) void k_hess_probe(const float* __restrict__ src, float* __restrict__ dxy, long stride, int w, int h,
+                                                                     int p, int ry, int nbx, int nby, int nimg)
+{
+    constexpr int PD = S == 3 ? 1 : 2, R = 2 * S + 1 + PD, M = S == 1 ? 4 : S == 4 ? 12 : 8, XV = 256 - 2 * M;
+    __shared__ float4 yring[4 * R * 64];
+    __shared__ float4 xstage[4 * 64];
+    __shared__ unsigned long long cbuf[4 * 256];
+    int bx, by, img;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, img)) return;
+    const float* L = src + (long)img * stride;
+    float* D = dxy + (long)img * stride * 2;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (threadIdx.x == 0) cbuf[0] = 0;                      // (keeps the candidate buffer allocated)
+    const int x0 = bx * XV - M + 4 * lane;
+    const int ybeg = (by * 4 + wv) * ry;
+    if (ybeg >= h) return;
+    const int yend = min(ybeg + ry, h);
+    const int xl = min(max(x0, 0), p - 4);
+    const int sx = x0 - 4 * lane;
+    auto pair_off = [&](int q) -> unsigned {
+        const int x = sx + q;
+        return q >= M && q < M + XV && x >= 0 && x < w ? (unsigned)x * 8u : HAK_BUF_OOB;
+    };
+    const unsigned o0 = pair_off(2 * lane), o2 = pair_off(128 + 2 * lane);
+    const __amdgpu_buffer_rsrc_t r = hak_buf_rsrc(D);
+    float4* Y = yring + wv * R * 64;
+    float4* XS = xstage + wv * 64;
+    const int t0 = max(0, ybeg - 1 - 2 * S), tend = yend + 2 * S;
+    float4 q[PD + 1];
+#pragma unroll
+    for (int i = 0; i < PD; i++) q[i] = hak_load_stream(reinterpret_cast<const float4*>(L + (unsigned)(min(t0 + i, h - 1) * p + xl)));
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int slot = 0;
+    for (int t = t0; t <= tend; t += PD + 1) {
+#pragma unroll
+        for (int u = 0; u <= PD; u++) {
+            const int row = t + u;
+            q[(u + PD) % (PD + 1)] = hak_load_stream(reinterpret_cast<const float4*>(L + (unsigned)(min(row + PD, h - 1) * p + xl)));
+            const float4 c = q[u];
+            acc.x += c.x; acc.y += c.y; acc.z += c.z; acc.w += c.w;
+            const int b = row - S;                              // the derivative row this iteration stores
+            __builtin_amdgcn_wave_barrier();
+            XS[lane] = c;
+            Y[slot * 64 + lane] = acc;
+            __builtin_amdgcn_wave_barrier();
+            const float2* xs2 = reinterpret_cast<const float2*>(XS);
+            const float2* ys2 = reinterpret_cast<const float2*>(Y + slot * 64);
+            const float2 xa = xs2[lane], ya = ys2[lane], xb = xs2[64 + lane], yb = ys2[64 + lane];
+            const unsigned roff = b >= ybeg && b < yend ? (unsigned)(b * p) * 8u : HAK_BUF_OOB;
+            hak_buf_store_nt(r, o0 + roff, make_float4(xa.x, ya.x, xa.y, ya.y));
+            hak_buf_store_nt(r, o2 + roff, make_float4(xb.x, yb.x, xb.y, yb.y));
+            slot = slot + 1 == R ? 0 : slot + 1;
+        }
+    }
+}
+
 static int probe_time(hipEvent_t a, hipEvent_t b, int iters, double* ms)
 {
     float t = 0;
@@ -211,6 +277,43 @@ int hak_launch_stream_probe(int w, int h, int nimg, int nwrite, int warm, int it
     (void)hipEventRecord(b, nullptr);
     const int rc = probe_time(a, b, iters, ms) || hipGetLastError() != hipSuccess;
     *bytes = (1.0 + nwrite) * 4.0 * (double)w * h * nimg;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    (void)hipFree(s); (void)hipFree(d);
+    return rc;
+}
+
+// the Hessian class's launch of one level: `nimg` planes of w x h, dilation S = step (1..4); *bytes = 12 B/px compulsory
+int hak_launch_hess_probe(int w, int h, int nimg, int step, int iters, double* ms, double* bytes)
+{
+    if ((w & 3) || w < 16 || h < 8 || nimg < 1 || step < 1 || step > 4 || iters < 1) return 1;
+    const int p = (w + 63) / 64 * 64;
+    const long plane = (long)h * p;
+    if (2 * plane * 4 >= (long)HAK_BUF_OOB) return 1;
+    float *s = nullptr, *d = nullptr;
+    if (hipMalloc((void**)&s, sizeof(float) * (size_t)plane * nimg) != hipSuccess) return 1;
+    if (hipMalloc((void**)&d, sizeof(float) * (size_t)plane * nimg * 2) != hipSuccess) { (void)hipFree(s); return 1; }
+    (void)hipMemset(s, 0, sizeof(float) * (size_t)plane * nimg);
+    const int M = step == 1 ? 4 : step == 4 ? 12 : 8, XV = 256 - 2 * M;
+    const int gx = (w + XV - 1) / XV;
+    const int ry = hak_stream_rows(h, (long)gx * nimg, 16);
+    const int gy = (h + 4 * ry - 1) / (4 * ry);
+    const unsigned grid = hak_xcd_grid(gx, gy, nimg);
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    auto launch = [&]() {
+        switch (step) {
+        case 1: k_hess_probe<1><<<grid, 256>>>(s, d, plane, w, h, p, ry, gx, gy, nimg); break;
+        case 2: k_hess_probe<2><<<grid, 256>>>(s, d, plane, w, h, p, ry, gx, gy, nimg); break;
+        case 3: k_hess_probe<3><<<grid, 256>>>(s, d, plane, w, h, p, ry, gx, gy, nimg); break;
+        default: k_hess_probe<4><<<grid, 256>>>(s, d, plane, w, h, p, ry, gx, gy, nimg); break;
+        }
+    };
+    launch();
+    (void)hipEventRecord(a, nullptr);
+    for (int i = 0; i < iters; i++) launch();
+    (void)hipEventRecord(b, nullptr);
+    const int rc = probe_time(a, b, iters, ms) || hipGetLastError() != hipSuccess;
+    *bytes = 12.0 * (double)w * h * nimg;
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     (void)hipFree(s); (void)hipFree(d);
     return rc;

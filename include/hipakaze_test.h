@@ -78,6 +78,12 @@ int hak_op_gather_probe(long bytes, int blocks, int per_lane, int iters, double*
  * average kernel time: the data-movement floor of k_fed_sf / k_fed_multi at that launch geometry. */
 int hak_op_stream_probe(int w, int h, int nimg, int nwrite, int warm_rows, int iters, double* ms_per_launch, double* gbytes_per_s);
 
+/* hak_op_hess_probe: the streaming Hessian's access shape with the arithmetic taken out (k_hessian_stream, dilation `step` 1..4): its strips,
+ * row segments and warm-up rows, 4 B/px read, the interleaved {Lx, Ly} plane written through the same per-wave LDS turn and the same
+ * two dense 16-byte nt buffer stores per lane and row, at the kernel's LDS footprint and occupancy target; *gbytes_per_s = 12 B/px
+ * compulsory / average kernel time: the data-movement floor of the Hessian class at that launch geometry. */
+int hak_op_hess_probe(int w, int h, int nimg, int step, int iters, double* ms_per_launch, double* gbytes_per_s);
+
 #ifdef __cplusplus
 }
 #endif
