@@ -137,6 +137,7 @@ HakKnobs hak_knobs_from_env()
     HakKnobs k;
     if (const char* e = getenv("HAK_HESS_STREAM")) k.hess_stream = atoi(e);
     if (const char* e = getenv("HAK_BASE_STREAM")) k.base_stream = atoi(e);
+    if (const char* e = getenv("HAK_BASE_HIST")) k.base_hist = atoi(e);
     if (const char* e = getenv("HAK_HESS_CBUF")) { const int v = atoi(e); k.hess_cbuf = v < 1 ? 1 : (v > 256 ? 256 : v); }
     if (const char* e = getenv("HAK_DESC_ORDER")) { const int v = atoi(e); k.desc_order = v < 0 ? 0 : (v > 255 ? 255 : v); }
     if (const char* e = getenv("HAK_DESC_PLAN")) k.desc_plan = atoi(e);

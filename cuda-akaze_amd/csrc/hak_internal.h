@@ -248,6 +248,9 @@ __host__ __device__ __forceinline__ float hak_expf(float x)
 struct HakKnobs {
     int hess_stream = 1;          // HAK_HESS_STREAM: register-streaming Hessian kernel 0 never / 1 by the size rule / 2 always where it applies
     int base_stream = 1;          // HAK_BASE_STREAM: same for pass A of the octave-0 prologue
+    int base_hist = 0;            // HAK_BASE_HIST=1: the streaming prologue finds the (lattice) contrast maximum first and bins the gradient on the
+                                  // fly (no gradient plane, no histogram pass).  Off by default: half the bytes, 4 % SLOWER (the pass is bound by
+                                  // vector issue; kernels_base_stream.hip)
     int hess_cbuf = 256;          // HAK_HESS_CBUF: staged candidates per block of the tile kernel (1..256; tests drive the overflow path)
     int desc_order = 4;           // HAK_DESC_ORDER: image group size of the describe kernels' block order
     int desc_plan = 1;            // HAK_DESC_PLAN: planned MLDB kernel (k_describe_runs) on / off

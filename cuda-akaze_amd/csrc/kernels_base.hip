@@ -310,7 +310,12 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     while (tpb > 1 && (long)ntx * ((nty + tpb - 1) / tpb) * nimg < 4096) tpb >>= 1;
     const int nby = (nty + tpb - 1) / tpb;
     const unsigned grid = hak_xcd_grid(ntx, nby, nimg);
-    if (hak_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, taps1, taps_base, R, state, knobs.base_stream)) {
+    // the streaming form with the histogram inside (round 5): contrast maximum first, from the lattice points alone, then ONE pass
+    if (knobs.base_hist && hak_launch_base_stream(st, img, img_stride, sp, lt, nullptr, stride, w, h, p, nimg, taps1, taps_base, R, state, knobs.base_stream)) {
+        k_kcontrast2<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
+        return true;
+    }
+    if (grad_scratch && hak_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, taps1, taps_base, R, state, knobs.base_stream)) {
         // pass A done by the streaming kernel
     } else
     switch (R) {

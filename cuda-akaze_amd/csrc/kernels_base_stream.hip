@@ -11,7 +11,18 @@
 //     Lt row t-R     = column pass over the base ring (2R+1 rows),
 //     smooth row t-2 = column pass over the sigma=1 ring (5 rows), kept in a 3-row ring with its two x-neighbour columns,
 //     gradient row t-3 = Scharr magnitude of smooth rows t-4 .. t-2.
-// No LDS, no barriers; 4 B/px read, 8 B/px written.  Reflect-101 is applied to the INPUT, as the tile kernels do
+// No LDS, no barriers; 4 B/px read, 8 B/px written.
+// Round 5 (HIST): the reference's contrast maximum is a maximum over the 16-px lattice (hak_on_lattice), so it can be had BEFORE
+// this pass from 1 / 256 of the pixels (k_lattice_hmax below: the sigma=1 image and its Scharr magnitude at the lattice points
+// only, same expressions); the pass then bins the gradient magnitude on the fly (LDS histograms, flushed per block) and neither
+// writes the gradient plane nor needs the second pass that re-read it: 4 B/px read, 4 B/px written.
+// MEASURED, OFF BY DEFAULT (HAK_BASE_HIST=1 switches it on; bit-identical, in the GPU tests' alternative list): half the bytes and
+// no gain -- prologue class per 512 x 1080p images 3.69-3.73 ms two-pass vs 3.85-3.88 ms (3.97-4.00 with run-aggregated atomics).
+// The pass is bound by vector issue, not by HBM: ~300 vector instructions per row and wave (75 per pixel: two separable Gaussians
+// and the Scharr magnitude in the reference's unfused mul / add order) = 2.57 ms of issue at two waves per SIMD against 2.96 ms
+// measured and a data-movement floor of 2.4 ms; the binning adds ~10 instructions per pixel to exactly that budget, more than the
+// dedicated histogram pass (0.70 ms, 6 TB/s read) costs beside it.
+// Reflect-101 is applied to the INPUT, as the tile kernels do
 // (rows: the row index is reflected; columns: the lane just outside the image loads the mirrored pixels), and every
 // stage then indexes plainly.  w % 4 == 0, R <= 4 (a deeper halo than one lane needs the tile kernel).
 #include "fed_common.h"
@@ -95,6 +106,22 @@ __device__ __forceinline__ int bsm_mag(int ul, int uc, int ur, int cl, int cr, i
 }
 __device__ __forceinline__ float bsm_max(float a, float b) { return fmaxf(a, b); }
 __device__ __forceinline__ int bsm_max(int a, int b) { return max(a, b); }
+// histogram bin of one gradient magnitude (akazed.cu:924-928 / 3319-3326); F = the per-image factor (float path: NBINS / hmax as a
+// double -- the exact double product truncated = __fmul_rz + float -> int; FAST path: the 16.16 factor, wrapping product)
+template <typename V> struct BsHistF;
+template <> struct BsHistF<float> { double f; };
+template <> struct BsHistF<int> { int f; };
+__device__ __forceinline__ int bsm_bin(float g, const BsHistF<float>& F)
+{
+    const int hi = (int)((double)g * F.f);
+    return hi >= HAK_NBINS ? HAK_NBINS - 1 : hi;
+}
+__device__ __forceinline__ int bsm_bin(int g, const BsHistF<int>& F)
+{
+    const int hi = (int)((unsigned)g * (unsigned)F.f) >> 16;
+    return hi >= HAK_NBINS ? HAK_NBINS - 1 : (hi < 0 ? 0 : hi);
+}
+#define BS_HIST_COPIES 8       // LDS histograms per block, selected by lane (LDS atomics on one address serialise)
 
 // Lt and the gradient plane as one raw buffer (lower pointer) + byte offsets: unconditional, countable stores (fed_common.h)
 struct BsmOut { __amdgpu_buffer_rsrc_t r; unsigned lt, gr; };    // per-lane byte offsets (column + plane) or HAK_BUF_OOB
@@ -110,11 +137,11 @@ struct BsmState {
     V tmax;
 };
 
-template <typename V, int R, int U, bool XE>
+template <typename V, int R, int U, bool XE, bool HIST>
 __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT,
                                          V* __restrict__ GR, const int sp, const int p, const int xl, const int x0, const int h,
                                          const int ybeg, const int yend, const bool owns, const bool lat, const int hcov, const bool edge, const int c0, const int c1,
-                                         const int c2, const int c3, const BsmTaps<V>& tp, const BsmOut& O)
+                                         const int c2, const int c3, const BsmTaps<V>& tp, const BsmOut& O, int* mine, const BsHistF<V>& HF)
 {
     using V4 = typename BsT<V>::V4;
     // ---- image row t arrives (virtual rows outside the image are their mirror rows); request row t + PD
@@ -191,15 +218,26 @@ __device__ __forceinline__ void bsm_iter(BsmState<V>& S, const int t, const type
         g.z = bsm_mag(su.y, su.z, su.w, sc.y, sc.w, sd.y, sd.z, sd.w);
         g.w = bsm_mag(su.z, su.w, uR, sc.z, cR, sd.z, sd.w, dR);
         const bool inr = b >= ybeg && b < yend;
-        hak_buf_store_nt(O.r, O.gr + (inr ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
-        // the reference's maximum runs over the 16-px lattice only (hak_on_lattice): x0 % 4 == 0, so only g.x can be on it
-        if (inr && lat && (b & 15) == 0 && b < hcov) S.tmax = bsm_max(S.tmax, g.x);
+        if constexpr (HIST) {
+            // the maximum is known (k_lattice_hmax ran first): bin the row's magnitudes instead of storing them
+            if (inr && owns) {
+                // (counting runs of equal bins in registers -- a lane's four pixels mostly share one -- and issuing one atomic per run
+                // was measured slower still: the pass is short of vector issue slots, not of LDS atomic throughput)
+                atomicAdd(&mine[bsm_bin(g.x, HF)], 1); atomicAdd(&mine[bsm_bin(g.y, HF)], 1);
+                atomicAdd(&mine[bsm_bin(g.z, HF)], 1); atomicAdd(&mine[bsm_bin(g.w, HF)], 1);
+            }
+        } else {
+            hak_buf_store_nt(O.r, O.gr + (inr ? (unsigned)(b * p) * (unsigned)sizeof(V) : HAK_BUF_OOB), g);
+            // the reference's maximum runs over the 16-px lattice only (hak_on_lattice): x0 % 4 == 0, so only g.x can be on it
+            if (inr && lat && (b & 15) == 0 && b < hcov) S.tmax = bsm_max(S.tmax, g.x);
+        }
     }
 }
 
-template <typename V, int R, bool XE>
+template <typename V, int R, bool XE, bool HIST>
 __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s, V* __restrict__ LT, V* __restrict__ GR, int sp, int p,
-                                       int w, int h, int x0, int ybeg, int yend, bool owns, const BsmTaps<V>& tp)
+                                       int w, int h, int x0, int ybeg, int yend, bool owns, const BsmTaps<V>& tp, int* mine,
+                                       const BsHistF<V>& HF)
 {
     using V4 = typename BsT<V>::V4;
     constexpr int RR = R < 3 ? 3 : R;                       // rows of context above and below the segment
@@ -209,11 +247,11 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
     const int c0 = hak_refl(x0, w), c1 = hak_refl(x0 + 1, w), c2 = hak_refl(x0 + 2, w), c3 = hak_refl(x0 + 3, w);
     BsmOut O;
     {
-        V* lo = LT < GR ? LT : GR;
+        V* lo = HIST || LT < GR ? LT : GR;
         O.r = hak_buf_rsrc(lo);
         const unsigned xb = (unsigned)x0 * (unsigned)sizeof(V);
         O.lt = owns ? xb + (unsigned)((LT - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
-        O.gr = owns ? xb + (unsigned)((GR - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
+        O.gr = owns && !HIST ? xb + (unsigned)((GR - lo) * (long)sizeof(V)) : HAK_BUF_OOB;
     }
     const int t0 = ybeg - RR;
     const int tend = yend - 1 + RR;
@@ -231,60 +269,132 @@ __device__ __forceinline__ V bsm_strip(const typename BsT<V>::In* __restrict__ s
 #pragma unroll
     for (int i = 0; i < BS_PD; i++) S.Lq[i] = bsm_load<V, XE>(s, hak_refl(min(t0 + i, h + 3), h), sp, xl, edge, c0, c1, c2, c3);
     for (int tb = t0; tb <= tend; tb += BS_RING) {
-        bsm_iter<V, R, 0, XE>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 1, XE>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 2, XE>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 3, XE>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 4, XE>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 5, XE>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 6, XE>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 7, XE>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
-        bsm_iter<V, R, 8, XE>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O);
+        bsm_iter<V, R, 0, XE, HIST>(S, tb + 0, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 1, XE, HIST>(S, tb + 1, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 2, XE, HIST>(S, tb + 2, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 3, XE, HIST>(S, tb + 3, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 4, XE, HIST>(S, tb + 4, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 5, XE, HIST>(S, tb + 5, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 6, XE, HIST>(S, tb + 6, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 7, XE, HIST>(S, tb + 7, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
+        bsm_iter<V, R, 8, XE, HIST>(S, tb + 8, s, LT, GR, sp, p, xl, x0, h, ybeg, yend, owns, lat, hcov, edge, c0, c1, c2, c3, tp, O, mine, HF);
     }
     return S.tmax;
 }
 
-// grid: hak_xcd_grid(strips, groups of four row segments, images); a block's four waves take four consecutive segments
-template <typename V, int R>
-__global__ __launch_bounds__(256) void k_base_stream(const typename BsT<V>::In* __restrict__ img, long img_stride, int sp,
-                                                     V* __restrict__ lt, V* __restrict__ grad, long stride, int w, int h, int p,
-                                                     BsmTaps<V> tp, HakImgState* state, int ry, int nbx, int nby, int nimg)
+// ---- the contrast maximum in front of the pass (HIST mode): the sigma=1 low-pass (gConv2d<2>, akazed.cu:204-296 / 2922-2985) and its
+// Scharr magnitude (akazed.cu:644-666 / 3208-3232) at the lattice points x % 16 == 0 && y % 16 == 0 that gFindMaxContrastU4's grid
+// covers (hak_on_lattice) -- one thread per lattice point: 7 x 7 input pixels (reflect-101 on the input index, as everywhere),
+// 7 rows x 3 columns of the row pass, 3 x 3 of the column pass, one magnitude, one atomicMax.  Same expressions, same order as the
+// streaming pass and the tile kernels (sf_conv, bsm_mag): the value is bit-identical to the plane's.
+template <typename V>
+__global__ __launch_bounds__(256) void k_lattice_hmax(const typename BsT<V>::In* __restrict__ img, long img_stride, int sp, int w, int h,
+                                                      SfTaps<V> tp, HakImgState* state, int nlx, int nly)
 {
-    int bx, by, im;
-    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
-    const typename BsT<V>::In* s = img + (long)im * img_stride;
-    V* LT = lt + (long)im * stride;
-    V* GR = grad + (long)im * stride;
-    const int lane = threadIdx.x & 63;
-    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int x0 = bx * BS_XV - BS_HX + 4 * lane;           // first pixel of this lane (may lie outside the image)
-    const int ybeg = (by * 4 + wv) * ry;
-    if (ybeg >= h) return;                                  // wave-uniform
-    const int yend = min(ybeg + ry, h);
-    const bool owns = lane >= 1 && lane < 63 && x0 < w;
-    V m;
-    if (bx == 0 || (bx + 1) * BS_XV + BS_HX >= w) m = bsm_strip<V, R, true>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp);
-    else m = bsm_strip<V, R, false>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp);
+    const int im = blockIdx.y;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    V m = 0;
+    if (idx < nlx * nly) {
+        const int ly = idx / nlx, lx = idx - ly * nlx;
+        const int x = 16 * lx, y = 16 * ly;
+        const typename BsT<V>::In* s = img + (long)im * img_stride;
+        // smooth is needed at the reflected neighbour coordinates the Scharr stencil reads (akazed.cu:655-662: abs / borderAdd)
+        const int xs[3] = {hak_refl(x - 1, w), x, hak_refl(x + 1, w)};
+        const int ys[3] = {hak_refl(y - 1, h), y, hak_refl(y + 1, h)};
+        V sm[3][3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            V rp[5][3];                                             // row pass at rows ys[j] - 2 .. ys[j] + 2 (reflected), columns xs[0..2]
+#pragma unroll
+            for (int d = 0; d < 5; d++) {
+                const typename BsT<V>::In* q = s + (long)hak_refl(ys[j] + d - 2, h) * sp;
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int xc = xs[i];
+                    rp[d][i] = sf_conv((V)q[xc], (V)q[hak_refl(xc - 1, w)], (V)q[hak_refl(xc + 1, w)], (V)q[hak_refl(xc - 2, w)],
+                                       (V)q[hak_refl(xc + 2, w)], tp);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 3; i++) sm[j][i] = sf_conv(rp[2][i], rp[1][i], rp[3][i], rp[0][i], rp[4][i], tp);
+        }
+        m = bsm_mag(sm[0][0], sm[0][1], sm[0][2], sm[1][0], sm[1][2], sm[2][0], sm[2][1], sm[2][2]);
+    }
     for (int off = 32; off > 0; off >>= 1) m = bsm_max(m, __shfl_xor(m, off));
-    if (lane == 0) {
+    if ((threadIdx.x & 63) == 0) {
         if constexpr (std::is_same<V, float>::value) {
-            if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // lattice maximum (akazed.cu:827-877)
+            if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // (floored at 0.03f by the reset, akazed.cu:2413)
         } else {
-            if (m > 1) atomicMax(&state[im].ihmax, m);
+            if (m > 1) atomicMax(&state[im].ihmax, m);                               // (floored at 1, akazed.cu:4101)
         }
     }
 }
 
+// grid: hak_xcd_grid(strips, groups of four row segments, images); a block's four waves take four consecutive segments
+template <typename V, int R, bool HIST>
+__global__ __launch_bounds__(256) void k_base_stream(const typename BsT<V>::In* __restrict__ img, long img_stride, int sp,
+                                                     V* __restrict__ lt, V* __restrict__ grad, long stride, int w, int h, int p,
+                                                     BsmTaps<V> tp, HakImgState* state, int ry, int nbx, int nby, int nimg)
+{
+    __shared__ int shist[HIST ? BS_HIST_COPIES * HAK_NBINS : 1];
+    int bx, by, im;
+    if (!hak_xcd_decode(nbx, nby, nimg, bx, by, im)) return;
+    const typename BsT<V>::In* s = img + (long)im * img_stride;
+    V* LT = lt + (long)im * stride;
+    V* GR = HIST ? LT : grad + (long)im * stride;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int x0 = bx * BS_XV - BS_HX + 4 * lane;           // first pixel of this lane (may lie outside the image)
+    const int ybeg = (by * 4 + wv) * ry;
+    BsHistF<V> HF{};
+    if constexpr (HIST) {
+        for (int i = threadIdx.x; i < BS_HIST_COPIES * HAK_NBINS; i += 256) shist[i] = 0;
+        if constexpr (std::is_same<V, float>::value) HF.f = (double)(HAK_NBINS / __uint_as_float(state[im].hmax_bits));   // akazed.cu:2450
+        else HF.f = (int)(HAK_NBINS / (float)state[im].ihmax * 65536 + 0.5f);                                          // akazed.cu:4133
+        __syncthreads();
+    }
+    int* mine = shist + (HIST ? (lane & (BS_HIST_COPIES - 1)) * HAK_NBINS : 0);
+    V m = 0;
+    if (ybeg < h) {                                         // wave-uniform
+        const int yend = min(ybeg + ry, h);
+        const bool owns = lane >= 1 && lane < 63 && x0 < w;
+        if (bx == 0 || (bx + 1) * BS_XV + BS_HX >= w) m = bsm_strip<V, R, true, HIST>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp, mine, HF);
+        else m = bsm_strip<V, R, false, HIST>(s, LT, GR, sp, p, w, h, x0, ybeg, yend, owns, tp, mine, HF);
+    }
+    if constexpr (HIST) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < HAK_NBINS; i += 256) {
+            int sum = 0;
+#pragma unroll
+            for (int c = 0; c < BS_HIST_COPIES; c++) sum += shist[c * HAK_NBINS + i];
+            if (sum) atomicAdd(&state[im].hist[i], sum);
+        }
+    } else {
+        if (ybeg >= h) return;
+        for (int off = 32; off > 0; off >>= 1) m = bsm_max(m, __shfl_xor(m, off));
+        if (lane == 0) {
+            if constexpr (std::is_same<V, float>::value) {
+                if (m > 0.f) atomicMax(&state[im].hmax_bits, __float_as_uint(m));        // lattice maximum (akazed.cu:827-877)
+            } else {
+                if (m > 1) atomicMax(&state[im].ihmax, m);
+            }
+        }
+    }
+}
+
+// grad != nullptr: pass A of the two-pass form (writes the gradient plane, finds the lattice maximum; the caller's histogram pass
+// follows); grad == nullptr: k_lattice_hmax + the pass with the histogram inside (the caller only finishes the contrast factor)
 template <typename V>
 bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img_stride, int sp, V* lt, V* grad, long stride, int w, int h,
                         int p, int nimg, const V* taps1, const V* taps_base, int R, HakImgState* state, int mode)
 {
     using In = typename BsT<V>::In;
     constexpr long LA = 4;                                  // elements per aligned lane load: 4 floats / 4 bytes
-    if (!grad || R < 2 || R > 4 || (w & 3) || w < 16 || h < 16) return false;
+    if (R < 2 || R > 4 || (w & 3) || w < 16 || h < 16) return false;
     if ((sp % LA) || (img_stride % LA) || (reinterpret_cast<uintptr_t>(img) % (LA * sizeof(In)))) return false;
     if (!hak_stream_pays(mode, w, h, nimg)) return false;
-    if ((lt < grad ? grad - lt : lt - grad) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;   // plane offset + plane size < marker
+    if (grad && (lt < grad ? grad - lt : lt - grad) + (long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;   // plane offset + plane size < marker
+    if ((long)h * p >= (long)HAK_BUF_OOB / (long)sizeof(V)) return false;
     BsmTaps<V> tp;
     tp.a = SfTaps<V>{taps1[0], taps1[1], taps1[2]};
     for (int i = 0; i < 5; i++) tp.b[i] = i <= R ? taps_base[i] : V(0);
@@ -293,10 +403,20 @@ bool launch_base_stream(hipStream_t st, const typename BsT<V>::In* img, long img
     const int ry = hak_stream_rows(h, (long)gx * nimg, 16);
     const int gy = ((h + ry - 1) / ry + 3) / 4;
     const unsigned grid = hak_xcd_grid(gx, gy, nimg);
+    if (!grad) {
+        const int nlx = (hak_lattice_cov(w) + 15) / 16, nly = (hak_lattice_cov(h) + 15) / 16;
+        k_lattice_hmax<V><<<dim3((nlx * nly + 255) / 256, nimg), 256, 0, st>>>(img, img_stride, sp, w, h, tp.a, state, nlx, nly);
+        switch (R) {
+        case 2: k_base_stream<V, 2, true><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, lt, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+        case 3: k_base_stream<V, 3, true><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, lt, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+        default: k_base_stream<V, 4, true><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, lt, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+        }
+        return true;
+    }
     switch (R) {
-    case 2: k_base_stream<V, 2><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
-    case 3: k_base_stream<V, 3><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
-    default: k_base_stream<V, 4><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    case 2: k_base_stream<V, 2, false><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    case 3: k_base_stream<V, 3, false><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
+    default: k_base_stream<V, 4, false><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad, stride, w, h, p, tp, state, ry, gx, gy, nimg); break;
     }
     return true;
 }

@@ -307,6 +307,11 @@ bool hakf_launch_base_level(hipStream_t st, const unsigned char* img, long img_s
     for (int i = 0; i < 8; i++) { t1.k[i] = i <= 2 ? itaps1[i] : 0; tb.k[i] = i <= R ? itaps_base[i] : 0; }
     const int nbx = (w + FB_TX - 1) / FB_TX, nby = (h + FB_TY - 1) / FB_TY;
     const unsigned grid = hak_xcd_grid(nbx, nby, nimg);
+    // the streaming form with the histogram inside (round 5): contrast maximum first, from the lattice points alone, then ONE pass
+    if (knobs.base_hist && hakf_launch_base_stream(st, img, img_stride, sp, lt, nullptr, stride, w, h, p, nimg, itaps1, itaps_base, R, state, knobs.base_stream)) {
+        kf_kcontrast<<<nimg, 64, 0, st>>>(state, w * h, hak_hist_extra0(w, h), per, noct);
+        return true;
+    }
     if (hakf_launch_base_stream(st, img, img_stride, sp, lt, grad_scratch, stride, w, h, p, nimg, itaps1, itaps_base, R, state, knobs.base_stream)) {
         // pass A done by the streaming kernel
     } else

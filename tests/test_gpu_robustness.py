@@ -227,6 +227,10 @@ def _alt_oracle(okz, synth, ah, u8, w, h, mp):
 @pytest.mark.parametrize("env", [{"HAK_FUSE_SF": "0"}, {"HAK_HESS_STREAM": "0"}, {"HAK_FED_MAX_FUSE": "1"}, {"HAK_GRAPH": "0", "HAK_SERIAL": "1"},
                                  {"HAK_FUSE_SF": "1", "HAK_HESS_STREAM": "1"},          # the default size rule
                                  {"HAK_FUSE_HEAD": "0"}, {"HAK_BASE_STREAM": "0"}, {"HAK_BASE_STREAM": "1"},
+                                 # the streaming prologue with the lattice maximum found first and the histogram inside the pass, instead of
+                                 # its two-pass form (gradient plane + histogram pass)
+                                 # (off by default: measured slower)
+                                 {"HAK_BASE_HIST": "1"}, {"HAK_BASE_STREAM": "2", "HAK_BASE_HIST": "1"}, {"HAK_BASE_STREAM": "2", "HAK_BASE_HIST": "0"},
                                  {"HAK_FUSE_SF": "0", "HAK_HESS_STREAM": "0", "HAK_BASE_STREAM": "0", "HAK_FED_MAX_FUSE": "2"},
                                  # tile Hessian with a 4-entry candidate staging buffer: nearly every row with a candidate takes the
                                  # overflow path of the reservation (direct global slots) next to staged ones
