@@ -53,14 +53,14 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
 MFMA_FP4_PEAK_TOPS = 10000.0     # dense FP4 / FP6 matrix peak (MI355X_MICROARCH.md: ~10 PF dense; the matcher's operand type)
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 CHECKSUM_FILE = os.path.join(ROOT, "tests", "golden", "bench_pair_checksums.json")
 NDIST = 16                 # distinct seeded pairs; the pair with global id g is drawn from seed 1 + g % NDIST on every rank
 # kernel-name substrings and the sources whose hash ties a PMC pass to the kernels it measured (tools/pmc_traffic.py)
 CLASS_KERNELS = {
     "fed": ("k_fed_multi", "k_fed_sf", "k_fed_generic", "k_level_tile"),
     "hessian": ("k_hessian_stream", "k_hessian_fused"),
-    "prologue": ("k_base_stream", "k_base_a", "kf_base", "k_grad_hist_plane", "k_kcontrast2"),
+    "prologue": ("k_base_stream", "k_base_a", "kf_base", "k_grad_hist_plane", "k_kcontrast2", "k_lattice_hmax"),
     "describe": ("k_describe", "k_orient", "k_desc_perm"),
     "nms": ("k_nms_cand", "k_row_scan", "k_emit", "k_refine", "k_clear_cand_maps"),
     "match": ("k_match",),
@@ -1096,7 +1096,7 @@ def main():
                                    "pmc_frac_peak": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (HBM_PEAK_GBS * world), 4),
                                    "pmc_frac_copy": round(bpi * 2.0 * total_pairs_timed / elapsed / 1e9 / (copy_gbs * world), 4)})(
                                        sum(pmc.values()) / nim))},
-                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r04_*_serial_kernel_stats.csv"}
+                "mode": "serial leg (one stream, HIP events per launch); rocprof counterpart: profiles/r05_*_serial_kernel_stats.csv"}
 
     # ---- the oracle legs (rank 0): the oracle on ALL distinct pairs, every slot of every context's last download of the timed
     # region and every pair of the gathered table against it, the FAST leg the same way; then the CPU baseline from the same runs

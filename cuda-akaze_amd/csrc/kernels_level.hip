@@ -359,7 +359,8 @@ void launch_level(hipStream_t st, const V* src, V* smooth, V* dst, long stride, 
     while (T > 8 && total(T) > LV_LDS_FLOATS) T -= 8;
     // ... but not so large that a small plane runs on a handful of CUs.  Smaller tiles mean more halo work in total (the planes are
     // (T + 2 ns + 6)^2): ~100 blocks keep a block short without multiplying the work of the octaves that run beside the critical chain
-    while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < 96) T -= 8;
+    static const long min_blocks = [] { const char* e = getenv("HAK_LEVEL_MIN_BLOCKS"); const long v = e ? atol(e) : 96; return v < 1 ? 1 : v; }();
+    while (T > 16 && (long)((w + T - 1) / T) * ((h + T - 1) / T) * nimg < min_blocks) T -= 8;
     const size_t lds = sizeof(V) * (size_t)total(T);
     // the 150 KB dynamic-LDS opt-in is a per-DEVICE attribute of the function: once per device and instantiation (contexts on
     // several devices may live in one process, and two threads may create contexts at once)

@@ -1,9 +1,9 @@
 #!/bin/bash
 # Regenerates the evidence under profiles/ on the GPU box (run via gpurun from the repo root):
-#   bash tools/refresh_profiles.sh r04_a
+#   bash tools/refresh_profiles.sh r05_a
 # Every profiler run is wrapped in `timeout`; PMC passes are separate runs without any trace option.
 set -u
-TAG=${1:-r04_x}
+TAG=${1:-r05_x}
 R=$(pwd)
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
