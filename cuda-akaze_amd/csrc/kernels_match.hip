@@ -249,6 +249,9 @@ typedef float mm_v16f __attribute__((ext_vector_type(16)));
 #define MM_BASE 1024.0f
 #define MM_BASE_BITS 0x44800000u
 #define MM_QSTEP 0.0001220703125f        /* 2^-13 */
+#ifndef MM_QT_DEFAULT
+#define MM_QT_DEFAULT 1                  /* query tiles per wave (HAK_MATCH_QT overrides per call; 2 measured slower, see k_match_mfma) */
+#endif
 #define MM_MAX_ROWS (2047 * MM_BCH)     /* train rows one block pass can number (q < 2048): larger sets take the vector-pipe kernels */
 #define MM_ROW 36       // dwords per staged train row: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | 4 of padding]: lane half h reads its
                         // 16 dwords at 16 h (no shift in the tile loop, where every VALU instruction counts); 144-byte rows make the
@@ -320,14 +323,23 @@ extern "C" int hak_debug_mm_blocks(unsigned long long* host) { return hipMemcpyF
 #define MM_STAMP(i) do { } while (0)
 #define MM_BLK(k) do { } while (0)
 #endif
-template <bool KNN, int MM_CH>
-__global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
+// QT = query tiles per wave (round 5): with QT = 2 a wave owns 64 queries, every expanded train fragment feeds TWO matrix
+// instructions (2 v_and per MFMA instead of 4, half the LDS reads per MFMA, two independent accumulation chains), a block 256
+// queries, and the kernel runs ONE wave per SIMD out of 485 registers; QT = 1 is the 32-query wave at two waves per SIMD.
+// MEASURED: QT = 2 is SLOWER (10k x 10k 0.0439 vs 0.0410 ms; a chunk of 96 matrix instructions per SIMD takes 2.7-2.9 us against
+// 1.9-2.0 us with two waves of 48): beyond 256 registers the accumulators live in AccVGPRs, every minimum first copies its two
+// operands out (v_accvgpr_read: 2 more vector instructions per MFMA, 5 in all again), and a lone wave cannot issue its vector
+// instructions beside its own dependent matrix chain the way a second wave does.  QT = 1 is the default; HAK_MATCH_QT=2 selects
+// the other instantiation (same results: the match tests run both).
+template <bool KNN, int MM_CH, int QT>
+__global__ __launch_bounds__(256, (QT == 2 ? 1 : 2)) void k_match_mfma(hak_point* __restrict__ pts1_base, const hak_point* __restrict__ pts2_base,
                                                        const int* __restrict__ n1_dev, const int* __restrict__ n2_dev,
                                                        int n1_host, int n2_host, long stride1, long stride2, int count_stride,
                                                        int rows_per_slice,
                                                        int4* __restrict__ knn_out_base, long knn_stride,
                                                        int* ticket, uint2* part, int n1_pad)
 {
+    constexpr int QPB = 128 * QT;                                            // queries per block
     // unsliced: grid (query blocks, pairs); sliced: grid (query blocks, slices, pairs)
     const bool sliced = ticket != nullptr;
     MM_STAMP(0);
@@ -349,13 +361,13 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     __shared__ __attribute__((aligned(16))) unsigned int tile[2][MM_CH * MM_ROW];
     __shared__ int s_last;
-    // thread t fetches dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptors j0 + (t >> 3) + 32 i, i < 8: one chunk, all eight
+    // thread t fetches dwords 2 (t & 7), 2 (t & 7) + 1 of train descriptors j0 + (t >> 3) + 32 i, i < 6: one chunk, all six
     // loads in flight together; byte offsets in 32 bits from the (uniform) set base (n2 < 2^20 records, checked by the launcher)
     const unsigned toff = (unsigned)(threadIdx.x >> 3) * (unsigned)sizeof(hak_point) + (unsigned)offsetof(hak_point, features) +
                           8u * (threadIdx.x & 7);
 
-    for (int qb = blockIdx.x * 128; qb < n1; qb += gridDim.x * 128) {                   // block-uniform: every wave takes part in the staging
-        const int q0 = qb + 32 * wv;                                                    // (a wave past n1 computes on zeros and stores nothing)
+    for (int qb = blockIdx.x * QPB; qb < n1; qb += gridDim.x * QPB) {                   // block-uniform: every wave takes part in the staging
+        const int q0 = qb + 32 * QT * wv;                                               // (a wave past n1 computes on zeros and stores nothing)
         // ---- the order in which the slice's rows meet the matrix unit (round 5).  The slice [jbeg, jend) is cut into a MAIN part of
         // nmain = 192 NQ rows and a tail of < 192 rows.  The main part is six SIXTHS of E = 32 NQ rows; chunk q (192 rows = 6 tiles)
         // holds tile q of every sixth: tile P of chunk q = rows jbeg + P E + 32 q .. + 31.  For a fixed accumulator slot the train
@@ -366,9 +378,9 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         const int NQ = nrows / MM_CH;                                                   // chunks of the main part (uniform)
         const int E = 32 * NQ;                                                          // rows per sixth
         const int jtail = jbeg + MM_CH * NQ;                                            // first row of the tail
-        // two chunks travel at a time: chunk q + 2 is requested when chunk q starts and written to LDS when chunk q + 1 ends (round 5:
-        // with one chunk in flight the loop was a chain of exposed memory round trips -- a build without any arithmetic still took
-        // 20 of the kernel's 35 us for 10k x 10k).  pre[c & 1] holds chunk c; the chunk loop is unrolled by two, so the index is static.
+        // two chunks travel at a time: chunk q + 2 is requested when chunk q starts and written to LDS when chunk q + 1 starts (round 5:
+        // with one chunk in flight the loop was a chain of exposed memory round trips).  pre[c & 1] holds chunk c; the chunk loop is
+        // unrolled by two, so the index is static.
         uint2 pre[2][MM_CH / 32];
         const int NC = NQ + (jtail < jend ? 1 : 0);                                     // chunks incl. the tail (uniform)
         // chunk c: a main chunk (every row exists) or, c == NQ, the tail (consecutive tiles, rows past jend do not exist)
@@ -392,17 +404,18 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         };
         using mm_c0 = std::integral_constant<int, 0>;
         using mm_c1 = std::integral_constant<int, 1>;
-        if (NC > 0) fetch(0, mm_c0{});                              // the first chunks travel while the query is loaded and expanded
+        if (NC > 0) fetch(0, mm_c0{});                              // the first chunks travel while the queries are loaded and expanded
         if (NC > 1) fetch(1, mm_c1{});
-        mm_v4i B[8];
-        float c0;                                                   // 2^10 + 2 |b|: the accumulators' start without the chunk number
-        {
-            // the lane half's eight dwords 8 h .. 8 h + 7 of query q0 + r (features start at byte 24 of the record: 8-byte aligned)
+        mm_v4i B[QT][8];
+        float c0[QT];                                               // 2^10 + 2 |b|: the accumulators' start without the chunk number
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            // the lane half's eight dwords 8 h .. 8 h + 7 of query q0 + 32 t + r (features start at byte 24 of the record: 8-byte aligned)
             unsigned int qd[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) qd[i] = 0;
-            if (q0 + r < n1) {
-                const uint2* f = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts1 + q0 + r) + offsetof(hak_point, features)) + 4 * h;
+            if (q0 + 32 * t + r < n1) {
+                const uint2* f = reinterpret_cast<const uint2*>(reinterpret_cast<const char*>(pts1 + q0 + 32 * t + r) + offsetof(hak_point, features)) + 4 * h;
 #pragma unroll
                 for (int i = 0; i < 4; i++) { const uint2 v = f[i]; qd[2 * i] = v.x; qd[2 * i + 1] = v.y; }
                 if (h) qd[7] &= 0xFFu;                              // byte 60 only; bytes 61..63 are struct padding
@@ -412,17 +425,20 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             for (int i = 0; i < 8; i++) pb = bcnt_acc(qd[i], pb);
             pb += (unsigned)__shfl_xor((int)pb, 32);
 #pragma unroll
-            for (int s = 0; s < 8; s++) B[s] = mm_frag_b4(qd[s]);
+            for (int s = 0; s < 8; s++) B[t][s] = mm_frag_b4(qd[s]);
             // the three index positions (bits 8, 12, 16 of descriptor dword 15: struct padding, zero in every query): magnitudes 0.5,
             // 1, 2 against the staged row's 0.5 -> P / 4
-            if (h) B[7].x = (int)(((unsigned)B[7].x & ~0x000FFF00u) | 0x00042100u);
-            c0 = MM_BASE + 2.0f * (float)pb;
+            if (h) B[t][7].x = (int)(((unsigned)B[t][7].x & ~0x000FFF00u) | 0x00042100u);
+            c0[t] = MM_BASE + 2.0f * (float)pb;
         }
-        unsigned best[16], sec[KNN ? 16 : 1];
+        unsigned best[QT][16], sec[QT][KNN ? 16 : 1];
 #pragma unroll
-        for (int i = 0; i < 16; i++) best[i] = 0xFFFFFFFFu;
+        for (int t = 0; t < QT; t++) {
 #pragma unroll
-        for (int i = 0; i < (KNN ? 16 : 1); i++) sec[i] = 0xFFFFFFFFu;
+            for (int i = 0; i < 16; i++) best[t][i] = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < (KNN ? 16 : 1); i++) sec[t][i] = 0xFFFFFFFFu;
+        }
         // the lane's 16 dwords of row r of tile K of chunk buffer BUF -> TD
 #define MM_READ(BUF, K, TD)                                                                                 \
         {                                                                                                   \
@@ -432,36 +448,40 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                 TD[4 * c] = v.x; TD[4 * c + 1] = v.y; TD[4 * c + 2] = v.z; TD[4 * c + 3] = v.w;             \
             }                                                                                               \
         }
-        // two finished tiles X, Y -> the slot's smallest (and, 2-NN, second smallest) key: one v_min3_u32 per element and pair of
-        // tiles (2-NN: five instructions).  The accumulators ARE the keys: positive floats order like their bit patterns.
-#define MM_EPI2(X, Y, I)                                                                                    \
+        // two finished tiles X, Y of query tile T -> the slot's smallest (and, 2-NN, second smallest) key: one v_min3_u32 per element
+        // and pair of tiles (2-NN: five instructions).  The accumulators ARE the keys: positive floats order like their bit patterns.
+#define MM_EPI2(T, X, Y, I)                                                                                 \
         {                                                                                                   \
-            const unsigned ka = __float_as_uint(X[I]), kb = __float_as_uint(Y[I]);                          \
+            const unsigned ka = __float_as_uint(X[T][I]), kb = __float_as_uint(Y[T][I]);                    \
             if constexpr (KNN) {                                                                            \
                 const unsigned lo = min(ka, kb), hi = max(ka, kb);                                          \
-                sec[I] = min(min(sec[I], hi), max(best[I], lo));                                            \
-                best[I] = min(best[I], lo);                                                                 \
-                asm volatile("" : "+v"(sec[I]));                                                            \
-            } else best[I] = min(min(best[I], ka), kb);                                                     \
+                sec[T][I] = min(min(sec[T][I], hi), max(best[T][I], lo));                                   \
+                best[T][I] = min(best[T][I], lo);                                                           \
+                asm volatile("" : "+v"(sec[T][I]));                                                         \
+            } else best[T][I] = min(min(best[T][I], ka), kb);                                               \
             /* (the minimum is associative and the compiler knows it: left alone it keeps SIX accumulator sets alive and takes   \
                all minima of a chunk at its end -- 96 registers and no overlap with the matrix instructions) */                  \
-            asm volatile("" : "+v"(best[I]));                                                               \
+            asm volatile("" : "+v"(best[T][I]));                                                            \
         }
-        // the eight matrix instructions of one tile (train rows from TD) into CUR, with the epilogue of the finished tiles EX, EY
-        // between them when EPI (two accumulator elements per MFMA: beside the four v_and of its own fragment that is six vector
-        // instructions per MFMA, what tools/probes/mfma_valu_overlap.hip found to be free)
+        // the eight matrix instructions per query tile of one train tile (rows from TD) into CUR, with the epilogue of the finished
+        // tiles EX, EY between them when EPI.  The train fragment is expanded once and feeds all QT query tiles.
 #define MM_PIPE(TD, CUR, EPI, EX, EY)                                                                       \
         {                                                                                                   \
             _Pragma("unroll") for (int s = 0; s < 8; s++) {                                                 \
-                const mm_v4i bs = B[s];                                                                     \
-                const mm_v8i bf = {bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0};                                     \
-                if (s == 0) CUR = MM_MFMA(mm_frag_a4(TD[0], TD[8]), bf, cinit);                             \
-                else CUR = MM_MFMA(mm_frag_a4(TD[s], TD[8 + s]), bf, CUR);                                  \
-                if (EPI) { MM_EPI2(EX, EY, 2 * s) MM_EPI2(EX, EY, 2 * s + 1) }                              \
+                const mm_v8i af = mm_frag_a4(TD[s], TD[8 + s]);                                             \
+                _Pragma("unroll") for (int t = 0; t < QT; t++) {                                            \
+                    const mm_v4i bs = B[t][s];                                                              \
+                    const mm_v8i bf = {bs.x, bs.y, bs.z, bs.w, 0, 0, 0, 0};                                 \
+                    if (s == 0) CUR[t] = MM_MFMA(af, bf, cinit[t]);                                         \
+                    else CUR[t] = MM_MFMA(af, bf, CUR[t]);                                                  \
+                }                                                                                           \
+                if (EPI) {                                                                                  \
+                    _Pragma("unroll") for (int t = 0; t < QT; t++) { MM_EPI2(t, EX, EY, 2 * s) MM_EPI2(t, EX, EY, 2 * s + 1) } \
+                }                                                                                           \
                 __builtin_amdgcn_sched_barrier(0);                                                          \
             }                                                                                               \
         }
-        // rows of chunk buffer `buf`: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | pad]: lane half h reads its 16 dwords at 16 h.
+        // rows of chunk buffer c & 1: [w0..w7 | w0..w7 >> 1 | w8..w15 | w8..w15 >> 1 | pad]: lane half h reads its 16 dwords at 16 h.
         // The thread that holds dword 15 plants the tile's number P (tail: 7) into its bits 8, 12, 16.
         auto stage = [&](int c, auto par) {                         // chunk c (held in pre[c & 1]) -> tile[c & 1]
             constexpr int PAR = decltype(par)::value;
@@ -481,10 +501,13 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         if (NC > 0) stage(0, mm_c0{});
         __syncthreads();
         MM_STAMP(2);
-        mm_v16f cinit;
+        mm_v16f cinit[QT], X0[QT], X1[QT], X2[QT];                  // three accumulator sets per query tile: train tile k lives in set k mod 3
 #pragma unroll
-        for (int i = 0; i < 16; i++) cinit[i] = c0;
-        mm_v16f X0 = cinit, X1 = cinit, X2 = cinit;                 // three accumulator sets: tile t of the stream lives in set t mod 3
+        for (int t = 0; t < QT; t++) {
+#pragma unroll
+            for (int i = 0; i < 16; i++) cinit[t][i] = c0[t];
+            X0[t] = cinit[t]; X1[t] = cinit[t]; X2[t] = cinit[t];
+        }
         bool pend = false;                                          // X1, X2 hold the last two tiles of the previous chunk (uniform)
         // one main chunk q out of tile[q & 1]: six tiles; the minima of tiles (4, 5) of the previous chunk ride on tile 0, those of
         // (0, 1) on tile 2, those of (2, 3) on tile 4
@@ -493,7 +516,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             using nxt = std::integral_constant<int, PAR ^ 1>;
             // chunk q + 1 (requested two chunks ago) goes to the other buffer FIRST -- its last readers passed the barrier at the end of
             // chunk q - 1 -- so that the LDS writes run beside this chunk's matrix instructions and the barrier below only collects
-            // stragglers (staging behind the tiles left the matrix unit idle for 0.55 of every 2.1 us); then chunk q + 2 is requested
+            // stragglers; then chunk q + 2 is requested
             if (q + 1 < NC) stage(q + 1, nxt{});
             if (q + 2 < NC) fetch(q + 2, par);                      // (pre[PAR] went to LDS one chunk ago)
             unsigned int ta[16], tb[16];
@@ -512,7 +535,10 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             MM_PIPE(tb, X2, false, X0, X0)
             pend = true;
 #pragma unroll
-            for (int i = 0; i < 16; i++) cinit[i] += MM_QSTEP;      // the next chunk's number (exact: one ulp of the accumulators' binade)
+            for (int t = 0; t < QT; t++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) cinit[t][i] += MM_QSTEP;   // the next chunk's number (exact: one ulp of the accumulators' binade)
+            }
             MM_STAMP(3 + 2 * q);
             __syncthreads();
             MM_STAMP(4 + 2 * q);
@@ -523,7 +549,10 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         }
         if (pend) {
 #pragma unroll
-            for (int i = 0; i < 16; i++) MM_EPI2(X1, X2, i)
+            for (int t = 0; t < QT; t++) {
+#pragma unroll
+                for (int i = 0; i < 16; i++) MM_EPI2(t, X1, X2, i)
+            }
         }
         // the tail: up to six consecutive tiles, tile k carries (P, q) = (7, k); rows past jend do not exist
         if (jtail < jend) {
@@ -537,14 +566,20 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                     for (int c = 0; c < 4; c++) { const uint4 v = row[c]; ta[4 * c] = v.x; ta[4 * c + 1] = v.y; ta[4 * c + 2] = v.z; ta[4 * c + 3] = v.w; }
                 }
 #pragma unroll
-                for (int i = 0; i < 16; i++) cinit[i] = c0 + (float)k * MM_QSTEP;
+                for (int t = 0; t < QT; t++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) cinit[t][i] = c0[t] + (float)k * MM_QSTEP;
+                }
                 MM_PIPE(ta, X0, false, X0, X0)
                 const int jb = jtail + 32 * k + 4 * h;
 #pragma unroll
-                for (int i = 0; i < 16; i++) {
-                    const unsigned key = jb + (i & 3) + 8 * (i >> 2) < jend ? __float_as_uint(X0[i]) : 0xFFFFFFFFu;
-                    if constexpr (KNN) sec[i] = min(sec[i], max(best[i], key));
-                    best[i] = min(best[i], key);
+                for (int t = 0; t < QT; t++) {
+#pragma unroll
+                    for (int i = 0; i < 16; i++) {
+                        const unsigned key = jb + (i & 3) + 8 * (i >> 2) < jend ? __float_as_uint(X0[t][i]) : 0xFFFFFFFFu;
+                        if constexpr (KNN) sec[t][i] = min(sec[t][i], max(best[t][i], key));
+                        best[t][i] = min(best[t][i], key);
+                    }
                 }
             }
             __syncthreads();                                        // (the tail's buffer is free for the next query group's first chunk)
@@ -552,6 +587,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
         MM_STAMP(40);
 #undef MM_PIPE
 #undef MM_EPI2
+#undef MM_READ
         // decode: bits - bits(2^10) = d 2^14 + P 2^11 + q  ->  d << 20 | first row of the slot's lane half in that tile
         auto decode = [&](unsigned k) -> unsigned {
             if (k == 0xFFFFFFFFu) return k;
@@ -561,65 +597,111 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
             return ((u >> 14) << 20) + row;
         };
 #pragma unroll
-        for (int i = 0; i < 16; i++) best[i] = decode(best[i]);
+        for (int t = 0; t < QT; t++) {
 #pragma unroll
-        for (int i = 0; i < (KNN ? 16 : 0); i++) sec[i] = decode(sec[i]);
-#undef MM_READ
-        const int qi = q0 + r;
-        if constexpr (KNN) {
-            // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset to both of its keys; the query's
-            // other sixteen slots sit in lane ^ 32
-            unsigned b1[32], b2[32];
+            for (int i = 0; i < 16; i++) best[t][i] = decode(best[t][i]);
 #pragma unroll
-            for (int i = 0; i < 16; i++) {
-                const unsigned off = (unsigned)((i & 3) + 8 * (i >> 2));
-                b1[i] = best[i] == 0xFFFFFFFFu ? best[i] : best[i] + off;
-                b2[i] = sec[i] == 0xFFFFFFFFu ? sec[i] : sec[i] + off;
-                b1[16 + i] = (unsigned)__shfl_xor((int)b1[i], 32);
-                b2[16 + i] = (unsigned)__shfl_xor((int)b2[i], 32);
+            for (int i = 0; i < (KNN ? 16 : 0); i++) sec[t][i] = decode(sec[t][i]);
+        }
+        // ---- per query: this block's result (unsliced: final; sliced: the slice's summary for the merge below)
+        int4* out = KNN ? knn_out_base + (long)pair * knn_stride : nullptr;
+#pragma unroll
+        for (int t = 0; t < QT; t++) {
+            const int qi = q0 + 32 * t + r;
+            if constexpr (KNN) {
+                // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset to both of its keys; the query's
+                // other sixteen slots sit in lane ^ 32
+                unsigned b1[32], b2[32];
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const unsigned off = (unsigned)((i & 3) + 8 * (i >> 2));
+                    b1[i] = best[t][i] == 0xFFFFFFFFu ? best[t][i] : best[t][i] + off;
+                    b2[i] = sec[t][i] == 0xFFFFFFFFu ? sec[t][i] : sec[t][i] + off;
+                    b1[16 + i] = (unsigned)__shfl_xor((int)b1[i], 32);
+                    b2[16 + i] = (unsigned)__shfl_xor((int)b2[i], 32);
+                }
+                unsigned m1 = b1[0];
+#pragma unroll
+                for (int i = 1; i < 32; i++) m1 = min(m1, b1[i]);
+                unsigned m2 = 0xFFFFFFFFu;                          // the keys are distinct (they carry the index): one slot holds m1
+#pragma unroll
+                for (int i = 0; i < 32; i++) m2 = min(m2, b1[i] == m1 ? b2[i] : b1[i]);
+                if (!sliced) {
+                    if (h == 0 && qi < n1)
+                        out[qi] = m1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
+                                                    : make_int4((int)(m1 & 0xFFFFFu), (int)(m1 >> 20), m2 == 0xFFFFFFFFu ? 512 : (int)(m2 >> 20), 0);
+                } else if (h == 0) {
+                    // sliced: this slice's two smallest keys of the query; the last block of the query block merges the slices:
+                    // nearest = the smallest m1, second = the smallest of the other slices' m1 and the winning slice's m2
+                    __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi), ((unsigned long long)m2 << 32) | m1,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            } else {
+                // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset, then slots i and i + 8 (rows 16
+                // apart) are one residue class: cls[k], k < 8 = class (k & 3) + 8 (k >> 2) + 4 h
+                unsigned cls[8];
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const unsigned lo = best[t][k] == 0xFFFFFFFFu ? best[t][k] : best[t][k] + (unsigned)((k & 3) + 8 * (k >> 2));
+                    const unsigned hi = best[t][k + 8] == 0xFFFFFFFFu ? best[t][k + 8] : best[t][k + 8] + (unsigned)((k & 3) + 8 * (k >> 2) + 16);
+                    cls[k] = min(lo, hi);
+                }
+                if (sliced) {                                       // (uniform)
+                    // What the accept rule needs of a slice is little: the smallest key (distance << 20 | index) and WHICH classes attain
+                    // its distance -- the rule asks whether exactly one class attains the global minimum distance (akazed.cu:2206, 2223).
+                    // Plain 8-byte stores; atomicMin on 16 class keys per query ran into the atomic units' throughput (2 M lane-atomics:
+                    // 35-85 us for 10k x 10k).
+                    unsigned kloc = cls[0];
+#pragma unroll
+                    for (int k = 1; k < 8; k++) kloc = min(kloc, cls[k]);
+                    const unsigned kmin = min(kloc, (unsigned)__shfl_xor((int)kloc, 32));
+                    unsigned mloc = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; k++) mloc |= (cls[k] >> 20) == (kmin >> 20) ? 1u << ((k & 3) + 8 * (k >> 2) + 4 * h) : 0u;
+                    const unsigned mask = mloc | (unsigned)__shfl_xor((int)mloc, 32);
+                    if (h == 0)
+                        __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi),
+                                           ((unsigned long long)(kmin == 0xFFFFFFFFu ? 0u : mask) << 32) | kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else {
+                    // the other half of the query's classes sits in lane ^ 32
+                    unsigned all[16];
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { all[k] = cls[k]; all[8 + k] = (unsigned)__shfl_xor((int)cls[k], 32); }
+                    if (h == 0 && qi < n1) mm_accept(pts1 + qi, pts2, all, n2);
+                }
             }
-            unsigned m1 = b1[0];
-#pragma unroll
-            for (int i = 1; i < 32; i++) m1 = min(m1, b1[i]);
-            unsigned m2 = 0xFFFFFFFFu;                              // the keys are distinct (they carry the index): one slot holds m1
-#pragma unroll
-            for (int i = 0; i < 32; i++) m2 = min(m2, b1[i] == m1 ? b2[i] : b1[i]);
-            int4* out = knn_out_base + (long)pair * knn_stride;
-            if (!sliced) {
-                if (h == 0 && qi < n1)
-                    out[qi] = m1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
-                                                : make_int4((int)(m1 & 0xFFFFFu), (int)(m1 >> 20), m2 == 0xFFFFFFFFu ? 512 : (int)(m2 >> 20), 0);
-                continue;
-            }
-            // sliced: this slice's two smallest keys of the query, then the ticket; the last block of the query block merges the slices:
-            // nearest = the smallest m1, second = the smallest of the other slices' m1 and the winning slice's m2
-            if (h == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi), ((unsigned long long)m2 << 32) | m1,
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
-            // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
-            // s_waitcnt orders them in front of the ticket.
-            // HARDWARE ASSUMPTION, not the HIP memory model: a workgroup-scope fence does not formally synchronise with another
-            // workgroup, so the finisher's reads of `part` have no happens-before edge on paper.  What orders them on gfx950: an
-            // agent-scope atomic store is issued sc1 (write-through to the device coherence point), __syncthreads() waits for
-            // vmcnt(0) -- the stores have been acknowledged there -- before thread 0's ticket RMW (performed at the same
-            // coherence point) is issued, and the finisher's agent-scope atomic loads bypass its own L1 / non-coherent L2 lines.
-            // tests/test_gpu_pipeline.py::test_match_sliced_handoff_stress repeats 10k x 10k and the sliced pair path against
-            // the VALU kernel to catch a compiler or cache-policy change that breaks this.)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const int tk = __hip_atomic_fetch_add(&ticket[qb >> 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = tk == (int)gridDim.y - 1;
-                if (s_last) __hip_atomic_store(&ticket[qb >> 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            if (s_last) {                                           // (block-uniform)
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int q = qb + (int)threadIdx.x;
-                if (threadIdx.x < 128 && q < n1) {
+        }
+        if (!sliced) continue;                                      // (uniform)
+        // ---- sliced: the ticket; the block that draws the last ticket of its query block merges the slices' summaries.
+        // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
+        // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
+        // s_waitcnt orders them in front of the ticket.
+        // HARDWARE ASSUMPTION, not the HIP memory model: a workgroup-scope fence does not formally synchronise with another
+        // workgroup, so the finisher's reads of `part` have no happens-before edge on paper.  What orders them on gfx950: an
+        // agent-scope atomic store is issued sc1 (write-through to the device coherence point), __syncthreads() waits for
+        // vmcnt(0) -- the stores have been acknowledged there -- before thread 0's ticket RMW (performed at the same
+        // coherence point) is issued, and the finisher's agent-scope atomic loads bypass its own L1 / non-coherent L2 lines.
+        // tests/test_gpu_pipeline.py::test_match_sliced_handoff_stress repeats 10k x 10k and the sliced pair path against
+        // the VALU kernel to catch a compiler or cache-policy change that breaks this.)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        MM_STAMP(41);
+        if (threadIdx.x == 0) {
+            const int tk = __hip_atomic_fetch_add(&ticket[qb / QPB], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = tk == (int)gridDim.y - 1;
+            if (s_last) __hip_atomic_store(&ticket[qb / QPB], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        MM_STAMP(42);
+        if (s_last) {                                               // (block-uniform) the last block of the query block decides
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            const int q = qb + (int)threadIdx.x;
+            if ((int)threadIdx.x < QPB && q < n1) {
+                // (eight slices' summaries in flight at a time: one memory round trip instead of one per slice -- the finishing
+                // blocks are the kernel's tail, round 5: they ended 4-8 us after the others)
+                if constexpr (KNN) {
                     unsigned M1 = 0xFFFFFFFFu, M2 = 0xFFFFFFFFu;
-                    for (int s0 = 0; s0 < (int)gridDim.y; s0 += 8) {        // (eight summaries in flight: see the 1-NN merge below)
+                    for (int s0 = 0; s0 < (int)gridDim.y; s0 += 8) {
                         unsigned long long pv[8];
 #pragma unroll
                         for (int j = 0; j < 8; j++)
@@ -638,55 +720,8 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                     }
                     out[q] = M1 == 0xFFFFFFFFu ? make_int4(-1, 512, 512, 0)
                                                : make_int4((int)(M1 & 0xFFFFFu), (int)(M1 >> 20), M2 == 0xFFFFFFFFu ? 512 : (int)(M2 >> 20), 0);
-                }
-            }
-            continue;
-        }
-        // slot i saw rows (i & 3) + 8 (i >> 2) + 4 h (+ 32 per tile): add the slot's row offset, then slots i and i + 8 (rows 16
-        // apart) are one residue class: cls[k], k < 8 = class (k & 3) + 8 (k >> 2) + 4 h
-        unsigned cls[8];
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const unsigned lo = best[k] == 0xFFFFFFFFu ? best[k] : best[k] + (unsigned)((k & 3) + 8 * (k >> 2));
-            const unsigned hi = best[k + 8] == 0xFFFFFFFFu ? best[k + 8] : best[k + 8] + (unsigned)((k & 3) + 8 * (k >> 2) + 16);
-            cls[k] = min(lo, hi);
-        }
-        if (sliced) {                                               // (uniform)
-            // What the accept rule needs of a slice is little: the smallest key (distance << 20 | index) and WHICH classes attain
-            // its distance -- the rule asks whether exactly one class attains the global minimum distance (akazed.cu:2206, 2223).
-            // Plain 8-byte stores; atomicMin on 16 class keys per query ran into the atomic units' throughput (2 M lane-atomics:
-            // 35-85 us for 10k x 10k).
-            unsigned kloc = cls[0];
-#pragma unroll
-            for (int k = 1; k < 8; k++) kloc = min(kloc, cls[k]);
-            const unsigned kmin = min(kloc, (unsigned)__shfl_xor((int)kloc, 32));
-            unsigned mloc = 0;
-#pragma unroll
-            for (int k = 0; k < 8; k++) mloc |= (cls[k] >> 20) == (kmin >> 20) ? 1u << ((k & 3) + 8 * (k >> 2) + 4 * h) : 0u;
-            const unsigned mask = mloc | (unsigned)__shfl_xor((int)mloc, 32);
-            if (h == 0)
-                __hip_atomic_store(reinterpret_cast<unsigned long long*>(part + (long)blockIdx.y * n1_pad + qi),
-                                   ((unsigned long long)(kmin == 0xFFFFFFFFu ? 0u : mask) << 32) | kmin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // (no agent-scope fence: on this part that is a write-back of the whole L2 per block -- 30-100 us for 10k x 10k.  The summaries
-            // are written and read with agent-scope atomic accesses, which go to the coherence point themselves; the barrier's
-            // s_waitcnt orders them in front of the ticket)
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __syncthreads();
-            MM_STAMP(41);
-            if (threadIdx.x == 0) {
-                const int tk = __hip_atomic_fetch_add(&ticket[qb >> 7], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                s_last = tk == (int)gridDim.y - 1;
-                if (s_last) __hip_atomic_store(&ticket[qb >> 7], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            __syncthreads();
-            MM_STAMP(42);
-            if (s_last) {                                           // (block-uniform) the last block of the query block decides
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                const int q = qb + (int)threadIdx.x;
-                if (threadIdx.x < 128 && q < n1) {
+                } else {
                     unsigned K = 0xFFFFFFFFu, M = 0u;
-                    // (eight slices' summaries in flight at a time: one memory round trip instead of one per slice -- the finishing
-                    // blocks are the kernel's tail, round 5: they ended 4-8 us after the others)
                     for (int s0 = 0; s0 < (int)gridDim.y; s0 += 8) {
                         unsigned long long pv[8];
 #pragma unroll
@@ -713,13 +748,7 @@ __global__ __launch_bounds__(256, 2) void k_match_mfma(hak_point* __restrict__ p
                     }
                 }
             }
-            continue;
         }
-        // the other half of the query's classes sits in lane ^ 32
-        unsigned all[16];
-#pragma unroll
-        for (int k = 0; k < 8; k++) { all[k] = cls[k]; all[8 + k] = (unsigned)__shfl_xor((int)cls[k], 32); }
-        if (h == 0 && qi < n1) mm_accept(pts1 + qi, pts2, all, n2);
     }
     MM_BLK(1);
 }
@@ -991,6 +1020,20 @@ static int mfma_slices(int gx, int n2, int* rows_per_slice, int want_blocks)
     return (tiles + tps - 1) / tps;
 }
 
+// query tiles per wave of k_match_mfma (HAK_MATCH_QT = 1 | 2, read per call like HAK_MATCH_VALU: A/B runs and the tests drive both)
+static int mm_query_tiles()
+{
+    const char* e = getenv("HAK_MATCH_QT");
+    const int v = e ? atoi(e) : MM_QT_DEFAULT;
+    return v == 1 ? 1 : 2;
+}
+template <bool KNN, typename... A>
+static void mm_launch(int qt, dim3 grid, hipStream_t st, A... a)
+{
+    if (qt == 2) k_match_mfma<KNN, MM_BCH, 2><<<grid, 256, 0, st>>>(a...);
+    else k_match_mfma<KNN, MM_BCH, 1><<<grid, 256, 0, st>>>(a...);
+}
+
 void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* ptsB, const int* nA_dev, const int* nB_dev,
                      int nA_host, int nB_host, long strideA, long strideB, int npairs, int4* out, long out_stride, HakMatchScratch* sc)
 {
@@ -998,21 +1041,22 @@ void hak_launch_knn2(hipStream_t st, const hak_point* ptsA, const hak_point* pts
     // (with device-side counts nA_host / nB_host carry the CAPACITY of the sets)
     if (!(env_valu && atoi(env_valu) != 0) && nB_host <= MM_MAX_ROWS) {
         // the matrix-core kernel with its 2-NN epilogue (the point records are only read: ptsA is not written)
-        int gx = nA_dev ? 83 : (nA_host + 127) / 128;
+        const int qt = mm_query_tiles(), qpb = 128 * qt;
+        int gx = nA_dev ? (qt == 2 ? 43 : 83) : (nA_host + qpb - 1) / qpb;
         if (gx < 1) gx = 1;
         if (gx > 4096) gx = 4096;
         // one big pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set
-        if (sc && !nA_dev && npairs == 1 && gx < 384 && (long)gx * 128 >= nA_host) {
+        if (sc && !nA_dev && npairs == 1 && gx < 384 && (long)gx * qpb >= nA_host) {
             int rps = 0;
-            const int slices = mfma_slices(gx, nB_host, &rps, 512);
-            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
-                k_match_mfma<true, MM_BCH><<<dim3(gx, slices), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nullptr, nullptr, nA_host, nB_host, 0, 0,
-                                                                    2, rps, out, 0, sc->ticket, sc->part, gx * 128);
+            const int slices = mfma_slices(gx, nB_host, &rps, qt == 2 ? 256 : 512);
+            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * qpb, 0, 0)) {
+                mm_launch<true>(qt, dim3(gx, slices), st, const_cast<hak_point*>(ptsA), ptsB, (const int*)nullptr, (const int*)nullptr, nA_host, nB_host, 0L, 0L,
+                                2, rps, out, 0L, sc->ticket, sc->part, gx * qpb);
                 return;
             }
         }
-        k_match_mfma<true, MM_BCH><<<dim3(gx, npairs), 256, 0, st>>>(const_cast<hak_point*>(ptsA), ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB,
-                                                            2, 0, out, out_stride, nullptr, nullptr, 0);
+        mm_launch<true>(qt, dim3(gx, npairs), st, const_cast<hak_point*>(ptsA), ptsB, nA_dev, nB_dev, nA_host, nB_host, strideA, strideB,
+                        2, 0, out, out_stride, (int*)nullptr, (uint2*)nullptr, 0);
         return;
     }
     int gx = nA_dev ? 640 : (nA_host + MQ - 1) / MQ;
@@ -1043,30 +1087,31 @@ void hak_launch_knn2_finish(hipStream_t st, hak_point* pts1, const hak_point* pt
 void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, const int* n1_dev, const int* n2_dev,
                       int n1_host, int n2_host, long pair_stride1, long pair_stride2, int npairs, HakMatchScratch* sc)
 {
-    // k_match_mfma: a wave = 32 queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
+    // k_match_mfma: a wave = 32 QT queries x the train set, four waves per block.  HAK_MATCH_VALU=1: the VALU / LDS kernel k_match
     const char* env_valu = getenv("HAK_MATCH_VALU");               // (read per call: the tests run both kernels in one process)
     const bool valu = (env_valu && atoi(env_valu) != 0) || n2_host > MM_MAX_ROWS;       // (device-side counts: n2_host = the capacity)
+    const int qt = mm_query_tiles(), qpb = 128 * qt;
     const int nq = n1_dev ? 0 : n1_host;
     const bool two = n1_dev ? npairs >= 8 : (long)((nq + 2 * MQ - 1) / (2 * MQ)) * npairs >= 2048;    // (k_match only: queries per thread)
-    const int qb = valu ? (two ? 2 * MQ : MQ) : 128;                // queries per block
+    const int qb = valu ? (two ? 2 * MQ : MQ) : qpb;                // queries per block
     // device-side counts: k_match loops over the queries; k_match_mfma gets blocks for 10 240 queries (waves past n1 leave at once)
-    // (83, not 80: blocks go to the eight XCDs by linear index mod 8, and with a multiple of 8 per pair the ~18 blocks of every pair
-    // that find queries would land on the same XCDs pair after pair -- two XCDs with three of them, six with two: 1.33 x the mean)
-    int gx = n1_dev ? (valu ? (two ? 320 : 640) : 83) : (nq + qb - 1) / qb;
+    // (83 / 43, not 80 / 40: blocks go to the eight XCDs by linear index mod 8, and with a multiple of 8 per pair the blocks of every
+    // pair that find queries would land on the same XCDs pair after pair -- two XCDs with three of them, six with two: 1.33 x the mean)
+    int gx = n1_dev ? (valu ? (two ? 320 : 640) : (qt == 2 ? 43 : 83)) : (nq + qb - 1) / qb;
     if (gx < 1) gx = 1;
     if (gx > 4096) gx = 4096;
     // with device-side counts n1_host carries the CAPACITY of a query set (the context's max_pts; 0: unknown).  The sliced path
-    // below gives every 128-query block its own ticket and partial-result rows, so its grid must cover the capacity -- the plain
+    // below gives every query block its own ticket and partial-result rows, so its grid must cover the capacity -- the plain
     // kernel's blocks loop over the queries and need no such bound.
-    const int cap_blocks = n1_dev && n1_host > 0 ? (n1_host + 127) / 128 : 0;
+    const int cap_blocks = n1_dev && n1_host > 0 ? (n1_host + qpb - 1) / qpb : 0;
     // one pair with host-side counts whose query blocks alone cannot fill the chip: slice the train set as well
     if (sc && !n1_dev && npairs == 1 && (long)gx * qb >= nq) {
         if (!valu && gx < 384) {
             int rps = 0;
-            const int slices = mfma_slices(gx, n2_host, &rps, 512);
-            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * 128, 0, 0)) {
-                k_match_mfma<false, MM_BCH><<<dim3(gx, slices), 256, 0, st>>>(pts1, pts2, nullptr, nullptr, n1_host, n2_host, 0, 0, 2, rps,
-                                                                        nullptr, 0, sc->ticket, sc->part, gx * 128);
+            const int slices = mfma_slices(gx, n2_host, &rps, qt == 2 ? 256 : 512);
+            if (slices > 1 && hak_match_scratch_reserve(sc, st, 0, gx, (long)slices * gx * qpb, 0, 0)) {
+                mm_launch<false>(qt, dim3(gx, slices), st, pts1, pts2, (const int*)nullptr, (const int*)nullptr, n1_host, n2_host, 0L, 0L, 2, rps,
+                                 (int4*)nullptr, 0L, sc->ticket, sc->part, gx * qpb);
                 return;
             }
         }
@@ -1083,20 +1128,20 @@ void hak_launch_match(hipStream_t st, hak_point* pts1, const hak_point* pts2, co
             }
         }
     }
-    // few pairs with device-side counts (the pair call, batches of a handful of images): 18 of a pair's 83 blocks find queries,
-    // each walks the whole train set (71 tiles, ~40 us) while most of the chip idles -- slice the train sets as for one big pair
+    // few pairs with device-side counts (the pair call, batches of a handful of images): few of a pair's blocks find queries,
+    // each walks the whole train set while most of the chip idles -- slice the train sets as for one big pair
     if (!valu && sc && n1_dev && npairs <= 12 && cap_blocks > 0 && cap_blocks <= 4096) {
         if (cap_blocks > gx) gx = cap_blocks | 3;                   // (odd, as 83: not a multiple of the eight XCDs)
-        const int slices = npairs <= 2 ? 8 : npairs <= 4 ? 4 : npairs <= 8 ? 3 : 2;
-        if (hak_match_scratch_reserve(sc, st, 0, (long)npairs * gx, (long)npairs * slices * gx * 128, 0, 0)) {
-            k_match_mfma<false, MM_BCH><<<dim3(gx, slices, npairs), 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2,
-                                                                                 2, 0, nullptr, 0, sc->ticket, sc->part, gx * 128);
+        const int slices = (npairs <= 2 ? 8 : npairs <= 4 ? 4 : npairs <= 8 ? 3 : 2) * (qt == 2 ? 2 : 1);
+        if (hak_match_scratch_reserve(sc, st, 0, (long)npairs * gx, (long)npairs * slices * gx * qpb, 0, 0)) {
+            mm_launch<false>(qt, dim3(gx, slices, npairs), st, pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2,
+                             2, 0, (int4*)nullptr, 0L, sc->ticket, sc->part, gx * qpb);
             return;
         }
     }
     dim3 grid(gx, npairs);
-    if (!valu) k_match_mfma<false, MM_BCH><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, 0,
-                                                        nullptr, 0, nullptr, nullptr, 0);
+    if (!valu) mm_launch<false>(qt, grid, st, pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, 0,
+                                (int4*)nullptr, 0L, (int*)nullptr, (uint2*)nullptr, 0);
     else if (two) k_match<2><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
     else k_match<1><<<grid, 256, 0, st>>>(pts1, pts2, n1_dev, n2_dev, n1_host, n2_host, pair_stride1, pair_stride2, 2, nullptr, 0);
 }

@@ -402,10 +402,12 @@ def gpu_match(ah, torch, p1, p2):
     return out
 
 
-@pytest.fixture(params=["0", "1"], ids=["k_match_mfma", "k_match (VALU)"])
+@pytest.fixture(params=["0", "qt2", "1"], ids=["k_match_mfma", "k_match_mfma 64-query waves", "k_match (VALU)"])
 def match_kernel(request, monkeypatch):
-    """both matcher kernels: the matrix-core one (default) and the vector-pipe one (HAK_MATCH_VALU=1, read per call)"""
-    monkeypatch.setenv("HAK_MATCH_VALU", request.param)
+    """the matcher kernels: the matrix-core one (default: 32-query waves; HAK_MATCH_QT=2: 64-query waves, one wave per SIMD) and the
+    vector-pipe one (HAK_MATCH_VALU=1); both variables are read per call"""
+    monkeypatch.setenv("HAK_MATCH_VALU", "1" if request.param == "1" else "0")
+    monkeypatch.setenv("HAK_MATCH_QT", "2" if request.param == "qt2" else "1")
     return request.param
 
 
