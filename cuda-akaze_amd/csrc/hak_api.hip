@@ -289,6 +289,12 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     // ... and so must the survivor bitmap and the row counts (hak_launch_clear_maps restores all three)
     if (e == hipSuccess) e = hipMemset(c->bitmap, 0, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
     if (e == hipSuccess) e = hipMemset(c->rowcount, 0, sizeof(int) * (size_t)L.oct[0].h * B);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->hess_stream, hipStreamNonBlocking);
+    for (int s = 0; s < HAK_MAX_SCALES && e == hipSuccess; s++) {
+        e = hipEventCreateWithFlags(&c->ev_hs[s], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_hd[s], hipEventDisableTiming);
+    }
+    if (const char* s = getenv("HAK_HESS_SIDE")) c->hess_side = atoi(s);
     for (int o = 0; o < L.noct && e == hipSuccess; o++) {
         if (o > 0) e = hipStreamCreateWithFlags(&c->oct_stream[o], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_ready[o], hipEventDisableTiming);
@@ -321,6 +327,11 @@ extern "C" void hak_destroy(hak_ctx* c)
         if (c->oct_stream[o]) { (void)hipStreamSynchronize(c->oct_stream[o]); (void)hipStreamDestroy(c->oct_stream[o]); }
         if (c->ev_ready[o]) (void)hipEventDestroy(c->ev_ready[o]);
         if (c->ev_done[o]) (void)hipEventDestroy(c->ev_done[o]);
+    }
+    if (c->hess_stream) { (void)hipStreamSynchronize(c->hess_stream); (void)hipStreamDestroy(c->hess_stream); }
+    for (int s = 0; s < HAK_MAX_SCALES; s++) {
+        if (c->ev_hs[s]) (void)hipEventDestroy(c->ev_hs[s]);
+        if (c->ev_hd[s]) (void)hipEventDestroy(c->ev_hd[s]);
     }
     for (auto& p : c->prof)
         for (auto ev : p.ev) (void)hipEventDestroy(ev);
@@ -434,9 +445,10 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     bool hess_lp[HAK_MAX_OCTAVES * HAK_MAX_SCALES] = {};     // the level's Hessian low-passes Lt(o,s-1) itself: `smooth` was not written
     static const bool level_hess_on = [] { const char* e = getenv("HAK_LEVEL_HESS"); return !e || atoi(e) != 0; }();
     // ---- part A of level (o, s): build Lt(o, s) and the sigma=1 low-pass `smooth` the level's Hessian reads (akaze.cpp:325-421)
-    auto build_level = [&](int o, int s, hipStream_t st) {
+    // smooth_alt != nullptr: the level's sigma=1 low-pass goes there instead of the octave's `smooth` plane (side-stream Hessians below)
+    auto build_level = [&](int o, int s, hipStream_t st, float* smooth_alt = nullptr) {
         const HakOct oc = L.oct[o];
-        float* smooth = A + L.smooth_off[o];
+        float* smooth = smooth_alt ? smooth_alt : A + L.smooth_off[o];
         float* flow = A + L.flow_off[o];
         float* tmp = A + L.tmp_off[o];
         const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
@@ -536,12 +548,12 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     // ---- part B of level (o, s): derivatives + determinant + extrema (akaze.cpp:354, 423, 431-433).  Level (0, 0) differentiates
     // Lt itself, every other level the low-pass of its predecessor (D13).  (The determinant goes to HBM only in the dilation > 4
     // fallback: `flow` is free at every call.)
-    auto hessian_level = [&](int o, int s, hipStream_t st) {
+    auto hessian_level = [&](int o, int s, hipStream_t st, const float* smooth_alt = nullptr) {
         if (hess_fused[o * HAK_MAX_SCALES + s]) return;              // done inside k_level_tile
         const HakOct oc = L.oct[o];
         const LevelPlan& lp = c->plan[(size_t)o * L.ms + s];
         const bool lph = hess_lp[o * HAK_MAX_SCALES + s];
-        const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : lph ? A + L.lt(o, s - 1) : A + L.smooth_off[o];
+        const float* hsrc = (o == 0 && s == 0) ? A + L.lt(0, 0) : lph ? A + L.lt(o, s - 1) : smooth_alt ? smooth_alt : A + L.smooth_off[o];
         ProfScope ps(c, HAK_PROF_HESSIAN, st);
         if (!hak_launch_hessian_level(st, hsrc, A + L.dxy(o, s), A + L.flow_off[o], false, S, oc.w, oc.h, oc.p, nimg,
                                       lp.sigma_size, &b, &L, &c->htab, o, s, cfg.dthreshold, lph ? c->taps1 : nullptr))
@@ -609,6 +621,21 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
     } else {
         // each octave on its own stream, chained by events: the small octaves' launches are latency chains of a few hundred waves
         // and hide under octave 0's chip-filling kernels
+        // Small launches in the tile-kernel regime (a pair, a handful of images): octave 0 is the longest chain, and a third of it
+        // are its four Hessians, which nothing in the scale space waits for.  They move to a stream of their own.  The only
+        // hazard is the `smooth` plane (level s's Hessian reads it, level s+1's low-pass overwrites it): the levels alternate
+        // between `smooth` and `tmp`, which is free in an octave whose FED cycles are single launches (G = 1: the cycle lands in
+        // Lt directly), so level s+1's low-pass only waits for the Hessian of level s-1.  profiles/r05_pair_serial_timeline.txt:
+        // 292 us of chain (alone) become 183 + the last Hessian.
+        // MEASURED, OFF BY DEFAULT (HAK_HESS_SIDE=1): the pair call gets SLOWER, 0.567-0.572 -> 0.620-0.623 ms (4 or 5 hardware
+        // queues alike; 6: 0.82): as with the spine order of round 4, a fifth chain of two-image kernels stretches the other four by
+        // more than the critical chain shrinks -- the call is bound by the chip's throughput on these small kernels, not by the
+        // order they are issued in.
+        bool side0 = c->hess_side != 0 && c->concurrent && L.noct > 1 && c->hess_stream && L.ms <= HAK_MAX_SCALES &&
+                     !hak_stream_pays(c->knobs.hess_stream, L.oct[0].w, L.oct[0].h, nimg) && !level_tile_pays(c, L.oct[0], nimg) &&
+                     !hak_stream_pays(c->fuse_sf, L.oct[0].w, L.oct[0].h, nimg);
+        for (int s = 1; s < L.ms && side0; s++)
+            side0 = hak_fed_groups(c->plan[s].nsteps, c->max_fuse, L.oct[0].w) == 1 && c->plan[s].sigma_size <= 4;
         hipStream_t st = main_st;
         for (int o = 0; o < L.noct; o++) {
             if (c->concurrent && o > 0) {                       // this octave's chain waits only for Lt(o-1,0)
@@ -616,6 +643,18 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
                 if (hipStreamWaitEvent(st, c->ev_ready[o - 1], 0) != hipSuccess) return fail("stream wait");
             }
             for (int s = 0; s < L.ms; s++) {
+                if (o == 0 && side0) {
+                    float* sm = (s & 1) ? A + L.tmp_off[0] : A + L.smooth_off[0];
+                    // (level s's low-pass target was last read by the Hessian of level s - 2)
+                    if (s >= 2 && hipStreamWaitEvent(st, c->ev_hd[s - 2], 0) != hipSuccess) return fail("stream wait");
+                    build_level(0, s, st, sm);
+                    if (s == 0) (void)hipEventRecord(c->ev_ready[0], st);
+                    (void)hipEventRecord(c->ev_hs[s], st);
+                    if (hipStreamWaitEvent(c->hess_stream, c->ev_hs[s], 0) != hipSuccess) return fail("stream wait");
+                    hessian_level(0, s, c->hess_stream, sm);
+                    (void)hipEventRecord(c->ev_hd[s], c->hess_stream);
+                    continue;
+                }
                 build_level(o, s, st);
                 if (c->concurrent && s == 0) (void)hipEventRecord(c->ev_ready[o], st);   // Lt(o,0) final: octave o+1 may start
                 hessian_level(o, s, st);
@@ -625,6 +664,8 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
         if (c->concurrent)
             for (int o = 1; o < L.noct; o++)
                 if (hipStreamWaitEvent(main_st, c->ev_done[o], 0) != hipSuccess) return fail("stream join");
+        if (side0)                                              // (the stream runs in order: its last event covers all four)
+            if (hipStreamWaitEvent(main_st, c->ev_hd[L.ms - 1], 0) != hipSuccess) return fail("stream join");
     }
     // the scale space (bound by HBM stores) is done, the keypoint stages (bound by gathers and integer work) begin: a caller that
     // runs two contexts lets the other one start its scale space here (hak_phase_event)

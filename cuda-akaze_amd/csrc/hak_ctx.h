@@ -55,6 +55,11 @@ struct hak_ctx {
     // latency-bound small-octave launches overlap octave 0's heavy kernels
     hipStream_t oct_stream[HAK_MAX_OCTAVES] = {};      // [0] unused (= stream)
     hipEvent_t ev_ready[HAK_MAX_OCTAVES] = {}, ev_done[HAK_MAX_OCTAVES] = {};
+    // small launches (a pair, a handful of images): octave 0's Hessians leave its FED chain for a stream of their own (enqueue_detect)
+    hipStream_t hess_stream = nullptr;
+    hipEvent_t ev_hs[HAK_MAX_SCALES] = {}, ev_hd[HAK_MAX_SCALES] = {};   // level s's Hessian input ready / its Hessian done
+    int hess_side = 0;              // HAK_HESS_SIDE=1: on for launches in the tile-kernel regime.  Off by default: measured SLOWER (pair call
+                                    // 0.62 vs 0.57 ms) -- a fifth concurrent chain stretches the other four more than the shorter chain gains
     bool concurrent = true;
     // the launch sequence has no host-side data dependence, so it is captured once per argument set and replayed
     bool use_graph = true;          // env HAK_GRAPH=0 disables; profiling (event pairs) always runs eagerly

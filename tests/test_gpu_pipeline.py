@@ -156,13 +156,15 @@ def test_natural_1080p_pair_vs_oracle(ah, okz, torch, synth, golden):
         assert_points_equal(gpu_fast_detect(ah, torch, rec[name]), r.points)
 
 
-@pytest.mark.parametrize("pinned", [True, False], ids=["pinned h_data", "pageable h_data"])
-def test_pair_call_equals_the_three_calls(ah, okz, torch, synth, golden, pinned):
+@pytest.mark.parametrize("pinned,side", [(True, "0"), (False, "0"), (True, "1")],
+                         ids=["pinned h_data", "pageable h_data", "pinned h_data, octave-0 Hessians on a side stream"])
+def test_pair_call_equals_the_three_calls(ah, okz, torch, synth, golden, monkeypatch, pinned, side):
     """hak_detect_and_compute_pair / Akazer.detectAndComputePair: both images + cuMatch as ONE launch sequence -- byte for byte what
     detectAndCompute x 2 + cuMatch leave in the two AkazeData (device and host arrays), on the reference's bundled pair; with
     unequal capacities every image keeps ITS OWN clamp (setMaxNumPoints(result.max_pts), akaze.cpp:246, 451) -- that call comes
     FIRST, on a fresh context, so that no earlier full-capacity call can have left the expected records in the pair buffer --
     and without the match"""
+    monkeypatch.setenv("HAK_HESS_SIDE", side)           # (read by hak_create: the launch order HAK_HESS_SIDE=1 selects is off by default)
     a, b = golden.lr_u8["left"], golden.lr_u8["right"]
     h, w = a.shape
     p = ah.iAlignUp(w, 128)
