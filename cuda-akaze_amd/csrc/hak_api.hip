@@ -690,7 +690,9 @@ static int enqueue_detect(hak_ctx* c, const float* d_images, long image_stride, 
       hak_launch_nms_emit(main_st, b, L, c->dtab, c->psz, d_points, max_pts, d_num_pts);
       // the clean-up for the next sequence needs only the candidate list: beside the descriptor kernels, not in front of them
       static const bool tail_fork_on = [] { const char* e = getenv("HAK_TAIL_FORK"); return !e || atoi(e) != 0; }();
-      tail_fork = spine && tail_fork_on;         // (batches: no gain beside 5 ms of descriptor kernels, A/B 5 640 vs 5 710 pairs/s)
+      // (batches: no gain beside 5 ms of descriptor kernels, A/B 5 640 vs 5 710 pairs/s; the pair call: the fork's two cross-stream
+      // waits in the replayed graph cost more than the 5 us kernel they move aside, 0.571 vs 0.544 ms, round 5)
+      tail_fork = spine && tail_fork_on;
       if (tail_fork) {
           (void)hipEventRecord(c->ev_tail_fork, main_st);
           if (hipStreamWaitEvent(c->oct_stream[1], c->ev_tail_fork, 0) != hipSuccess) return fail("stream wait");

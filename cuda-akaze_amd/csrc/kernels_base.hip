@@ -325,8 +325,13 @@ bool hak_launch_base_level(hipStream_t st, const float* img, long img_stride, in
     default: k_base_a<5><<<grid, 256, 0, st>>>(img, img_stride, sp, lt, grad_scratch, stride, w, h, p, t, state, tpb, ntx, nby, nimg); break;
     }
     if (grad_scratch) {
-        int rpb = 8;
-        while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < 2048) rpb >>= 1;
+        static const long hist_min_blocks = [] { const char* e = getenv("HAK_HIST_MIN_BLOCKS"); const long v = e ? atol(e) : 256; return v < 1 ? 1 : v; }();
+        static const int hist_rpb_max = [] { const char* e = getenv("HAK_HIST_RPB_MAX"); const int v = e ? atoi(e) : 8; return v < 1 ? 1 : v; }();
+        int rpb = hist_rpb_max;
+        while (rpb > 1 && (long)((h + rpb - 1) / rpb) * nimg < hist_min_blocks) rpb >>= 1;
+        // rows per block: 8 unless that leaves fewer than 256 blocks (round 5; 2048 before: a pair's two images then ran 2 160 one-row
+        // blocks, each zeroing 2 400 LDS words and flushing its bins with global atomics for 1 920 pixels -- 27 us alone, on the
+        // critical chain of the pair call; with 8 rows per block the call is 0.547 instead of 0.567 ms, batches are unchanged)
         // (noct = 0: the contrast factor stays a launch of its own.  Letting the last histogram block finish it was measured:
         // the fence every block then needs behind its ~300 bin atomics, which are otherwise fire-and-forget, took the kernel from
         // 22 to 73 us on a single 1080p image -- far more than the launch it saves)
