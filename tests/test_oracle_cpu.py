@@ -247,3 +247,28 @@ def test_oracle_knn2_edge_cases(okz):
     assert got[0]["query"] == 0 and got[0]["distance"] == 0 and got[0]["second"] == 512
     got = okz.match_knn2(q, one, cross=True)
     assert len(got) == 1
+
+
+def test_hmax_racy_remainder_is_inert_on_every_fixture(okz, golden):
+    """gFindMaxContrastU4's deterministic core is the lattice maximum (what the oracle takes); its racy remainder -- thread 0 of a block
+    also compares with eight pixels of the image's top-left tile, which other blocks lower and block (0, 0) raises -- can add at most
+    max(grad[0..31][0..31]) (akazed.cu:859-873).  On every input the goldens, the bench and the statistical pin use,
+    that bound lies BELOW the lattice maximum: there the reference's hmax is the oracle's exactly, whatever the race does."""
+    import os
+    from akaze_hip import synth
+    from conftest import GOLDEN
+    rec = np.load(os.path.join(GOLDEN, "ref_recon_1080p_u8.npz"))
+    imgs = [golden.lr_u8["left"], golden.lr_u8["right"], rec["img1"], rec["img2"]]
+    for seed in (1, 2, 3, 9, 16):
+        imgs += list(synth.pair(1920, 1080, seed))
+    for seed in (1, 8):
+        imgs += list(synth.pair(1280, 720, seed))
+    for u8 in imgs:
+        h, w = u8.shape
+        p = (w + 127) // 128 * 128
+        g = okz.scharr_grad(okz.lowpass(synth.to_float(u8, p), w, 1.0, 2), w)[:, :w]
+        lattice = max(np.float32(0.03), g[::16, ::16].max())
+        assert g[:32, :32].max() <= lattice, (u8.shape, float(g[:32, :32].max()), float(lattice))
+        _, hmax, _ = okz.kcontrast(okz.scharr_grad(okz.lowpass(synth.to_float(u8, p), w, 1.0, 2), w), w, 0.7)
+        assert hmax == lattice
+
