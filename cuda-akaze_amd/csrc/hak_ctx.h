@@ -98,8 +98,14 @@ struct ProfScope {
         if (!c || !c->prof_on) return;      // (no context: hak_match(NULL, ...))
         ProfClass& p = c->prof[k];
         if (p.used + 2 > p.ev.size()) {
+            // timing-only events: without the system-scope fence a default event carries (hip_runtime_api.h, hipEventDisableSystemFence:
+            // "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation, and the
+            // performance impact of those actions on the execution of following work").  With default events every one of the ~190
+            // records of a profiled sequence wrote the L2 back and the next kernel started on an invalidated cache: the serial leg's
+            // FED class read 17.2 ms where rocprofv3 sees 16.3 ms for the same launches in a replayed sequence.  hak_prof_read
+            // synchronises the stream before it reads the events.
             hipEvent_t a, b;
-            (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+            (void)hipEventCreateWithFlags(&a, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&b, hipEventDisableSystemFence);
             p.ev.push_back(a); p.ev.push_back(b);
         }
         (void)hipEventRecord(p.ev[p.used], s);
