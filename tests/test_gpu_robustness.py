@@ -437,7 +437,10 @@ def test_download_batch_pinned_and_pageable(ah, torch, synth):
 # with 8 / 12 / 4 margin columns): exact multiples, one float4 over, last strip narrower than the margin, single strip; heights
 # around the 8..128-row segments and the 2S+1 / NS+4 warm-up rows
 SWEEP = [(240, 131), (244, 96), (248, 203), (252, 117), (232, 88), (236, 129), (480, 135), (484, 97), (472, 160), (720, 81),
-         (964, 92), (1204, 83), (196, 259), (300, 300), (1000, 130)]
+         (964, 92), (1204, 83), (196, 259), (300, 300), (1000, 130),
+         # odd extents with (n - 1) % 32 == 0: gFindMaxContrastU4's grid leaves the last lattice column / row to no block (hak_lattice_cov),
+         # and the histogram's 32 x 16 blocks hang 31 columns / 15 rows over the image (hak_hist_extra0); the tile kernels' path
+         (129, 97), (161, 225), (193, 100)]
 
 
 @pytest.mark.parametrize("w,h", SWEEP, ids=lambda v: str(v))
