@@ -27,4 +27,20 @@ def test_fp4_hamming_probe(tmp_path):
     assert b.returncode == 0, b.stderr[-2000:]
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert r.stdout.count("0 mismatches of 1024") == 2, r.stdout
+    # ... and round 5's form: the accumulator as the finished key, 2^10 + 2 d + P / 4 + q 2^-13 (first and last chunk number)
+    assert r.stdout.count(": 0 mismatches of 1024") == 4, r.stdout
+
+
+def test_access_shape_probes_run(ah):
+    """the floor probes of DESIGN.md 4 lesson 31 at small sizes (they are measurements, not checks: this only guards their launch
+    geometry against faults): the FED family's stream probe, the Hessian's (every dilation) and the random-sector probe"""
+    import ctypes as C
+    ms, gbs = C.c_double(), C.c_double()
+    for step in (1, 2, 3, 4):
+        ah.check(ah.lib.hak_op_hess_probe(480, 270, 8, step, 2, C.byref(ms), C.byref(gbs)))
+        assert ms.value > 0 and gbs.value > 10
+    ah.check(ah.lib.hak_op_hess_probe(244, 97, 3, 3, 1, C.byref(ms), C.byref(gbs)))
+    ah.check(ah.lib.hak_op_stream_probe(480, 270, 8, 2, 7, 2, C.byref(ms), C.byref(gbs)))
+    assert gbs.value > 10
+    ah.check(ah.lib.hak_op_gather_probe(1 << 28, 512, 16, 2, C.byref(ms)))
+    assert ms.value > 0
