@@ -93,6 +93,18 @@ static inline int iabs(int a) { return a < 0 ? -a : a; }
 
 int okz_sizeof_point(void) { return (int)sizeof(OkzPoint); }
 
+/* The team size of the oracle's parallel loops, set explicitly: OMP_NUM_THREADS is read once, when libgomp initialises -- in a
+ * process that has imported torch that happened long before the oracle's first call, and the loops then ran with one thread per
+ * logical CPU of the box (256 on the GPU boxes: 10 x slower than 16, which is what bench.py's cpu_baseline reported until round 5). */
+#ifdef _OPENMP
+#include <omp.h>
+void okz_set_num_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+int okz_get_max_threads(void) { return omp_get_max_threads(); }
+#else
+void okz_set_num_threads(int n) { (void)n; }
+int okz_get_max_threads(void) { return 1; }
+#endif
+
 /* ---------------------------------------------------------------- FED tau */
 
 /* fed.cpp:128-148 */

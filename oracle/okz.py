@@ -85,6 +85,12 @@ def lib():
     return _lib
 
 
+def set_num_threads(n):
+    """team size of the oracle's OpenMP loops (omp_set_num_threads: effective whatever OMP_NUM_THREADS said when libgomp started)"""
+    lib().okz_set_num_threads(int(n))
+    return lib().okz_get_max_threads()
+
+
 def ref_lib():
     """the reference's own fed.cpp, compiled from /root/reference (None when unavailable)"""
     if not os.path.exists(REF_LIB):

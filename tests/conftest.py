@@ -29,6 +29,13 @@ def okz():
     """the CPU parity oracle (oracle/akaze_oracle.c) -- the checker, never the thing under test on GPU"""
     import okz as _okz
     _okz.build()
+    # (a process that has imported torch has initialised libgomp with one thread per logical CPU: 256 on the GPU boxes, where the
+    # oracle's short loops then run ten times slower than on 16)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    _okz.set_num_threads(max(1, min(16, ncpu)))
     return _okz
 
 
