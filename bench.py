@@ -1015,9 +1015,24 @@ def main():
         ah.check(ah.lib.hak_prof_enable(det.ctx, 1))
         nprof = max(1, min(args.steps, 3))
         rl_pairs = chunks[0]                # the per-class legs run the launch sequence of the timed region (256 pairs by default)
+        # one untimed sequence first, like the timed region's warm-up: the first serial sequence after the switch creates the leg's
+        # ~400 events between its launches and reads 0.6-0.8 ms (4 %) more FED time than the ones after it (DESIGN.md 4 lesson 34)
+        pipe.enqueue(0, d_imgs, rl_pairs)
+        pipe.download(0, rl_pairs)
+        m2, n2 = C.c_double(), C.c_int()
+        ah.check(ah.lib.hak_prof_read(det.ctx, ah.PROF["fed"], C.byref(m2), C.byref(n2)))
+        fed_warm = round(m2.value, 4)
+        for k in ah.PROF.values():
+            ah.check(ah.lib.hak_prof_read(det.ctx, k, None, None))      # (collects and releases every class's events of that sequence)
+        ah.check(ah.lib.hak_prof_reset(det.ctx))
+        fed_seq, fed_cum = [], 0.0          # the FED class per profiled sequence (its run-to-run spread is part of the result)
         for _ in range(nprof):
             pipe.enqueue(0, d_imgs, rl_pairs)
             pipe.download(0, rl_pairs)
+            m2, n2 = C.c_double(), C.c_int()
+            ah.check(ah.lib.hak_prof_read(det.ctx, ah.PROF["fed"], C.byref(m2), C.byref(n2)))
+            fed_seq.append(round(m2.value - fed_cum, 4))
+            fed_cum = m2.value
         cls_ms, cls_n = {}, {}
         for name, k in ah.PROF.items():
             m2, n2 = C.c_double(), C.c_int()
@@ -1085,7 +1100,7 @@ def main():
                 "traffic_frac": None if traffic is None else round(traffic / avg_s / 1e9 / HBM_PEAK_GBS, 4),
                 "copy_ceiling_GBs": round(copy_gbs, 1), "frac_copy": round(achieved / copy_gbs, 4),
                 "bytes_per_launch": round(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 3),
-                "launches_per_step": fed_n,
+                "launches_per_step": fed_n, "fed_ms_by_sequence": fed_seq, "fed_ms_warmup_sequence": fed_warm,
                 # the unfused model of SURVEY 8d (12 B/px per STEP + 16 B/px of low-pass and conductivity) priced at the same time:
                 # how much HBM traffic temporal fusion removed -- a gain, not a utilisation
                 "unfused_model_GBs": round(unfused_GBs, 1), "fusion_gain": round(tr.fed_bytes / tr.fed_fused_bytes, 3),

@@ -134,6 +134,7 @@ TEST_SYMBOLS = {
     "hak_op_copy_probe_shapes": (C.c_int, [C.c_long, C.c_int, C.POINTER(C.c_double), C.c_int]),
     "hak_op_stream_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "hak_op_hess_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "hak_debug_fill_match_scratch": (C.c_int, [_vp, C.c_int]),
     "hak_op_gather_probe": (C.c_int, [C.c_long, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_double)]),
 }
 

@@ -289,6 +289,9 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     // ... and so must the survivor bitmap and the row counts (hak_launch_clear_maps restores all three)
     if (e == hipSuccess) e = hipMemset(c->bitmap, 0, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
     if (e == hipSuccess) e = hipMemset(c->rowcount, 0, sizeof(int) * (size_t)L.oct[0].h * B);
+    // (hipMemset fills on the NULL stream and may return before the fill has run; the context's streams are non-blocking and would
+    // not wait for it)
+    if (e == hipSuccess) e = hipStreamSynchronize(nullptr);
     if (const char* s = getenv("HAK_HESS_SIDE")) c->hess_side = atoi(s);
     // (only when asked for, and behind the octave streams: the runtime deals a process's streams to its four hardware queues in
     // creation order, so one more stream per context moves every later stream to another queue -- creating it unconditionally put
@@ -1131,6 +1134,7 @@ extern "C" int hak_points_alloc(hak_point** d, int count)
 {
     HIP_TRY(hipMalloc((void**)d, sizeof(hak_point) * (size_t)count));
     HIP_TRY(hipMemset(*d, 0, sizeof(hak_point) * (size_t)count));
+    HIP_TRY(hipStreamSynchronize(nullptr));                     // (the fill runs on the NULL stream; the caller's streams need not wait for that one)
     return 0;
 }
 extern "C" int hak_points_free(hak_point* d) { HIP_TRY(hipFree(d)); return 0; }

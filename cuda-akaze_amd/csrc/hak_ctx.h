@@ -100,12 +100,12 @@ struct ProfScope {
         if (p.used + 2 > p.ev.size()) {
             // timing-only events: without the system-scope fence a default event carries (hip_runtime_api.h, hipEventDisableSystemFence:
             // "can improve the accuracy of timing measurements by avoiding the cost of cache writeback and invalidation, and the
-            // performance impact of those actions on the execution of following work").  With default events every one of the ~190
-            // records of a profiled sequence wrote the L2 back and the next kernel started on an invalidated cache: the serial leg's
-            // FED class read 17.2 ms where rocprofv3 sees 16.3 ms for the same launches in a replayed sequence.  hak_prof_read
-            // synchronises the stream before it reads the events.
+            // performance impact of those actions on the execution of following work").  Measured on one box in alternating runs the
+            // difference is 0.3-0.4 % of the FED class (DESIGN.md 4 lesson 34: the leg's first sequence is what read 4 % high).
+            // hak_prof_read synchronises the stream before it reads the events.
+            static const unsigned evflags = [] { const char* e = getenv("HAK_PROF_FENCE"); return e && atoi(e) ? 0u : (unsigned)hipEventDisableSystemFence; }();   // (=1: default events, for A/B)
             hipEvent_t a, b;
-            (void)hipEventCreateWithFlags(&a, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&b, hipEventDisableSystemFence);
+            (void)hipEventCreateWithFlags(&a, evflags); (void)hipEventCreateWithFlags(&b, evflags);
             p.ev.push_back(a); p.ev.push_back(b);
         }
         (void)hipEventRecord(p.ev[p.used], s);

@@ -323,3 +323,12 @@ extern "C" int hak_op_gather_probe(long bytes, int blocks, int per_lane, int ite
     if (hak_launch_gather_probe(bytes & ~127L, blocks, per_lane & ~3, iters, ms_per_launch)) return fail("gather probe failed");
     return 0;
 }
+
+// the sliced matcher's per-slice summaries filled with `byte` on the context's stream (tests/stress_handoff.py: a stale read of a
+// summary is only visible when the scratch does not already hold the same launch's values from the call before)
+extern "C" int hak_debug_fill_match_scratch(hak_ctx* c, int byte)
+{
+    if (!c) return fail("null context");
+    if (c->msc.part && c->msc.part_cap > 0) HIP_TRY(hipMemsetAsync(c->msc.part, byte, sizeof(uint2) * (size_t)c->msc.part_cap, c->stream));
+    return 0;
+}

@@ -976,7 +976,9 @@ static bool grow(void** p, long* cap, long want, size_t elem, int fill, hipStrea
     if (*p) { (void)hipStreamSynchronize(st); (void)hipFree(*p); }
     *p = nullptr; *cap = 0;
     if (hipMalloc(p, elem * (size_t)want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; return false; }
-    if (fill >= 0 && hipMemset(*p, fill, elem * (size_t)want) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*p); *p = nullptr; return false; }
+    // (on the stream of the search itself: hipMemset works on the NULL stream and may return before the fill has run, and a context's
+    // stream is non-blocking -- nothing would order the fill in front of the kernel that takes the tickets)
+    if (fill >= 0 && hipMemsetAsync(*p, fill, elem * (size_t)want, st) != hipSuccess) { (void)hipGetLastError(); (void)hipFree(*p); *p = nullptr; return false; }
     *cap = want;
     return true;
 }

@@ -83,6 +83,9 @@ int hak_op_stream_probe(int w, int h, int nimg, int nwrite, int warm_rows, int i
  * two dense 16-byte nt buffer stores per lane and row, at the kernel's LDS footprint and occupancy target; *gbytes_per_s = 12 B/px
  * compulsory / average kernel time: the data-movement floor of the Hessian class at that launch geometry. */
 int hak_op_hess_probe(int w, int h, int nimg, int step, int iters, double* ms_per_launch, double* gbytes_per_s);
+/* hak_debug_fill_match_scratch: fills the context's per-slice match summaries (kernels_match.hip: `part`) with `byte`, on the context's
+ * stream -- the hand-off stress run makes a stale summary visible with it (tests/stress_handoff.py) */
+int hak_debug_fill_match_scratch(hak_ctx* ctx, int byte);
 
 #ifdef __cplusplus
 }

@@ -252,6 +252,19 @@ void okz_scharr_grad(const float* src, float* grad, int w, int h, int p)
         }
 }
 
+
+/* double / float -> int as the device does it (cvt.rzi.s32: toward zero, SATURATING, NaN -> 0); a C cast of a NaN or of a value
+ * outside the int range is undefined (x86: INT_MIN).  Needed where the reference's arithmetic can leave the finite range: a constant
+ * image has hmax == 0, hfactor == inf and 0 * inf == NaN in every histogram bin index (akazed.cu:924), and a sample without gradient has
+ * atan2(0, 0) -- NaN through the polynomial -- as its angle (akazed.cu:1702). */
+static inline int okz_d2i(double v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0) return 2147483647;
+    if (v <= -2147483648.0) return (int)0x80000000;
+    return (int)v;
+}
+
 /* akazed.cu:2410-2484 hScharrContrast host half + 827-877 gFindMaxContrastU4 + 901-938 gConstrastHistShared.
  * hist (300 ints) and hmax are optional outputs.
  *
@@ -297,7 +310,7 @@ float okz_kcontrast(const float* grad, int w, int h, int p, float per, float* hm
             /* __fmul_rz(grad, factor) then float->int truncation (:924):
              * the double product of two floats is exact, so truncating it
              * equals truncating the RZ-rounded float product. */
-            int hi = (int)((double)grad[(size_t)y * p + x] * (double)hfactor);
+            int hi = okz_d2i((double)grad[(size_t)y * p + x] * (double)hfactor);
             if (hi >= OKZ_NBINS) hi = OKZ_NBINS - 1;
             hist[hi]++;
         }
@@ -554,7 +567,7 @@ void okz_orient_point(OkzPoint* pt, const float* dxd, const float* dyd, int o, i
         float dx = gweight * dxd[pos];
         float dy = gweight * dyd[pos];
         float angle = okz_atan2f(dy, dx);
-        int a = (int)(angle * (21 / OKZ_PI_D)) + 21;                    /* :1702 (double) */
+        int a = okz_d2i(angle * (21 / OKZ_PI_D)) + 21;                  /* :1702 (double) */
         a = a > 41 ? 41 : a;
         a = a < 0 ? 0 : a;
         resx[a] += dx;

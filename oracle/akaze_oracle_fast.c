@@ -54,6 +54,26 @@ static inline int fiabs(int a) { return a < 0 ? -a : a; }
 static inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }   /* F1 */
 static inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+/* float -> int as the device does it (cvt.rzi.s32.f32 / v_cvt_i32_f32: toward zero, SATURATING, NaN -> 0).  A C cast of a NaN or of
+ * a value outside the int range is undefined and x86 delivers INT_MIN for all of them.  It matters where the integer pipeline has
+ * left its range: a long FED cycle at a coarse level (tau up to ~50 against 16-bit truncations) can blow the plane up, the wrapped
+ * sum of squares of gFlowNaive (akazed.cu:3427) turns NEGATIVE, and the conductivity is then sqrt of a negative number (Charbonnier:
+ * NaN) or exp of a huge one (PM_G1: inf) -- found by tests/fuzz_parity.py, round 5; likewise the rotated derivatives of gDescribe2
+ * (akazed.cu:3779-3780). */
+static inline int d2i_sat(double v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0) return 2147483647;
+    if (v <= -2147483648.0) return (int)0x80000000;
+    return (int)v;
+}
+static inline int f2i_sat(float v)
+{
+    if (v != v) return 0;
+    if (v >= 2147483648.0f) return 2147483647;
+    if (v <= -2147483648.0f) return (int)0x80000000;
+    return (int)v;
+}
 
 /* akazed.cu:3855-3900 fastakaze::createGaussKernel: ik[i] = (int)(k[i]*65536 + 0.5f) */
 void fkz_gauss_taps(float var, int radius, int* ik)
@@ -163,7 +183,7 @@ int fkz_kcontrast(const int* smooth, int w, int h, int p, float per, int* hmax_o
         for (int x = 0; x < w; x++) {
             int dx, dy;
             fscharr(smooth, x, y, w, h, p, &dx, &dy);
-            int g = (int)(sqrtf((float)wadd(wmul(dx, dx), wmul(dy, dy))) + 0.5f);   /* :3231 */
+            int g = f2i_sat(sqrtf((float)wadd(wmul(dx, dx), wmul(dy, dy))) + 0.5f);   /* :3231 */
             grad[(size_t)y * w + x] = g;
             if (g > hmax && x % lat == 0 && y % lat == 0 && x < wcov && y < hcov) hmax = g;   /* :3245-3296 */
         }
@@ -207,7 +227,7 @@ void fkz_flow(const int* src, int* dst, int type, int kcontrast, int w, int h, i
             else if (type == 1) g = 1.f / (1.f + dif2);
             else if (type == 2) { float d2 = dif2 * dif2; g = 1.f - okz_expf(-3.315f / (d2 * d2)); }
             else g = 1.f / sqrtf(1.f + dif2);
-            dst[(size_t)y * p + x] = (int)(g * 65536 + 0.5f);
+            dst[(size_t)y * p + x] = f2i_sat(g * 65536 + 0.5f);         /* :3431-3443: a device cast (NaN -> 0, saturating): dif2 < 0 once the sum of squares has wrapped */
         }
 }
 
@@ -373,7 +393,7 @@ void fkz_orient(FkPoint* pt, const int* dxd, const int* dyd, int o, int w, int h
         size_t pos = (size_t)clampi(y + step * j, 0, h - 1) * p + clampi(x + step * i, 0, w - 1);
         float dx = wtab[r2] * dxd[pos], dy = wtab[r2] * dyd[pos];
         float angle = fast_atan2(dy, dx);
-        int a = (int)(angle * (21 / OKZ_PI_D)) + 21;
+        int a = d2i_sat(angle * (21 / OKZ_PI_D)) + 21;                 /* (NaN for a sample without gradient: 0 on the device) */
         a = a > 41 ? 41 : a; a = a < 0 ? 0 : a;
         resx[a] += dx; resy[a] += dy;
     }
@@ -406,8 +426,8 @@ void fkz_describe(FkPoint* pt, const int* imd, const int* dxd, const int* dyd, i
         int yp = clampi((int)(yf + scale * (k * si + l * co) + 0.5f), 0, h - 1);
         size_t pos = (size_t)yp * p + xp;
         int im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-        int rx = (int)(-dx * si + dy * co);                             /* akazed.cu:3777 */
-        int ry = (int)(dx * co + dy * si);
+        int rx = f2i_sat(-dx * si + dy * co);                           /* akazed.cu:3777 */
+        int ry = f2i_sat(dx * co + dy * si);
         if (m < 2 * size2) { int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)); acc[c] = wadd(acc[c], im); acc[c + 1] = wadd(acc[c + 1], rx); acc[c + 2] = wadd(acc[c + 2], ry); }
         if (m < 3 * size3) {
             int x3 = (x < size3 ? 0 : (x < 2 * size3 ? 1 : 2)), y3 = (y < size3 ? 0 : (y < 2 * size3 ? 1 : 2));

@@ -44,3 +44,21 @@ def test_access_shape_probes_run(ah):
     assert gbs.value > 10
     ah.check(ah.lib.hak_op_gather_probe(1 << 28, 512, 16, 2, C.byref(ms)))
     assert ms.value > 0
+
+
+def test_stream_ordering_probe(tmp_path):
+    """what the library relies on, and what it must not rely on, when a caller's blocking runtime calls meet its non-blocking streams
+    (tools/probes/memset_order_probe.hip): a blocking hipMemcpy / hipMemcpy2D from host memory IS complete when it returns (the
+    reference's upload pattern, main.cpp:181-188, needs no extra synchronisation) -- while hipMemset returns before its fill has run and
+    nothing orders that fill in front of a kernel on a non-blocking stream (round 5: the matcher's ticket array was cleared that way;
+    1 launch in 600 saw the old contents)"""
+    cc = _hipcc()
+    if cc is None:
+        pytest.skip("no hipcc on this box")
+    exe = str(tmp_path / "memset_probe")
+    b = subprocess.run([cc, "--offload-arch=gfx950", "-O2", "-o", exe, os.path.join(ROOT, "tools", "probes", "memset_order_probe.hip")],
+                       capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "non-blocking stream: 0 stale words in 10 x 128" in r.stdout, r.stdout       # the blocking copies

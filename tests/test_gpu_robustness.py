@@ -487,3 +487,31 @@ def test_strip_geometry_sweep_both_paths(ah, okz, torch, synth, w, h):
         assert_points_equal(data.h_data[:data.num_pts], rf.points)
     ah.freeAkazeData(data)
     det.close()
+
+
+def test_constant_image_vs_oracle_both_paths(ah, okz, torch, synth):
+    """a constant image: hmax = 0, hfactor = inf, every histogram index 0 * inf = NaN -> bin 0 by the device cast (akazed.cu:924): no
+    keypoints and the same contrast factor as the oracle, float and FAST; then a real image through the same context"""
+    w, h = 320, 240
+    p = ah.iAlignUp(w, 128)
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=2000)
+    data = ah.AkazeData()
+    ah.initAkazeData(data, 2000, True, True)
+    flat = torch.full((h, p), 0.25, dtype=torch.float32, device="cuda")
+    det.detectAndCompute(flat.data_ptr(), data, (w, h, p), True)
+    r = okz.detect_and_compute(np.full((h, p), 0.25, np.float32), w)
+    assert data.num_pts == 0 == len(r.points)
+    kc = C.c_float()
+    ah.check(ah.lib.hak_debug_kcontrast(det.ctx, 0, C.byref(kc)))
+    assert np.float32(kc.value).tobytes() == np.float32(r.kcontrast).tobytes()
+    flat8 = torch.full((h, p), 64, dtype=torch.uint8, device="cuda")
+    det.fastDetectAndCompute(flat8.data_ptr(), data, (w, h, p), True)
+    assert data.num_pts == 0 == len(okz.fast_detect_and_compute(np.full((h, w), 64, np.uint8)).points)
+    u8 = _mg().case_scene(w, h, 5)
+    det.detectAndCompute(torch.from_numpy(synth.to_float(u8, p)).cuda().data_ptr(), data, (w, h, p), True)
+    want = okz.detect_and_compute(synth.to_float(u8, p), w, max_pts=2000).points
+    assert data.num_pts == len(want) > 20
+    assert_points_equal(data.h_data[:data.num_pts], want)
+    ah.freeAkazeData(data)
+    det.close()

@@ -272,3 +272,12 @@ def test_hmax_racy_remainder_is_inert_on_every_fixture(okz, golden):
         _, hmax, _ = okz.kcontrast(okz.scharr_grad(okz.lowpass(synth.to_float(u8, p), w, 1.0, 2), w), w, 0.7)
         assert hmax == lattice
 
+
+
+def test_constant_image_both_oracles(okz):
+    """hmax == 0: hfactor = inf and every bin index is 0 * inf = NaN, which the device cast turns into bin 0 (akazed.cu:924; a C cast is
+    undefined there and x86 would index the histogram with INT_MIN) -- no keypoints, no crash, in both pipelines"""
+    r = okz.detect_and_compute(np.full((240, 384), 0.25, np.float32), 320)
+    assert len(r.points) == 0
+    rf = okz.fast_detect_and_compute(np.full((240, 320), 64, np.uint8))
+    assert len(rf.points) == 0 and rf.kcontrast == 0
