@@ -13,6 +13,8 @@ What a case draws (reference: main.cpp:156-166 for the parameter set, akaze.cpp:
   params    octaves 1-5, sublevels 2-5, per, dthreshold, soffset, derivative factor, all four diffusivities, pattern size, upright,
             max_pts small enough to clamp in a quarter of the cases
   content   drawn scenes (tests/golden/make_golden.case_scene), optionally with uniform noise on top
+  legs      float batch -> 1-NN pair matching [-> 2-NN + ratio + cross-check] [-> the batch again on rolled images] [-> the pair call with a
+            clamp of its own for image 2, pinned or pageable host arrays] -> the single-image call [-> FAST batch -> FAST single call]
 """
 import argparse
 import ctypes as C
@@ -56,8 +58,9 @@ def draw_case(seed, index, big=False):
         kw = dict(noctaves=pick((3, 4, 4, 5)), max_scale=pick((3, 4, 4)), per=pick((0.5, 0.7, 0.7, 0.9)), dthreshold=pick((0.0005, 0.001, 0.001)),
                   soffset=pick((1.2, 1.6, 1.6, 2.0)), derivative_factor=pick((1.0, 1.5, 1.5, 2.0)), diffusivity=pick((1, 1, 1, 0, 2, 3)),
                   descriptor_pattern_size=pick((10, 10, 8, 12)), upright=bool(rng.random() < 0.2))
-        return dict(index=index, w=w, h=h, B=B, kw=kw, mode=pick(("size rule", "size rule", "streaming")), max_pts=pick((2000, 10000, 10000)),
-                    noise=pick((0, 0, 6)), scene_seed=int(rng.integers(1 << 20)), fast=bool(rng.random() < 0.5), desc=True)
+        c = dict(index=index, w=w, h=h, B=B, kw=kw, mode=pick(("size rule", "size rule", "streaming")), max_pts=pick((2000, 10000, 10000)),
+                 noise=pick((0, 0, 6)), scene_seed=int(rng.integers(1 << 20)), fast=bool(rng.random() < 0.5), desc=True)
+        return draw_more(c, rng, pick)
     if rng.random() < 0.33:
         # strip edges of the streaming kernels (240 / 232 / 248 stored columns per wave), 16-byte rows, lattice-blind extents
         w = max(80, pick((240, 480, 720, 960, 232, 464, 248, 496, 256, 512, 1024, 1280)) + pick((-1, 0, 1, 4, 5)))
@@ -74,15 +77,27 @@ def draw_case(seed, index, big=False):
               dthreshold=pick((0.0005, 0.001, 0.001, 0.003)), soffset=pick((1.2, 1.6, 1.6, 2.0)),
               derivative_factor=pick((1.0, 1.5, 1.5, 2.0, 2.5)), diffusivity=pick((1, 1, 1, 0, 2, 3)),
               descriptor_pattern_size=pick((10, 10, 6, 8, 12)), upright=bool(rng.random() < 0.2))
-    return dict(index=index, w=w, h=h, B=B, kw=kw, mode=pick(tuple(MODES)), max_pts=pick((150, 3000, 3000, 10000)),
-                noise=pick((0, 0, 0, 6, 40)), scene_seed=int(rng.integers(1 << 20)), fast=bool(rng.random() < 0.6),
-                desc=bool(rng.random() < 0.9))
+    c = dict(index=index, w=w, h=h, B=B, kw=kw, mode=pick(tuple(MODES)), max_pts=pick((150, 3000, 3000, 10000)),
+             noise=pick((0, 0, 0, 6, 40)), scene_seed=int(rng.integers(1 << 20)), fast=bool(rng.random() < 0.6),
+             desc=bool(rng.random() < 0.9))
+    return draw_more(c, rng, pick)
+
+
+def draw_more(c, rng, pick):
+    """the legs added after the first long runs (drawn last, so that the earlier fields of a (seed, index) keep their values):
+    knn2 = (ratio, cross-check) of the 2-NN search on the batch's pairs; pair = (clamp of image 2 as a fraction of max_pts, pinned host
+    arrays) for the one-launch-sequence pair call; again = the batch a second time on rolled images (same buffers: a replayed graph)"""
+    c["knn2"] = (pick(((1, 1), (4, 5), (3, 4))), bool(rng.random() < 0.5)) if rng.random() < 0.5 else None
+    c["pair"] = (pick((1.0, 1.0, 0.5, 0.1)), bool(rng.random() < 0.5)) if rng.random() < 0.5 else None
+    c["again"] = bool(rng.random() < 0.4)
+    return c
 
 
 def describe(c):
     kw = ",".join(f"{k}={v}" for k, v in c["kw"].items())
     return (f"#{c['index']:<4d} {c['w']:4d}x{c['h']:<4d} B={c['B']:<2d} {c['mode']:<10s} max_pts={c['max_pts']:<5d} noise={c['noise']:<2d} "
-            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{kw}")
+            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}"
+            f"{'pair(%.1f%s) ' % (c['pair'][0], ',pinned' if c['pair'][1] else '') if c['pair'] else ''}{kw}")
 
 
 def diff_points(tag, got, want, fields):
@@ -155,6 +170,55 @@ def run_case(ah, okz, torch, synth, mg, c):
                 ok2 = all(not diff_points("", again[2 * k, :len(want[(2 * k) % nd])], okz.match(want[(2 * k) % nd].copy(), want[(2 * k + 1) % nd]), MFIELDS)
                           for k in range(B // 2))
                 fails.append(f"the same hak_match_batch launched a second time: {'equal to the oracle' if ok2 else 'still different'}; counts {nums.tolist()}")
+        # ---- 2-NN + ratio + cross-check on the same device records
+        if B >= 2 and c["desc"] and c["knn2"] and not fails:
+            ratio, cross = c["knn2"]
+            out = torch.zeros((B // 2) * mp * 32, dtype=torch.uint8, device="cuda")
+            cnt = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
+            ah.check(ah.lib.hak_match_knn2_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B // 2, ratio[0], ratio[1], int(cross), 0, out.data_ptr(), cnt.data_ptr()))
+            ah.check(ah.lib.hak_sync(det.ctx))
+            cnts = cnt.cpu().numpy()
+            allo = out.cpu().numpy().view(ah.MATCH_PAIR_DTYPE).reshape(B // 2, mp)
+            allk = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+            for k in range(B // 2):
+                a, b = want[(2 * k) % nd].copy(), want[(2 * k + 1) % nd]
+                wl = okz.match_knn2(a, b, ratio, cross)
+                if cnts[k] != len(wl):
+                    fails.append(f"knn2 pair {k}: {cnts[k]} accepted, oracle {len(wl)}")
+                    continue
+                for f in ah.MATCH_PAIR_DTYPE.names:
+                    if not np.array_equal(allo[k, :cnts[k]][f].view(np.uint32), wl[f].view(np.uint32)):
+                        fails.append(f"knn2 pair {k}: list field {f} differs")
+                fails += diff_points(f"knn2 pair {k}", allk[2 * k, :len(a)], a, MFIELDS)
+                nmatch += len(wl)
+        # ---- the same batch again on rolled images: same buffers and arguments (a replayed graph where the path captures one)
+        if c["again"] and B >= 2 and not fails:
+            stack.copy_(torch.roll(stack, 1, 0))
+            torch.cuda.synchronize()
+            ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
+            ah.check(ah.lib.hak_sync(det.ctx))
+            nums2 = d_num.cpu().numpy()
+            allp2 = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+            for i in range(B):
+                fails += diff_points(f"second batch call, image {i}", allp2[i, :min(nums2[i], mp)], want[((i - 1) % B) % nd], fields)
+            stack.copy_(torch.roll(stack, -1, 0))
+            torch.cuda.synchronize()
+        # ---- both images + the match as ONE launch sequence (detectAndComputePair), image 2 with a clamp of its own
+        if c["pair"] and B >= 2 and c["desc"]:
+            frac, pinned = c["pair"]
+            cap2 = max(1, int(mp * frac))
+            r1, r2 = ah.AkazeData(), ah.AkazeData()
+            ah.initAkazeData(r1, mp, True, True, pinned=pinned)
+            ah.initAkazeData(r2, cap2, True, True, pinned=pinned)
+            det.detectAndComputePair(stack[0].data_ptr(), stack[1 % B].data_ptr(), r1, r2, (w, h, p), True, True)
+            a = want[0].copy()
+            b = want[1 % nd] if cap2 >= len(want[1 % nd]) else okz.detect_and_compute(synth.to_float(u8s[1 % nd], p), w, okz.default_params(**okw), max_pts=cap2).points
+            okz.match(a, b)
+            fails += diff_points("pair call image 1", r1.h_data[:r1.num_pts], a, FIELDS + MFIELDS)
+            fails += diff_points("pair call image 2", r2.h_data[:r2.num_pts], b, FIELDS)
+            npts += len(a) + len(b)
+            ah.freeAkazeData(r1)
+            ah.freeAkazeData(r2)
         # ---- the single-image entry point (akaze.cpp:101-150) on image 0: other launch shapes than the batch
         data = ah.AkazeData()
         ah.initAkazeData(data, mp, True, True)
