@@ -13,6 +13,8 @@ What a case draws (reference: main.cpp:156-166 for the parameter set, akaze.cpp:
   params    octaves 1-5, sublevels 2-5, per, dthreshold, soffset, derivative factor, all four diffusivities, pattern size, upright,
             max_pts small enough to clamp in a quarter of the cases
   content   drawn scenes (tests/golden/make_golden.case_scene), optionally with uniform noise on top
+  layout    the caller's images at pitch iAlignUp(w, 128) (main.cpp:174), dense, or at an odd pitch; 0 / 1 / 3 elements into their buffer;
+            NaN (0xFF) everywhere outside the images
   legs      float batch -> 1-NN pair matching [-> 2-NN + ratio + cross-check] [-> the batch again on rolled images] [-> the pair call with a
             clamp of its own for image 2, pinned or pageable host arrays] -> the single-image call [-> FAST batch -> FAST single call]
 """
@@ -90,13 +92,17 @@ def draw_more(c, rng, pick):
     c["knn2"] = (pick(((1, 1), (4, 5), (3, 4))), bool(rng.random() < 0.5)) if rng.random() < 0.5 else None
     c["pair"] = (pick((1.0, 1.0, 0.5, 0.1)), bool(rng.random() < 0.5)) if rng.random() < 0.5 else None
     c["again"] = bool(rng.random() < 0.4)
+    # the caller's image layout: pitch = iAlignUp(w, 128) as main.cpp:174 has it, a dense image (pitch = w), or an odd pitch; the first
+    # image 0, 1 or 3 elements into its allocation (no 16-byte alignment of rows or base); margins hold NaN / 0xFF
+    c["pitch_mode"] = pick((0, 0, 0, 1, 2, 3))
+    c["in_offset"] = pick((0, 0, 0, 1, 3))
     return c
 
 
 def describe(c):
     kw = ",".join(f"{k}={v}" for k, v in c["kw"].items())
     return (f"#{c['index']:<4d} {c['w']:4d}x{c['h']:<4d} B={c['B']:<2d} {c['mode']:<10s} max_pts={c['max_pts']:<5d} noise={c['noise']:<2d} "
-            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}"
+            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} "
             f"{'pair(%.1f%s) ' % (c['pair'][0], ',pinned' if c['pair'][1] else '') if c['pair'] else ''}{kw}")
 
 
@@ -139,8 +145,20 @@ def run_case(ah, okz, torch, synth, mg, c):
         d_num = torch.zeros(B, dtype=torch.int32, device="cuda")
         # ---- float path: batch entry point, then pair matching on the device records
         want = [okz.detect_and_compute(synth.to_float(u, p), w, okz.default_params(**okw), max_pts=mp, desc=c["desc"]).points for u in u8s]
-        stack = torch.from_numpy(np.stack([synth.to_float(u8s[i % nd], p) for i in range(B)])).cuda()
-        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
+        pin = {0: p, 1: w, 2: w + 1, 3: w + 3}[c["pitch_mode"]]
+        off = c["in_offset"]
+
+        def upload(order, as_u8):
+            """the B images in `order` at pitch pin, the first one `off` elements into the buffer; everything outside the images is NaN / 0xFF"""
+            hb = np.full(off + B * h * pin + 4, 0xFF if as_u8 else np.nan, np.uint8 if as_u8 else np.float32)
+            for k, i in enumerate(order):
+                v = hb[off + k * h * pin: off + (k + 1) * h * pin].reshape(h, pin)
+                v[:, :w] = u8s[i % nd] if as_u8 else synth.to_float(u8s[i % nd], p)[:, :w]
+            return torch.from_numpy(hb).cuda()
+
+        stack = upload(range(B), False)
+        img_ptr = lambda k: stack.data_ptr() + 4 * (off + k * h * pin)
+        ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, img_ptr(0), h * pin, pin, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
         ah.check(ah.lib.hak_sync(det.ctx))
         nums = d_num.cpu().numpy()
         allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
@@ -193,15 +211,15 @@ def run_case(ah, okz, torch, synth, mg, c):
                 nmatch += len(wl)
         # ---- the same batch again on rolled images: same buffers and arguments (a replayed graph where the path captures one)
         if c["again"] and B >= 2 and not fails:
-            stack.copy_(torch.roll(stack, 1, 0))
+            stack.copy_(upload([(i - 1) % B for i in range(B)], False))
             torch.cuda.synchronize()
-            ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, stack.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
+            ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, img_ptr(0), h * pin, pin, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
             ah.check(ah.lib.hak_sync(det.ctx))
             nums2 = d_num.cpu().numpy()
             allp2 = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
             for i in range(B):
                 fails += diff_points(f"second batch call, image {i}", allp2[i, :min(nums2[i], mp)], want[((i - 1) % B) % nd], fields)
-            stack.copy_(torch.roll(stack, -1, 0))
+            stack.copy_(upload(range(B), False))
             torch.cuda.synchronize()
         # ---- both images + the match as ONE launch sequence (detectAndComputePair), image 2 with a clamp of its own
         if c["pair"] and B >= 2 and c["desc"]:
@@ -210,7 +228,7 @@ def run_case(ah, okz, torch, synth, mg, c):
             r1, r2 = ah.AkazeData(), ah.AkazeData()
             ah.initAkazeData(r1, mp, True, True, pinned=pinned)
             ah.initAkazeData(r2, cap2, True, True, pinned=pinned)
-            det.detectAndComputePair(stack[0].data_ptr(), stack[1 % B].data_ptr(), r1, r2, (w, h, p), True, True)
+            det.detectAndComputePair(img_ptr(0), img_ptr(1 % B), r1, r2, (w, h, pin), True, True)
             a = want[0].copy()
             b = want[1 % nd] if cap2 >= len(want[1 % nd]) else okz.detect_and_compute(synth.to_float(u8s[1 % nd], p), w, okz.default_params(**okw), max_pts=cap2).points
             okz.match(a, b)
@@ -222,24 +240,21 @@ def run_case(ah, okz, torch, synth, mg, c):
         # ---- the single-image entry point (akaze.cpp:101-150) on image 0: other launch shapes than the batch
         data = ah.AkazeData()
         ah.initAkazeData(data, mp, True, True)
-        det.detectAndCompute(stack.data_ptr(), data, (w, h, p), c["desc"])
+        det.detectAndCompute(img_ptr(0), data, (w, h, pin), c["desc"])
         fails += diff_points("float single call", data.h_data[:data.num_pts], want[0], fields)
         del stack
         # ---- integer FAST path (akaze.cpp:153-201): batch + single
         if c["fast"]:
             fwant = [okz.fast_detect_and_compute(u, okz.default_params(**okw), max_pts=mp, desc=c["desc"]).points for u in u8s]
-            pad = np.zeros((B, h, p), np.uint8)
-            for i in range(B):
-                pad[i, :, :w] = u8s[i % nd]
-            d8 = torch.from_numpy(pad).cuda()
-            ah.check(ah.lib.hak_fast_detect_and_compute_batch(det.ctx, d8.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
+            d8 = upload(range(B), True)
+            ah.check(ah.lib.hak_fast_detect_and_compute_batch(det.ctx, d8.data_ptr() + off, h * pin, pin, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
             ah.check(ah.lib.hak_sync(det.ctx))
             nums = d_num.cpu().numpy()
             allp = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
             for i in range(B):
                 fails += diff_points(f"FAST batch image {i}", allp[i, :min(nums[i], mp)], fwant[i % nd], fields)
                 npts += len(fwant[i % nd])
-            det.fastDetectAndCompute(d8.data_ptr(), data, (w, h, p), c["desc"])
+            det.fastDetectAndCompute(d8.data_ptr() + off, data, (w, h, pin), c["desc"])
             fails += diff_points("FAST single call", data.h_data[:data.num_pts], fwant[0], fields)
         ah.freeAkazeData(data)
     finally:
