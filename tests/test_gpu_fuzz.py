@@ -6,6 +6,7 @@ import os
 
 import pytest
 
+import fuzz_match
 import fuzz_parity
 
 pytestmark = pytest.mark.gpu
@@ -36,3 +37,11 @@ def test_cases_the_long_runs_found(seed, index, big):
     assert c["fast"] and c["kw"]["diffusivity"] in (0, 3)
     fails, npts, _ = fuzz_parity.run_case(ah, okz, torch, synth, fuzz_parity._mg(), c)
     assert not fails and npts > 1000, fails
+
+
+def test_match_fuzz_slice_vs_oracle():
+    """tests/fuzz_match.py: random set sizes and descriptor populations (planted copies, exact duplicates, all-zero / all-one rows)
+    through hak_match and hak_match_knn2, matrix-core (both wave shapes) and VALU kernels, with and without a context"""
+    buf = io.StringIO()
+    failed = fuzz_match.run(int(os.environ.get("HAK_FUZZ_MATCH_CASES", "12")), int(os.environ.get("HAK_FUZZ_SEED", "5")), verbose=False, out=buf)
+    assert not failed, buf.getvalue()
