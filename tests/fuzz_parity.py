@@ -55,13 +55,21 @@ def draw_case(seed, index, big=False):
         # the bench's regime: 720p .. 4K frames, up to 65 images per launch sequence (full-height row segments, every streaming kernel)
         w, h = int(rng.integers(1000, 4201)), int(rng.integers(600, 2401))
         B = pick((1, 2, 4, 9, 33, 65))
+        if big == 2:
+            # beyond 4K: planes of 10-60 Mpx (the streaming kernels' 32-bit buffer offsets end at 2 GiB per plane group: their launchers
+            # must hand such planes to the tile kernels), 5-7 octaves
+            w, h = int(rng.integers(4200, 9001)), int(rng.integers(2400, 7001))
+            B = pick((1, 1, 2))
+            huge_pts = pick((150000, 300000))          # (no clamp: every keypoint of the frame is compared; such sets skip the matching legs)
         while w * h * B > 160e6:
             B = max(1, B // 2)
-        kw = dict(noctaves=pick((3, 4, 4, 5)), max_scale=pick((3, 4, 4)), per=pick((0.5, 0.7, 0.7, 0.9)), dthreshold=pick((0.0005, 0.001, 0.001)),
+        kw = dict(noctaves=pick((3, 4, 4, 5)) + (2 if big == 2 else 0), max_scale=pick((3, 4, 4)), per=pick((0.5, 0.7, 0.7, 0.9)), dthreshold=pick((0.0005, 0.001, 0.001)),
                   soffset=pick((1.2, 1.6, 1.6, 2.0)), derivative_factor=pick((1.0, 1.5, 1.5, 2.0)), diffusivity=pick((1, 1, 1, 0, 2, 3)),
                   descriptor_pattern_size=pick((10, 10, 8, 12)), upright=bool(rng.random() < 0.2))
         c = dict(index=index, w=w, h=h, B=B, kw=kw, mode=pick(("size rule", "size rule", "streaming")), max_pts=pick((2000, 10000, 10000)),
                  noise=pick((0, 0, 6)), scene_seed=int(rng.integers(1 << 20)), fast=bool(rng.random() < 0.5), desc=True)
+        if big == 2:
+            c["max_pts"] = huge_pts
         return draw_more(c, rng, pick)
     if rng.random() < 0.33:
         # strip edges of the streaming kernels (240 / 232 / 248 stored columns per wave), 16-byte rows, lattice-blind extents
@@ -96,13 +104,15 @@ def draw_more(c, rng, pick):
     # image 0, 1 or 3 elements into its allocation (no 16-byte alignment of rows or base); margins hold NaN / 0xFF
     c["pitch_mode"] = pick((0, 0, 0, 1, 2, 3))
     c["in_offset"] = pick((0, 0, 0, 1, 3))
+    # a last call through the same Akazer with OTHER extents (akaze.cpp:109: the arena is rebuilt when the size differs from init)
+    c["resize"] = (int(rng.integers(1, 40)), int(rng.integers(1, 40))) if rng.random() < 0.2 else None
     return c
 
 
 def describe(c):
     kw = ",".join(f"{k}={v}" for k, v in c["kw"].items())
     return (f"#{c['index']:<4d} {c['w']:4d}x{c['h']:<4d} B={c['B']:<2d} {c['mode']:<10s} max_pts={c['max_pts']:<5d} noise={c['noise']:<2d} "
-            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} "
+            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} {'resize ' if c['resize'] else ''}"
             f"{'pair(%.1f%s) ' % (c['pair'][0], ',pinned' if c['pair'][1] else '') if c['pair'] else ''}{kw}")
 
 
@@ -130,7 +140,13 @@ def run_case(ah, okz, torch, synth, mg, c):
     rng = np.random.default_rng(c["scene_seed"])
     u8s = []
     for i in range(nd):
-        u = mg.case_scene(max(w, 134), h, (c["scene_seed"] + i) % 9973)[:, :w].astype(np.int32)     # (the scene generator's minimum width)
+        if w * h > 12e6:        # (huge frames: a 1600 x 1200 scene tiled with alternating mirror images -- the generator draws shape by shape in Python)
+            t = mg.case_scene(1600, 1200, (c["scene_seed"] + i) % 9973)
+            t = np.concatenate([t, t[:, ::-1]], axis=1)
+            t = np.concatenate([t, t[::-1]], axis=0)
+            u = np.tile(t, ((h + 2399) // 2400, (w + 3199) // 3200))[:h, :w].astype(np.int32)
+        else:
+            u = mg.case_scene(max(w, 134), h, (c["scene_seed"] + i) % 9973)[:, :w].astype(np.int32)     # (the scene generator's minimum width)
         if c["noise"]:
             u = u + rng.integers(-c["noise"], c["noise"] + 1, u.shape)
         u8s.append(np.clip(u, 0, 255).astype(np.uint8))
@@ -166,7 +182,8 @@ def run_case(ah, okz, torch, synth, mg, c):
         for i in range(B):
             fails += diff_points(f"float batch image {i}", allp[i, :min(nums[i], mp)], want[i % nd], fields)
             npts += len(want[i % nd])
-        if B >= 2 and c["desc"] and not fails:
+        small_sets = max(len(x) for x in want) <= 20000      # (the oracle's brute-force matcher is the limit)
+        if B >= 2 and c["desc"] and small_sets and not fails:
             ah.check(ah.lib.hak_match_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B // 2))
             ah.check(ah.lib.hak_sync(det.ctx))
             allm = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
@@ -189,7 +206,7 @@ def run_case(ah, okz, torch, synth, mg, c):
                           for k in range(B // 2))
                 fails.append(f"the same hak_match_batch launched a second time: {'equal to the oracle' if ok2 else 'still different'}; counts {nums.tolist()}")
         # ---- 2-NN + ratio + cross-check on the same device records
-        if B >= 2 and c["desc"] and c["knn2"] and not fails:
+        if B >= 2 and c["desc"] and c["knn2"] and small_sets and not fails:
             ratio, cross = c["knn2"]
             out = torch.zeros((B // 2) * mp * 32, dtype=torch.uint8, device="cuda")
             cnt = torch.zeros(B // 2, dtype=torch.int32, device="cuda")
@@ -222,7 +239,7 @@ def run_case(ah, okz, torch, synth, mg, c):
             stack.copy_(upload(range(B), False))
             torch.cuda.synchronize()
         # ---- both images + the match as ONE launch sequence (detectAndComputePair), image 2 with a clamp of its own
-        if c["pair"] and B >= 2 and c["desc"]:
+        if c["pair"] and B >= 2 and c["desc"] and small_sets:
             frac, pinned = c["pair"]
             cap2 = max(1, int(mp * frac))
             r1, r2 = ah.AkazeData(), ah.AkazeData()
@@ -256,6 +273,16 @@ def run_case(ah, okz, torch, synth, mg, c):
                 npts += len(fwant[i % nd])
             det.fastDetectAndCompute(d8.data_ptr() + off, data, (w, h, pin), c["desc"])
             fails += diff_points("FAST single call", data.h_data[:data.num_pts], fwant[0], fields)
+        if c["resize"] and w - c["resize"][0] >= 134 and h - c["resize"][1] >= 80:
+            w2, h2 = w - c["resize"][0], h - c["resize"][1]
+            p2 = ah.iAlignUp(w2, 128)
+            crop = np.ascontiguousarray(synth.to_float(u8s[0], p)[:h2, :p2]) if p2 <= p else None
+            if crop is not None:
+                crop[:, w2:] = 0
+                det.detectAndCompute(torch.from_numpy(crop).cuda().data_ptr(), data, (w2, h2, p2), c["desc"])
+                wr = okz.detect_and_compute(crop, w2, okz.default_params(**okw), max_pts=mp, desc=c["desc"]).points
+                fails += diff_points(f"call with other extents ({w2} x {h2})", data.h_data[:data.num_pts], wr, fields)
+                npts += len(wr)
         ah.freeAkazeData(data)
     finally:
         det.close()
@@ -292,7 +319,7 @@ def run(cases, seed, only=None, verbose=True, out=sys.stdout, big=False):
             print("       " + f, file=out, flush=True)
         if fails:
             failed.append(i)
-    print(f"== seed {seed}{' (big)' if big else ''}: {len(list(idx))} cases, {len(failed)} failed {failed}; {tp} keypoint records and {tm} accepted matches compared "
+    print(f"== seed {seed}{(' (big)', ' (huge)')[big - 1] if big else ''}: {len(list(idx))} cases, {len(failed)} failed {failed}; {tp} keypoint records and {tm} accepted matches compared "
           f"bit for bit with the oracle in {time.time() - t0:.0f} s", file=out, flush=True)
     return failed
 
@@ -304,5 +331,6 @@ if __name__ == "__main__":
     ap.add_argument("--only", type=int, default=None)
     ap.add_argument("--quiet", action="store_true")
     ap.add_argument("--big", action="store_true", help="720p .. 4K frames, up to 65 images per launch sequence")
+    ap.add_argument("--huge", action="store_true", help="4K .. 9000 x 7000 frames, one or two per launch sequence")
     a = ap.parse_args()
-    sys.exit(1 if run(a.cases, a.seed, a.only, not a.quiet, big=a.big) else 0)
+    sys.exit(1 if run(a.cases, a.seed, a.only, not a.quiet, big=2 if a.huge else int(a.big)) else 0)
