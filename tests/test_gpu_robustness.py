@@ -515,3 +515,64 @@ def test_constant_image_vs_oracle_both_paths(ah, okz, torch, synth):
     assert_points_equal(data.h_data[:data.num_pts], want)
     ah.freeAkazeData(data)
     det.close()
+
+
+def test_four_host_threads_four_contexts(ah, torch, synth):
+    """contexts are independent (the reference's detector is a process-wide singleton: global device symbols, a function-static
+    Gaussian cache): four host threads drive four contexts of different extents at once -- batch detect (graph capture
+    and replay per thread), batched match, the pool-backed hak_match without a context -- and every round must equal what the same
+    context delivered alone"""
+    import threading
+    shapes = [(400, 300, 4), (512, 384, 3), (333, 251, 2), (640, 360, 4)]
+    mp = 2500
+    jobs = []
+    for t, (w, h, B) in enumerate(shapes):
+        p = ah.iAlignUp(w, 128)
+        stack = torch.from_numpy(np.stack([synth.to_float(_mg().case_scene(w, h, 700 + 10 * t + i), p) for i in range(B)])).cuda()
+        det = ah.Akazer()
+        det.init((w, h, p), max_pts=mp, batch=B)
+        pts = torch.zeros(B * mp * 104, dtype=torch.uint8, device="cuda")
+        num = torch.zeros(B, dtype=torch.int32, device="cuda")
+        jobs.append(dict(w=w, h=h, p=p, B=B, stack=stack, det=det, pts=pts, num=num))
+    torch.cuda.synchronize()
+
+    def one_round(j):
+        ah.check(ah.lib.hak_detect_and_compute_batch(j["det"].ctx, j["stack"].data_ptr(), j["h"] * j["p"], j["p"], j["B"], j["pts"].data_ptr(), j["num"].data_ptr(), 1))
+        ah.check(ah.lib.hak_match_batch(j["det"].ctx, j["pts"].data_ptr(), j["num"].data_ptr(), j["B"] // 2))
+        ah.check(ah.lib.hak_sync(j["det"].ctx))
+        n = j["num"].cpu().numpy().copy()
+        # cuMatch without a context (scratch from the per-device pool): image 0 against image 1, on the caller's copies
+        a = j["pts"][:mp * 104].clone()
+        ah.check(ah.lib.hak_match(None, a.data_ptr(), int(n[0]), j["pts"][mp * 104:].data_ptr(), int(n[1]), None))
+        return n, j["pts"].cpu().numpy().copy(), a.cpu().numpy().copy()
+
+    alone = [one_round(j) for j in jobs]
+    for n, _, _ in alone:
+        assert n.min() > 30
+    errors, results = [], [[] for _ in jobs]
+
+    def worker(k):
+        try:
+            for _ in range(12):
+                results[k].append(one_round(jobs[k]))
+        except Exception as e:                            # noqa: BLE001 -- reported below, in the test's thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k, rounds in enumerate(results):
+        assert len(rounds) == 12
+        for n, pts, a in rounds:
+            assert np.array_equal(n, alone[k][0]) and np.array_equal(pts, alone[k][1]) and np.array_equal(a, alone[k][2]), k
+    # the batched match of pair 0 and the context-free hak_match of the same pair agree (both are cuMatch, akaze.cpp:55-64)
+    for k, j in enumerate(jobs):
+        n0 = int(alone[k][0][0])
+        b = alone[k][1].view(ah.POINT_DTYPE).reshape(j["B"], mp)[0, :n0]
+        c = alone[k][2].view(ah.POINT_DTYPE)[:n0]
+        for f in ("match", "distance", "match_x", "match_y"):
+            assert np.array_equal(b[f], c[f]), (k, f)
+        j["det"].close()
