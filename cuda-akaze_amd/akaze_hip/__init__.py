@@ -80,6 +80,7 @@ SYMBOLS = {
     "hak_wait_event": (C.c_int, [_vp, _vp]),
     "hak_phase_event": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "hak_set_concurrency": (C.c_int, [_vp, C.c_int]),
+    "hak_set_null_order": (C.c_int, [_vp, C.c_int]),
     "hak_detect_and_compute": (C.c_int, [_vp, _vp, C.c_int, _vp, C.c_int, _ip, _vp, C.c_int]),
     "hak_detect_and_compute_pair": (C.c_int, [_vp, _vp, _vp, C.c_int, _vp, _vp, C.c_int, C.c_int, _ip, _ip, _vp, _vp, C.c_int, C.c_int]),
     "hak_detect_and_compute_batch": (C.c_int, [_vp, _vp, C.c_long, C.c_int, C.c_int, _vp, _vp, C.c_int]),

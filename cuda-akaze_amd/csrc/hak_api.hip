@@ -285,6 +285,8 @@ extern "C" int hak_create(const hak_config* cfg, int w, int h, hak_ctx** out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_last, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_fork, hipEventDisableTiming);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_phase, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_null, hipEventDisableTiming);
+    if (const char* s = getenv("HAK_NULL_ORDER")) c->null_order = atoi(s) != 0;
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_tail_join, hipEventDisableTiming);
     // ... and so must the survivor bitmap and the row counts (hak_launch_clear_maps restores all three)
     if (e == hipSuccess) e = hipMemset(c->bitmap, 0, sizeof(unsigned long long) * (size_t)L.oct[0].h * words * B);
@@ -328,6 +330,7 @@ extern "C" void hak_destroy(hak_ctx* c)
     if (c->ev_last) { (void)hipEventSynchronize(c->ev_last); (void)hipEventDestroy(c->ev_last); }
     if (c->ev_tail_fork) (void)hipEventDestroy(c->ev_tail_fork);
     if (c->ev_phase) (void)hipEventDestroy(c->ev_phase);
+    if (c->ev_null) (void)hipEventDestroy(c->ev_null);
     if (c->ev_tail_join) (void)hipEventDestroy(c->ev_tail_join);
     if (c->own_stream) (void)hipStreamSynchronize(c->own_stream);
     for (auto& g : c->graph_exec) if (g) (void)hipGraphExecDestroy(g);
@@ -364,6 +367,29 @@ extern "C" int hak_set_concurrency(hak_ctx* c, int on)
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->concurrent = on != 0;
     return 0;
+}
+
+extern "C" int hak_set_null_order(hak_ctx* c, int on)
+{
+    if (!c) return fail("null context");
+    c->null_order = on != 0;
+    return 0;
+}
+
+// The reference issues everything on stream 0 (akaze.cpp:101-150, 55-64): whatever its caller enqueued on the default stream before a call
+// -- a hipMemset of an output array, an asynchronous upload, a kernel of its own -- is finished when the call's first kernel starts.  A
+// context's streams are non-blocking; this makes the call's stream wait for the NULL stream's work enqueued so far (device-side: an event
+// record there, a wait here; nothing when the context runs on the NULL stream itself).  Never inside a stream capture: every caller sits
+// in front of run_detect_inner's capture.
+static void order_after_null_stream(hak_ctx* c, hipStream_t st)
+{
+    if (!c || !c->null_order || !c->ev_null || st == nullptr) return;
+    // (an idle NULL stream -- the reference's own call pattern with its blocking copies -- costs one query; the cross-queue dependency
+    // itself was measured at ~15 us per call: 0.54 -> 0.55 ms for the pair call when taken unconditionally)
+    const hipError_t q = hipStreamQuery(nullptr);
+    if (q == hipSuccess) return;
+    (void)hipGetLastError();
+    if (hipEventRecord(c->ev_null, nullptr) != hipSuccess || hipStreamWaitEvent(st, c->ev_null, 0) != hipSuccess) (void)hipGetLastError();
 }
 
 extern "C" int hak_phase_event(hak_ctx* c, void** ev)
@@ -825,6 +851,7 @@ extern "C" int hak_fast_detect_and_compute_batch(hak_ctx* c, const unsigned char
     if (!c || !d_images || !d_points || !d_num_pts) return fail("null argument");
     if (nimg < 1 || nimg > c->cfg.batch) return fail("nimg exceeds the context's batch capacity");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    order_after_null_stream(c, c->stream);
     maps_guard_begin(c);
     return maps_guard_end(c, enqueue_fast_detect(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, c->cfg.max_pts));
 }
@@ -835,6 +862,7 @@ extern "C" int hak_fast_detect_and_compute(hak_ctx* c, const unsigned char* d_im
     if (!c || !d_image || !d_points || !num_pts) return fail("null argument");
     if (max_pts < 1) return fail("max_pts < 1");
     if (pitch < c->L.oct[0].w) return fail("pitch smaller than width");
+    order_after_null_stream(c, c->stream);
     maps_guard_begin(c);
     if (maps_guard_end(c, enqueue_fast_detect(c, d_image, 0, pitch, 1, d_points, c->d_num, desc, max_pts))) return 1;
     HIP_TRY(hipMemcpyAsync(c->h_num, c->d_num, sizeof(int), hipMemcpyDeviceToHost, c->stream));
@@ -853,6 +881,7 @@ static int run_detect_inner(hak_ctx* c, const float* d_images, long image_stride
 static int run_detect(hak_ctx* c, const float* d_images, long image_stride, int pitch, int nimg,
                       hak_point* d_points, int* d_num_pts, int desc, int max_pts, hak_point* h_pinned = nullptr, int cap0 = 0, int cap1 = 0)
 {
+    order_after_null_stream(c, c->stream);
     maps_guard_begin(c);
     return maps_guard_end(c, run_detect_inner(c, d_images, image_stride, pitch, nimg, d_points, d_num_pts, desc, max_pts, h_pinned, cap0, cap1));
 }
@@ -1028,6 +1057,7 @@ extern "C" int hak_match(hak_ctx* c, hak_point* d_pts1, int n1, const hak_point*
     // one, comes from the per-device pool above for the duration of the call -- no process-wide buffer
     hipStream_t st = c ? c->stream : nullptr;
     HakMatchScratch* sc = c ? &c->msc : pool_acquire();
+    order_after_null_stream(c, st);
     {
         ProfScope ps(c, HAK_PROF_MATCH);
         hak_launch_match(st, d_pts1, d_pts2, nullptr, nullptr, n1, n2, 0, 0, 1, sc);
@@ -1049,6 +1079,7 @@ extern "C" int hak_match_batch(hak_ctx* c, hak_point* d_points, const int* d_num
     if (!c || !d_points || !d_num_pts || npairs < 1) return fail("bad argument");
     const long mp = c->cfg.max_pts;
     if (mp >= (1 << 20)) return fail("max_pts must stay below 2^20 for the matcher");   // k_match packs distance << 20 | index
+    order_after_null_stream(c, c->stream);
     { ProfScope ps(c, HAK_PROF_MATCH);
       hak_launch_match(c->stream, d_points, d_points + mp, d_num_pts, d_num_pts + 1, (int)mp, (int)mp, 2 * mp, 2 * mp, npairs, &c->msc); }
     if (hipGetLastError() != hipSuccess) return fail("match launch failed");
@@ -1077,6 +1108,7 @@ extern "C" int hak_match_knn2(hak_ctx* c, hak_point* d_pts1, int n1, const hak_p
     if (max_dist <= 0) max_dist = HAK_MAX_DIST;
     hipStream_t st = c ? c->stream : nullptr;
     HakMatchScratch* sc = c ? &c->msc : pool_acquire();
+    order_after_null_stream(c, st);
     const int nb = (n1 + 1023) / 1024;
     if (!hak_match_scratch_reserve(sc, st, 0, 0, 0, (long)n1 + (long)(n2 > 0 ? n2 : 1), nb)) {
         if (!c) pool_release(sc, false);
@@ -1116,6 +1148,7 @@ extern "C" int hak_match_knn2_batch(hak_ctx* c, hak_point* d_points, const int* 
     if (ratio_num <= 0 || ratio_den <= 0) return fail("ratio must be a positive fraction");
     if (max_dist <= 0) max_dist = HAK_MAX_DIST;
     if (knn_scratch(c)) return 1;
+    order_after_null_stream(c, c->stream);
     const long mp = c->cfg.max_pts;
     int4* fwd = c->knn;
     int4* rev = c->knn + (size_t)((c->cfg.batch + 1) / 2) * mp;
@@ -1158,6 +1191,7 @@ extern "C" int hak_ingest_u8(hak_ctx* c, const unsigned char* d_src, long src_st
 {
     if (!d_src || !d_dst || w < 1 || h < 1 || nimg < 1 || src_pitch < w || dst_pitch < w) return fail("bad ingest argument");
     if (hak_device_count() == 0) return fail("no HIP device: libhipakaze has no CPU fallback");
+    order_after_null_stream(c, c ? c->stream : nullptr);
     hak_launch_ingest_u8(c ? c->stream : nullptr, d_src, src_stride, src_pitch, d_dst, dst_stride, dst_pitch, w, h, nimg);
     if (hipGetLastError() != hipSuccess) return fail("ingest launch failed");
     return 0;

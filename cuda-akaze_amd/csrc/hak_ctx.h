@@ -85,6 +85,8 @@ struct hak_ctx {
     HakKnobs knobs;                 // kernel-selection knobs of THIS context (two contexts of a process may differ)
     hipEvent_t ev_last = nullptr;   // recorded after the last enqueue on c->stream: hak_destroy waits for it (external streams)
     hipEvent_t ev_tail_fork = nullptr, ev_tail_join = nullptr;   // the map clean-up runs beside the descriptor kernels
+    hipEvent_t ev_null = nullptr;   // recorded on the NULL stream at the start of a call: the context's stream waits for it (hak_set_null_order)
+    bool null_order = true;
     hipEvent_t ev_phase = nullptr;  // recorded in every detect sequence between the scale space and the keypoint stages (hak_phase_event)
     hipStream_t sync_stream = nullptr;                            // where the last detect sequence ends (c->stream unless it was left on the chain)
     bool last_fast = false;         // the arena holds the integer path's planes (hak_debug_plane)

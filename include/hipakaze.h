@@ -98,6 +98,13 @@ int hak_phase_event(hak_ctx* ctx, void** hip_event);
 /* 1 (default): octaves run on their own HIP streams (octave o+1 depends only on Lt(o,0), akaze.cpp:371-375);
  * 0: one stream, strictly serial launches (used for per-kernel timing). Env HAK_SERIAL=1 presets 0. */
 int hak_set_concurrency(hak_ctx* ctx, int on);
+/* 1 (default): every call that enqueues work on the context first makes the context's stream wait for what the caller has enqueued on
+ * the NULL stream so far (an event recorded there; no host wait).  The reference runs on the default stream, so its callers' own
+ * hipMemset / hipMemcpyAsync / kernels on that stream are ordered in front of detectAndCompute and cuMatch by themselves
+ * (akaze.cpp:101-150 issues everything on stream 0); a context's streams are non-blocking and would not wait (hipMemset returns
+ * before its fill has run: tools/probes/memset_order_probe.hip).  0: no such dependency (a caller that drives the context from its
+ * own stream, hak_set_stream, or captures graphs while calling).  Env HAK_NULL_ORDER=0 presets 0. */
+int hak_set_null_order(hak_ctx* ctx, int on);
 
 /* ---- Akazer::detectAndCompute (akaze.h:29, akaze.cpp:101-150), one image,
  * synchronous.  d_image: device float32, pitch elements per row.  d_points:

@@ -53,6 +53,10 @@ static inline int fborder_add(int a, int b, int m) { int c = a + b; return c < m
 static inline int fiabs(int a) { return a < 0 ? -a : a; }
 static inline int wmul(int a, int b) { return (int)((unsigned)a * (unsigned)b); }   /* F1 */
 static inline int wadd(int a, int b) { return (int)((unsigned)a + (unsigned)b); }
+static inline int wsub(int a, int b) { return (int)((unsigned)a - (unsigned)b); }
+static inline int wneg(int a) { return (int)(0u - (unsigned)a); }
+/* (every +, - and * on plane values goes through these: the device wraps, C leaves signed overflow undefined -- and the planes do
+ * leave the int range once a long FED cycle has blown a coarse level up; `make asan` runs such a case under UBSan) */
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 /* float -> int as the device does it (cvt.rzi.s32.f32 / v_cvt_i32_f32: toward zero, SATURATING, NaN -> 0).  A C cast of a NaN or of
  * a value outside the int range is undefined and x86 delivers INT_MIN for all of them.  It matters where the integer pipeline has
@@ -102,7 +106,7 @@ static void conv_rows_cols(const int* in, int* dst, int w, int h, int p, const i
         for (int x = 0; x < w; x++) {
             const int* s = in + (size_t)y * p;
             int ws = wmul(k[0], s[x]);
-            for (int i = 1; i <= R; i++) ws = wadd(ws, wmul(k[i], s[fiabs(x - i)] + s[fborder_add(x, i, w)]));
+            for (int i = 1; i <= R; i++) ws = wadd(ws, wmul(k[i], wadd(s[fiabs(x - i)], s[fborder_add(x, i, w)])));
             rows[(size_t)y * w + x] = ws >> 16;
         }
 #pragma omp parallel for schedule(static)
@@ -110,7 +114,7 @@ static void conv_rows_cols(const int* in, int* dst, int w, int h, int p, const i
         for (int x = 0; x < w; x++) {
             int ws = wmul(k[0], rows[(size_t)y * w + x]);
             for (int i = 1; i <= R; i++)
-                ws = wadd(ws, wmul(k[i], rows[(size_t)fiabs(y - i) * w + x] + rows[(size_t)fborder_add(y, i, h) * w + x]));
+                ws = wadd(ws, wmul(k[i], wadd(rows[(size_t)fiabs(y - i) * w + x], rows[(size_t)fborder_add(y, i, h) * w + x])));
             dst[(size_t)y * p + x] = ws >> 16;
         }
     free(rows);
@@ -139,7 +143,7 @@ void fkz_down_smooth(const int* src, int* dst, int* smooth, int sw, int sh, int 
             const int* s = src + (size_t)sy * sp;
             int six = dx + dx;
             int x0 = fiabs(six - 4), x1 = fiabs(six - 2), x3 = fborder_add(six, 2, sw), x4 = fborder_add(six, 4, sw);
-            rows[(size_t)sy * dw + dx] = wadd(wadd(wmul(k[0], s[six]), wmul(k[1], s[x1] + s[x3])), wmul(k[2], s[x0] + s[x4])) >> 16;
+            rows[(size_t)sy * dw + dx] = wadd(wadd(wmul(k[0], s[six]), wmul(k[1], wadd(s[x1], s[x3]))), wmul(k[2], wadd(s[x0], s[x4]))) >> 16;
         }
     for (int dy = 0; dy < dh; dy++) {
         int siy = dy + dy;
@@ -148,8 +152,8 @@ void fkz_down_smooth(const int* src, int* dst, int* smooth, int sw, int sh, int 
             dst[(size_t)dy * dp + dx] = src[(size_t)siy * sp + dx + dx];
             smooth[(size_t)dy * dp + dx] =
                 wadd(wadd(wmul(k[0], rows[(size_t)siy * dw + dx]),
-                          wmul(k[1], rows[(size_t)y1 * dw + dx] + rows[(size_t)y3 * dw + dx])),
-                     wmul(k[2], rows[(size_t)y0 * dw + dx] + rows[(size_t)y4 * dw + dx])) >> 16;
+                          wmul(k[1], wadd(rows[(size_t)y1 * dw + dx], rows[(size_t)y3 * dw + dx]))),
+                     wmul(k[2], wadd(rows[(size_t)y0 * dw + dx], rows[(size_t)y4 * dw + dx]))) >> 16;
         }
     }
     free(rows);
@@ -161,8 +165,8 @@ static inline void fscharr(const int* src, int x, int y, int w, int h, int p, in
     const int* r0 = src + (size_t)y0 * p;
     const int* r1 = src + (size_t)y * p;
     const int* r2 = src + (size_t)y2 * p;
-    *dx = 10 * (r1[x2] - r1[x0]) + 3 * (r0[x2] + r2[x2] - r0[x0] - r2[x0]);
-    *dy = 10 * (r2[x] - r0[x]) + 3 * (r2[x0] + r2[x2] - r0[x0] - r0[x2]);
+    *dx = wadd(wmul(10, wsub(r1[x2], r1[x0])), wmul(3, wsub(wsub(wadd(r0[x2], r2[x2]), r0[x0]), r2[x0])));
+    *dy = wadd(wmul(10, wsub(r2[x], r0[x])), wmul(3, wsub(wsub(wadd(r2[x0], r2[x2]), r0[x0]), r0[x2])));
 }
 
 /* akazed.cu:3208-3232 gScharrContrastNaive + 4098-4165 hScharrContrast + 3245-3296 gFindMaxContrastU4 + 3299-3336
@@ -242,8 +246,8 @@ void fkz_nld_step(const int* src, const int* flow, int* dst, float tau, int w, i
         const int *f0 = flow + (size_t)y0 * p, *f1 = flow + (size_t)y * p, *f2 = flow + (size_t)y2 * p;
         for (int x = 0; x < w; x++) {
             int x0 = fiabs(x - 1), x2 = fborder_add(x, 1, w);
-            int step = wadd(wadd(wadd(wmul(f1[x] + f1[x2], s1[x2] - s1[x]), wmul(f1[x] + f1[x0], s1[x0] - s1[x])),
-                                 wmul(f1[x] + f2[x], s2[x] - s1[x])), wmul(f1[x] + f0[x], s0[x] - s1[x])) >> 16;
+            int step = wadd(wadd(wadd(wmul(wadd(f1[x], f1[x2]), wsub(s1[x2], s1[x])), wmul(wadd(f1[x], f1[x0]), wsub(s1[x0], s1[x]))),
+                                 wmul(wadd(f1[x], f2[x]), wsub(s2[x], s1[x]))), wmul(wadd(f1[x], f0[x]), wsub(s0[x], s1[x]))) >> 16;
             dst[(size_t)y * p + x] = wadd(wmul(stepfac, step) >> 16, s1[x]);
         }
     }
@@ -271,8 +275,8 @@ void fkz_hessian(const int* src, int* dxo, int* dyo, int* det, int step, int w, 
         for (int x = 0; x < w; x++) {
             int x0 = fiabs(x - step), x2 = fborder_add(x, step, w);
             int ul = r0[x0], uc = r0[x], ur = r0[x2], cl = r1[x0], cr = r1[x2], ll = r2[x0], lc = r2[x], lr = r2[x2];
-            dxo[(size_t)y * p + x] = wadd(wmul(fac1, ur + lr - ul - ll), wmul(fac2, cr - cl)) >> 16;
-            dyo[(size_t)y * p + x] = wadd(wmul(fac1, lr + ll - ur - ul), wmul(fac2, lc - uc)) >> 16;
+            dxo[(size_t)y * p + x] = wadd(wmul(fac1, wsub(wsub(wadd(ur, lr), ul), ll)), wmul(fac2, wsub(cr, cl))) >> 16;
+            dyo[(size_t)y * p + x] = wadd(wmul(fac1, wsub(wsub(wadd(lr, ll), ur), ul)), wmul(fac2, wsub(lc, uc))) >> 16;
         }
     }
 #pragma omp parallel for schedule(static)
@@ -281,10 +285,10 @@ void fkz_hessian(const int* src, int* dxo, int* dyo, int* det, int step, int w, 
         for (int x = 0; x < w; x++) {
             int x0 = fiabs(x - step), x2 = fborder_add(x, step, w);
             const int* dx = dxo; const int* dy = dyo;
-            int dxx = wadd(wmul(fac1, dx[o0 + x2] + dx[o2 + x2] - dx[o0 + x0] - dx[o2 + x0]), wmul(fac2, dx[o1 + x2] - dx[o1 + x0])) >> 16;
-            int dxy = wadd(wmul(fac1, dx[o2 + x2] + dx[o2 + x0] - dx[o0 + x2] - dx[o0 + x0]), wmul(fac2, dx[o2 + x] - dx[o0 + x])) >> 16;
-            int dyy = wadd(wmul(fac1, dy[o2 + x2] + dy[o2 + x0] - dy[o0 + x2] - dy[o0 + x0]), wmul(fac2, dy[o2 + x] - dy[o0 + x])) >> 16;
-            det[o1 + x] = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
+            int dxx = wadd(wmul(fac1, wsub(wsub(wadd(dx[o0 + x2], dx[o2 + x2]), dx[o0 + x0]), dx[o2 + x0])), wmul(fac2, wsub(dx[o1 + x2], dx[o1 + x0]))) >> 16;
+            int dxy = wadd(wmul(fac1, wsub(wsub(wadd(dx[o2 + x2], dx[o2 + x0]), dx[o0 + x2]), dx[o0 + x0])), wmul(fac2, wsub(dx[o2 + x], dx[o0 + x]))) >> 16;
+            int dyy = wadd(wmul(fac1, wsub(wsub(wadd(dy[o2 + x2], dy[o2 + x0]), dy[o0 + x2]), dy[o0 + x0])), wmul(fac2, wsub(dy[o2 + x], dy[o0 + x]))) >> 16;
+            det[o1 + x] = wsub(wmul(dxx, dyy), wmul(dxy, dxy));
         }
     }
 }
@@ -351,16 +355,16 @@ void fkz_refine(FkPoint* pt, const int* det, int o, int p)
 {
     int y = (int)pt->y >> o, x = (int)pt->x >> o;
     size_t idx = (size_t)y * p + x;
-    int v2 = det[idx] + det[idx];
-    int dx = (det[idx + 1] - det[idx - 1]) >> 1;
-    int dy = (det[idx + p] - det[idx - p]) >> 1;
-    int dxx = det[idx + 1] + det[idx - 1] - v2;
-    int dyy = det[idx + p] + det[idx - p] - v2;
-    int dxy = (det[idx + p + 1] + det[idx - p - 1] - det[idx - p + 1] - det[idx + p - 1]) >> 2;
-    int dd = wadd(wmul(dxx, dyy), -wmul(dxy, dxy));
+    int v2 = wadd(det[idx], det[idx]);
+    int dx = wsub(det[idx + 1], det[idx - 1]) >> 1;
+    int dy = wsub(det[idx + p], det[idx - p]) >> 1;
+    int dxx = wsub(wadd(det[idx + 1], det[idx - 1]), v2);
+    int dyy = wsub(wadd(det[idx + p], det[idx - p]), v2);
+    int dxy = wsub(wsub(wadd(det[idx + p + 1], det[idx - p - 1]), det[idx - p + 1]), det[idx + p - 1]) >> 2;
+    int dd = wsub(wmul(dxx, dyy), wmul(dxy, dxy));
     float idd = dd != 0 ? (1.f / dd) : 0.f;
-    float dst0 = idd * wadd(wmul(dxy, dy), -wmul(dyy, dx));
-    float dst1 = idd * wadd(wmul(dxy, dx), -wmul(dxx, dy));
+    float dst0 = idd * wsub(wmul(dxy, dy), wmul(dyy, dx));
+    float dst1 = idd * wsub(wmul(dxy, dx), wmul(dxx, dy));
     if (dst0 < -1.f || dst0 > 1.f || dst1 < -1.f || dst1 > 1.f) return;
     int ratio = 1 << o;
     pt->y = ratio * (y + dst1);
@@ -426,7 +430,7 @@ void fkz_describe(FkPoint* pt, const int* imd, const int* dxd, const int* dyd, i
         int yp = clampi((int)(yf + scale * (k * si + l * co) + 0.5f), 0, h - 1);
         size_t pos = (size_t)yp * p + xp;
         int im = imd[pos], dx = dxd[pos], dy = dyd[pos];
-        int rx = f2i_sat(-dx * si + dy * co);                           /* akazed.cu:3777 */
+        int rx = f2i_sat(wneg(dx) * si + dy * co);                           /* akazed.cu:3777 */
         int ry = f2i_sat(dx * co + dy * si);
         if (m < 2 * size2) { int c = 3 * ((y < size2 ? 0 : 2) + (x < size2 ? 0 : 1)); acc[c] = wadd(acc[c], im); acc[c + 1] = wadd(acc[c + 1], rx); acc[c + 2] = wadd(acc[c + 2], ry); }
         if (m < 3 * size3) {

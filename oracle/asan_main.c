@@ -90,6 +90,13 @@ int main(void)
     total += run_case(256, 256, &g, 10000, 1);
     Prm wk = d; wk.diffusivity = 2; wk.reordering = 0;
     total += run_case(288, 200, &wk, 10000, 1);
+    /* the integer pipeline far outside its range: two sublevels per octave make FED cycles of ~31 steps at octave 3 (tau up to 50), the
+     * 16-bit truncations blow the plane up, sums of squares wrap negative and the conductivity casts see NaN / inf (f2i_sat); found by
+     * tests/fuzz_parity.py (seed 5, case 1504) */
+    Prm b = d; b.max_scale = 2; b.diffusivity = 3; b.derivative_factor = 1.0f; b.dthreshold = 0.0005f; b.descriptor_pattern_size = 6;
+    total += run_case(754, 869, &b, 3000, 1);
+    b.diffusivity = 0;
+    total += run_case(720, 700, &b, 3000, 1);
     if (total < 200) { fprintf(stderr, "asan_main: the scenes hold too few keypoints (%d) to exercise the tail\n", total); return 1; }
     printf("asan_main: oracle clean\n");
     return 0;

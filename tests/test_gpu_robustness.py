@@ -576,3 +576,46 @@ def test_four_host_threads_four_contexts(ah, torch, synth):
         for f in ("match", "distance", "match_x", "match_y"):
             assert np.array_equal(b[f], c[f]), (k, f)
         j["det"].close()
+
+
+def test_calls_are_ordered_behind_the_callers_null_stream_work(ah, okz, torch, synth):
+    """the reference runs on the default stream, so what its caller enqueued there before a call (an asynchronous copy into the image, a
+    hipMemset of an output array) is done when the call starts (akaze.cpp:101-150); a context's streams are non-blocking, and every
+    entry point makes its stream wait for the NULL stream's work first (hak_set_null_order, default on).  Here: a 1 GiB fill, then a
+    device-to-device copy of ANOTHER image into the input buffer, both only enqueued on the NULL stream, then the call"""
+    w, h = 640, 480
+    p = ah.iAlignUp(w, 128)
+    a, b = (synth.to_float(_mg().case_scene(w, h, 900 + k), p) for k in range(2))
+    want_b = okz.detect_and_compute(b, w, max_pts=4000).points
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    work = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+    det = ah.Akazer()
+    det.init((w, h, p), max_pts=4000, batch=2)
+    data, data2 = ah.AkazeData(), ah.AkazeData()
+    ah.initAkazeData(data, 4000, True, True)
+    ah.initAkazeData(data2, 4000, True, True)
+    for entry in ("single", "pair", "batch"):
+        buf = da.clone()
+        det.detectAndCompute(buf.data_ptr(), data, (w, h, p), True)        # (the context has seen image a in this buffer)
+        torch.cuda.synchronize()
+        work.fill_(1.0)                                                    # ~0.3 ms of NULL-stream work in front of the copy
+        buf.copy_(db)
+        if entry == "single":
+            det.detectAndCompute(buf.data_ptr(), data, (w, h, p), True)
+            got = data.h_data[:data.num_pts]
+        elif entry == "pair":
+            det.detectAndComputePair(buf.data_ptr(), da.data_ptr(), data, data2, (w, h, p), True, True)
+            got = data.h_data[:data.num_pts]
+        else:
+            d_pts = torch.empty(4000 * 104, dtype=torch.uint8, device="cuda")
+            d_num = torch.empty(1, dtype=torch.int32, device="cuda")
+            d_pts.zero_()                                                  # an output cleared on the NULL stream, not waited for either
+            ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, buf.data_ptr(), h * p, p, 1, d_pts.data_ptr(), d_num.data_ptr(), 1))
+            ah.check(ah.lib.hak_sync(det.ctx))
+            n = int(d_num.cpu()[0])
+            got = d_pts.cpu().numpy().view(ah.POINT_DTYPE)[:n]
+        assert len(got) == len(want_b) > 100, entry
+        assert_points_equal(got, want_b)
+    ah.freeAkazeData(data)
+    ah.freeAkazeData(data2)
+    det.close()

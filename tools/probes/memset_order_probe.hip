@@ -65,5 +65,18 @@ int main()
         for (int i = 0; i < 64; i++) copy_stale += h[i] != 0xA0000000u + rep;
     }
     printf("hipMemcpy / hipMemcpy2D (pageable host -> device) then a kernel on a non-blocking stream: %d stale words in 10 x 128\n", copy_stale);
+    // ... and small ones (a context's parameter tables are a few KiB): 4 KiB, the kernel reads word 1023 - 16 t
+    int small_copy_stale = 0;
+    for (int rep = 0; rep < 20000; rep++) {
+        for (int i = 0; i < 1024; i++) hostbuf[i] = 0xB0000000u + rep;
+        hipMemcpy(buf, hostbuf, 4096, hipMemcpyHostToDevice);
+        k_read16<<<1, 64, 0, st>>>(buf, out);
+        hipStreamSynchronize(st);
+        hipMemcpy(h, out, 256, hipMemcpyDeviceToHost);
+        int stale = 0;
+        for (int i = 0; i < 64; i++) stale += h[i] != 0xB0000000u + rep;
+        small_copy_stale += stale != 0;
+    }
+    printf("hipMemcpy(4 KiB, pageable host -> device) then a kernel on a non-blocking stream: stale reads in %d of 20000 launches\n", small_copy_stale);
     return 0;
 }
