@@ -33,7 +33,9 @@ for sub in ("cuda-akaze_amd", "oracle", ""):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-KNOBS = ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM", "HAK_LEVEL_TILE")
+KNOBS = ("HAK_HESS_STREAM", "HAK_FUSE_SF", "HAK_BASE_STREAM", "HAK_LEVEL_TILE", "HAK_GRAPH", "HAK_SERIAL")
+# launch-order variants (read at hak_create, drawn last): the library's rule, every sequence as a replayed graph, never a graph, one stream
+ORDERS = {"": {}, "graph always": {"HAK_GRAPH": "2"}, "no graph": {"HAK_GRAPH": "0"}, "one stream": {"HAK_SERIAL": "1"}}
 MODES = {"size rule": {}, "streaming": {"HAK_HESS_STREAM": "2", "HAK_FUSE_SF": "2", "HAK_BASE_STREAM": "2", "HAK_LEVEL_TILE": "1"},
          "level tile": {"HAK_LEVEL_TILE": "2"}}
 FIELDS = ("x", "y", "octave", "response", "size", "angle", "features")
@@ -106,13 +108,14 @@ def draw_more(c, rng, pick):
     c["in_offset"] = pick((0, 0, 0, 1, 3))
     # a last call through the same Akazer with OTHER extents (akaze.cpp:109: the arena is rebuilt when the size differs from init)
     c["resize"] = (int(rng.integers(1, 40)), int(rng.integers(1, 40))) if rng.random() < 0.2 else None
+    c["order"] = pick(("", "", "", "graph always", "no graph", "one stream"))
     return c
 
 
 def describe(c):
     kw = ",".join(f"{k}={v}" for k, v in c["kw"].items())
     return (f"#{c['index']:<4d} {c['w']:4d}x{c['h']:<4d} B={c['B']:<2d} {c['mode']:<10s} max_pts={c['max_pts']:<5d} noise={c['noise']:<2d} "
-            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} {'resize ' if c['resize'] else ''}"
+            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} {'resize ' if c['resize'] else ''}{c['order'] + ' ' if c['order'] else ''}"
             f"{'pair(%.1f%s) ' % (c['pair'][0], ',pinned' if c['pair'][1] else '') if c['pair'] else ''}{kw}")
 
 
@@ -154,6 +157,7 @@ def run_case(ah, okz, torch, synth, mg, c):
     fails, npts, nmatch = [], 0, 0
     saved = {k: os.environ.pop(k, None) for k in KNOBS}
     os.environ.update(MODES[c["mode"]])
+    os.environ.update(ORDERS[c["order"]])
     det = ah.Akazer()
     try:
         det.init((w, h, p), max_pts=mp, batch=B, **kw)
