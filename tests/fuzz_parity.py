@@ -109,13 +109,17 @@ def draw_more(c, rng, pick):
     # a last call through the same Akazer with OTHER extents (akaze.cpp:109: the arena is rebuilt when the size differs from init)
     c["resize"] = (int(rng.integers(1, 40)), int(rng.integers(1, 40))) if rng.random() < 0.2 else None
     c["order"] = pick(("", "", "", "graph always", "no graph", "one stream"))
+    # uint8 images converted on the device (hak_ingest_u8 = main.cpp:149) in front of the float batch; results fetched with
+    # hak_download_batch into pinned / pageable host arrays
+    c["ingest"] = bool(rng.random() < 0.3)
+    c["download"] = pick((None, None, "pinned", "pageable"))
     return c
 
 
 def describe(c):
     kw = ",".join(f"{k}={v}" for k, v in c["kw"].items())
     return (f"#{c['index']:<4d} {c['w']:4d}x{c['h']:<4d} B={c['B']:<2d} {c['mode']:<10s} max_pts={c['max_pts']:<5d} noise={c['noise']:<2d} "
-            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} {'resize ' if c['resize'] else ''}{c['order'] + ' ' if c['order'] else ''}"
+            f"{'fast ' if c['fast'] else ''}{'' if c['desc'] else 'nodesc '}{'knn2 ' if c['knn2'] else ''}{'again ' if c['again'] else ''}pitch{c['pitch_mode']}+{c['in_offset']} {'resize ' if c['resize'] else ''}{c['order'] + ' ' if c['order'] else ''}{'ingest ' if c['ingest'] else ''}{'dl-' + c['download'] + ' ' if c['download'] else ''}"
             f"{'pair(%.1f%s) ' % (c['pair'][0], ',pinned' if c['pair'][1] else '') if c['pair'] else ''}{kw}")
 
 
@@ -209,6 +213,35 @@ def run_case(ah, okz, torch, synth, mg, c):
                 ok2 = all(not diff_points("", again[2 * k, :len(want[(2 * k) % nd])], okz.match(want[(2 * k) % nd].copy(), want[(2 * k + 1) % nd]), MFIELDS)
                           for k in range(B // 2))
                 fails.append(f"the same hak_match_batch launched a second time: {'equal to the oracle' if ok2 else 'still different'}; counts {nums.tolist()}")
+        # ---- the batch's results through hak_download_batch (counts + the valid prefix of every image's records)
+        if c["download"] and not fails:
+            if c["download"] == "pinned":
+                pp, pn = C.c_void_p(), C.c_void_p()
+                ah.check(ah.lib.hak_host_alloc(C.byref(pp), B * mp * 104))
+                ah.check(ah.lib.hak_host_alloc(C.byref(pn), B * 4))
+                ah.check(ah.lib.hak_download_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B, pp, pn))
+                hn = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_int)), shape=(B,)).copy()
+                hp = np.ctypeslib.as_array(C.cast(pp, C.POINTER(C.c_uint8)), shape=(B * mp * 104,)).view(ah.POINT_DTYPE).reshape(B, mp).copy()
+                ah.lib.hak_host_free(pp)
+                ah.lib.hak_host_free(pn)
+            else:
+                hp, hn = np.zeros((B, mp), ah.POINT_DTYPE), np.full(B, -1, np.int32)
+                ah.check(ah.lib.hak_download_batch(det.ctx, d_pts.data_ptr(), d_num.data_ptr(), B, hp.ctypes.data, hn.ctypes.data))
+            cur = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)          # (the records as they are now: the match leg has written its fields)
+            for i in range(B):
+                if hn[i] != nums[i] or hp[i, :nums[i]].tobytes() != cur[i, :nums[i]].tobytes():
+                    fails.append(f"hak_download_batch ({c['download']}): image {i} differs from the device records")
+        # ---- the same images as uint8, converted on the device (hak_ingest_u8: dst = (float)(src * (1.0 / 255.0)), main.cpp:149)
+        if c["ingest"] and not fails:
+            src8 = upload(range(B), True)
+            fbuf = torch.full((B * h * p,), float("nan"), dtype=torch.float32, device="cuda")
+            ah.check(ah.lib.hak_ingest_u8(det.ctx, src8.data_ptr() + off, h * pin, pin, fbuf.data_ptr(), h * p, p, w, h, B))
+            ah.check(ah.lib.hak_detect_and_compute_batch(det.ctx, fbuf.data_ptr(), h * p, p, B, d_pts.data_ptr(), d_num.data_ptr(), int(c["desc"])))
+            ah.check(ah.lib.hak_sync(det.ctx))
+            nums3 = d_num.cpu().numpy()
+            allp3 = d_pts.cpu().numpy().view(ah.POINT_DTYPE).reshape(B, mp)
+            for i in range(B):
+                fails += diff_points(f"device-side uint8 ingest, image {i}", allp3[i, :min(nums3[i], mp)], want[i % nd], fields)
         # ---- 2-NN + ratio + cross-check on the same device records
         if B >= 2 and c["desc"] and c["knn2"] and small_sets and not fails:
             ratio, cross = c["knn2"]
