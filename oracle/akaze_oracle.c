@@ -553,9 +553,11 @@ void okz_orient_point(OkzPoint* pt, const float* dxd, const float* dyd, int o, i
 {
     float resx[42], resy[42], re8x[42], re8y[42];
     for (int t = 0; t < 42; t++) { resx[t] = 0.f; resy[t] = 0.f; }
-    int step = (int)(pt->size + 0.5f);
-    int x = (int)(pt->x + 0.5f) >> o;
-    int y = (int)(pt->y + 0.5f) >> o;
+    /* (device casts: gRefine can leave NaN coordinates behind -- a determinant of inf - inf at a coarse level of a deep pyramid -- and the
+     * device turns them into 0 where a C cast is undefined; found by tests/fuzz_parity.py --huge) */
+    int step = okz_d2i(pt->size + 0.5f);
+    int x = okz_d2i(pt->x + 0.5f) >> o;
+    int y = okz_d2i(pt->y + 0.5f) >> o;
     for (int tix = 0; tix < 13 * 16; tix++) {
         int i = (tix & 15) - 6;
         int j = (tix / 16) - 6;
@@ -632,7 +634,7 @@ void okz_describe_point(OkzPoint* pt, const float* imd, const float* dxd, const 
     int size3 = (int)ceilf(2.0f * patsize / 3.0f);                      /* :2682 */
     int size4 = (int)ceilf(0.5f * patsize);                             /* :2683 */
     float iratio = 1.f / (1 << o);
-    int scale = (int)(pt->size + 0.5f);
+    int scale = okz_d2i(pt->size + 0.5f);
     float xf = pt->x * iratio;
     float yf = pt->y * iratio;
     float co, si;
@@ -648,8 +650,8 @@ void okz_describe_point(OkzPoint* pt, const float* imd, const float* dxd, const 
             if (m >= winsize) continue;
             int l = x - size2;
             int k = y - size2;
-            int xp = (int)(xf + scale * (k * co - l * si) + 0.5f);      /* :1921 */
-            int yp = (int)(yf + scale * (k * si + l * co) + 0.5f);      /* :1922 */
+            int xp = okz_d2i(xf + scale * (k * co - l * si) + 0.5f);    /* :1921 */
+            int yp = okz_d2i(yf + scale * (k * si + l * co) + 0.5f);    /* :1922 */
             xp = clampi(xp, 0, w - 1);
             yp = clampi(yp, 0, h - 1);
             size_t pos = (size_t)yp * p + xp;

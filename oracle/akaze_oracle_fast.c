@@ -389,8 +389,8 @@ void fkz_orient(FkPoint* pt, const int* dxd, const int* dyd, int o, int w, int h
 {
     float resx[42], resy[42], re8x[42], re8y[42];
     for (int t = 0; t < 42; t++) { resx[t] = 0.f; resy[t] = 0.f; }
-    int step = (int)(pt->size + 0.5f);
-    int x = (int)(pt->x + 0.5f) >> o, y = (int)(pt->y + 0.5f) >> o;
+    int step = f2i_sat(pt->size + 0.5f);
+    int x = f2i_sat(pt->x + 0.5f) >> o, y = f2i_sat(pt->y + 0.5f) >> o;
     for (int tix = 0; tix < 13 * 16; tix++) {
         int i = (tix & 15) - 6, j = (tix / 16) - 6, r2 = i * i + j * j;
         if (r2 >= 36) continue;
@@ -419,15 +419,15 @@ void fkz_describe(FkPoint* pt, const int* imd, const int* dxd, const int* dyd, i
     memset(acc, 0, sizeof(acc));
     int size2 = patsize, size3 = (int)ceilf(2.0f * patsize / 3.0f), size4 = (int)ceilf(0.5f * patsize);
     float iratio = 1.f / (1 << o);
-    int scale = (int)(pt->size + 0.5f);
+    int scale = f2i_sat(pt->size + 0.5f);
     float xf = pt->x * iratio, yf = pt->y * iratio, co, si;
     okz_sincosf(pt->angle, &si, &co);
     int winsize = 3 * size3 > 4 * size4 ? 3 * size3 : 4 * size4;
     for (int i = 0; i < winsize * winsize; i++) {
         int y = i / winsize, x = i - winsize * y, m = x > y ? x : y;
         int l = x - size2, k = y - size2;
-        int xp = clampi((int)(xf + scale * (k * co - l * si) + 0.5f), 0, w - 1);
-        int yp = clampi((int)(yf + scale * (k * si + l * co) + 0.5f), 0, h - 1);
+        int xp = clampi(f2i_sat(xf + scale * (k * co - l * si) + 0.5f), 0, w - 1);
+        int yp = clampi(f2i_sat(yf + scale * (k * si + l * co) + 0.5f), 0, h - 1);
         size_t pos = (size_t)yp * p + xp;
         int im = imd[pos], dx = dxd[pos], dy = dyd[pos];
         int rx = f2i_sat(wneg(dx) * si + dy * co);                           /* akazed.cu:3777 */
